@@ -1,0 +1,115 @@
+/*
+ * scda_ops.h -- C ABI of libscda_ops.so, the MI355X (gfx950) implementation of
+ * the SCDA Faster-R-CNN hot path.
+ *
+ * This is the drop-in boundary: every entry point replaces one function that
+ * the reference exported through torch.utils.ffi (cffi) or Cython; the
+ * reference declaration it replaces is cited as  <file>:<line>  relative to the
+ * reference tree.  INTEGRATION.md shows the ctypes stub that binds each one.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every data pointer is a DEVICE pointer
+ *     (hipMalloc'd / torch CUDA tensor .data_ptr()) unless the name ends in _host
+ *   - the caller owns and allocates every output and workspace buffer
+ *     (reference convention: Python allocates keep/num_out/output/argmax/...,
+ *     extensions/_roi_pooling/functions/roi_pool.py:19-22)
+ *   - `stream` is a hipStream_t passed as void* (NULL = legacy default stream);
+ *     all work is enqueued asynchronously on it, nothing synchronises
+ *   - return value: 0 = ok, <0 = error (SCDA_E*), never exit(): the reference's
+ *     "1 = ok / 0 = bad shape / exit(-1) on launch failure"
+ *     (roi_pooling_cuda.c:20-23, roi_pooling_kernel.cu:117-122) becomes a status
+ *   - all tensors are contiguous, row-major, fp32 unless stated
+ */
+#ifndef SCDA_OPS_H
+#define SCDA_OPS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCDA_OK 0
+#define SCDA_EINVAL (-1)  /* bad shape / null pointer / unsupported size */
+#define SCDA_ELAUNCH (-2) /* hipGetLastError() != hipSuccess after a launch */
+#define SCDA_ENODEV (-3)  /* no HIP device */
+
+/* library / device probes (no compute) */
+int scda_version(void);
+int scda_device_count(void);
+const char *scda_last_error(void);
+
+/* ---------------------------------------------------------------- NMS ---- */
+/* replaces  int gpu_nms(THLongTensor* keep, THLongTensor* num_out, THCudaTensor* boxes, float thresh)
+ *           extensions/_nms/src/nms_cuda.h:1, nms_cuda.c:17-67, cuda/nms_kernel.cu:26-83
+ * boxes   [n,5] (x1,y1,x2,y2,score) sorted by score descending
+ * mask_ws  workspace, scda_nms_workspace_bytes(n) bytes
+ * keep    int64 [n]   indices of kept boxes, ascending            (device)
+ * num_out int64 [1]   number of valid entries in keep             (device)
+ * max_keep  <=0: full sweep (reference semantics); >0: stop after max_keep
+ *           kept boxes (identical to truncating the full result, which is what
+ *           both call sites do: functions/rpn_proposal.py:65-66)
+ * Unlike the reference nothing is copied to the host: the greedy sweep
+ * (nms_cuda.c:47-58) also runs on the device.                                */
+size_t scda_nms_workspace_bytes(int n);
+int scda_nms_hip(const float *boxes, int n, float thresh, void *mask_ws, int64_t *keep, int64_t *num_out,
+                 int max_keep, void *stream);
+/* the pairwise suppression bit-mask alone (upper triangle of col-blocks only):
+ * mask uint64 [n, ceil(n/64)]                                                */
+int scda_nms_mask_hip(const float *boxes, int n, float thresh, uint64_t *mask, void *stream);
+
+/* ------------------------------------------------------------ RoIPool ---- */
+/* replaces  int roi_pooling_forward_cuda(int ph,int pw,float scale, THCudaTensor* features,
+ *               THCudaTensor* rois, THCudaTensor* output, THCudaIntTensor* argmax)
+ *           extensions/_roi_pooling/src/roi_pooling_cuda.h:1-2, roi_pooling_kernel.cu:24-125
+ * features [B,C,H,W], rois [R,5] (batch,x1,y1,x2,y2), out [R,C,PH,PW],
+ * argmax int32 [R,C,PH,PW] (flat index into features, -1 = empty bin; may be NULL) */
+int scda_roi_pool_fwd_hip(const float *features, const float *rois, int R, int B, int C, int H, int W, int PH, int PW,
+                          float spatial_scale, float *out, int32_t *argmax, void *stream);
+/* replaces  int roi_pooling_backward_cuda(..., top_grad, rois, bottom_grad, argmax)
+ *           roi_pooling_cuda.h:4-5, roi_pooling_kernel.cu:128-234
+ * bottom_grad [B,C,H,W] is fully overwritten (need not be zeroed).
+ * Summation order per input element: roi ascending, ph ascending, pw ascending
+ * -- the reference's order, so the result is bit-identical.                    */
+int scda_roi_pool_bwd_hip(const float *top_grad, const int32_t *argmax, const float *rois, int R, int B, int C, int H,
+                          int W, int PH, int PW, float spatial_scale, float *bottom_grad, void *stream);
+
+/* ----------------------------------------------------------- RoIAlign ---- */
+/* replaces  roi_align_forward_cuda / roi_align_backward_cuda
+ *           extensions/_roi_align/src/roi_align_cuda.h:1-5, roi_align_kernel.cu:15-162
+ * out [R,C,AH,AW]; bottom_grad [B,C,H,W] must be zeroed by the caller
+ * (reference convention, functions/roi_align.py:40-41; the kernel accumulates) */
+int scda_roi_align_fwd_hip(const float *features, const float *rois, int R, int B, int C, int H, int W, int AH, int AW,
+                           float spatial_scale, float *out, void *stream);
+int scda_roi_align_bwd_hip(const float *top_grad, const float *rois, int R, int B, int C, int H, int W, int AH,
+                           int AW, float spatial_scale, float *bottom_grad, void *stream);
+
+/* --------------------------------------------------------- focal loss ---- */
+/* replaces the four functions of extensions/_focal_loss/src/focal_loss_cuda.h:2-43
+ * N = rows*num_classes; logits [rows,num_classes]; targets int32 [rows]
+ * (-1 ignore, 0 background, 1..C foreground)                                  */
+int scda_focal_sigmoid_fwd_hip(int N, const float *logits, const int32_t *targets, float weight_pos, float gamma,
+                               float alpha, int num_classes, float *losses /*[N]*/, void *stream);
+int scda_focal_sigmoid_bwd_hip(int N, const float *logits, const int32_t *targets, float *dX /*[N]*/,
+                               float weight_pos, float gamma, float alpha, int num_classes, void *stream);
+int scda_focal_softmax_fwd_hip(int N, const float *logits, const int32_t *targets, float weight_pos, float gamma,
+                               float alpha, int num_classes, float *losses /*[rows]*/, float *priors /*[N]*/,
+                               void *stream);
+int scda_focal_softmax_bwd_hip(int N, const float *logits, const int32_t *targets, float *dX /*[N]*/,
+                               float weight_pos, float gamma, float alpha, int num_classes,
+                               const float *priors /*[N]*/, float *buff /*[rows]*/, void *stream);
+
+/* -------------------------------------------------------- box overlaps ---- */
+/* replaces  int gpu_iou_overlaps(THCudaTensor* b1, THCudaTensor* b2, THCudaTensor* out)
+ *           extensions/_bbox_helper/src/bbox_helper_cuda.h:1, cuda/iou_overlap_kernel.cu:33-100
+ * (no +1, union clamped to >= 1)                                              */
+int scda_iou_overlaps_hip(const float *b1, const float *b2, int size_bbox, int n1, int n2, float *out, void *stream);
+/* replaces  cython_bbox.bbox_overlaps(boxes f32[N,4], query f32[K,4]) -> f32[N,K]
+ *           extensions/_cython_bbox/cython_bbox.pyx:32-73   (no +1, 0 unless iw>0 and ih>0) */
+int scda_bbox_overlaps_hip(const float *boxes, int N, const float *query, int K, float *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCDA_OPS_H */

@@ -1,0 +1,656 @@
+// detection_ops.hip -- NMS, RoIPool, RoIAlign, focal loss and box-overlap
+// kernels for gfx950 (wave64), behind the C ABI of include/scda_ops.h.
+//
+// All of these are HBM/L2-bound integer-and-compare work; none is GEMM shaped.
+// This translation unit is compiled with -ffp-contract=off: the operators are
+// defined (oracle/scda_oracle.c) as one IEEE fp32 operation per source operator,
+// and the NMS keep list / RoIPool argmax must be bit-identical to that.
+#include <float.h>
+#include <stdarg.h>
+
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+namespace scda {
+
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ---------------------------------------------------------------------------
+// NMS.  Reference: extensions/_nms/src/cuda/nms_kernel.cu:16-70 (bit mask) and
+// extensions/_nms/src/nms_cuda.c:47-58 (greedy sweep, on the host there).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float iou_plus1(const float *a, const float *b) {
+    float left = fmaxf(a[0], b[0]), right = fminf(a[2], b[2]);
+    float top = fmaxf(a[1], b[1]), bottom = fminf(a[3], b[3]);
+    float width = fmaxf(right - left + 1.f, 0.f), height = fmaxf(bottom - top + 1.f, 0.f);
+    float interS = width * height;
+    float Sa = (a[2] - a[0] + 1.f) * (a[3] - a[1] + 1.f);
+    float Sb = (b[2] - b[0] + 1.f) * (b[3] - b[1] + 1.f);
+    return __fdiv_rn(interS, (Sa + Sb - interS));
+}
+
+// One wave per (row block, column block) of 64x64 box pairs; a 64-wide block is
+// exactly one gfx950 wavefront, so the 64 column boxes sit in LDS and every lane
+// owns one row box and emits one 64-bit word.  Only col_block >= row_block is
+// computed: the sweep never reads the lower triangle (nms_cuda.c:53 starts at
+// j = nblock); those workgroups exit at once.
+__global__ __launch_bounds__(64) void nms_mask_kernel(const int n, const float thresh, const float *__restrict__ boxes,
+                                                       uint64_t *__restrict__ mask, const int col_blocks) {
+    const int row_start = blockIdx.y;
+    const int col_start = blockIdx.x;
+    if (col_start < row_start) return;  // lower triangle is never read by the sweep
+    const int row_size = min(n - row_start * 64, 64);
+    const int col_size = min(n - col_start * 64, 64);
+
+    __shared__ float bb[64 * 5];
+    // 320 contiguous floats of the column block: 5 coalesced passes of 64 lanes
+    const float *src = boxes + (size_t)col_start * 64 * 5;
+    for (int k = threadIdx.x; k < col_size * 5; k += 64) bb[k] = src[k];
+    __syncthreads();
+
+    if ((int)threadIdx.x < row_size) {
+        const int cur = row_start * 64 + threadIdx.x;
+        float me[4];
+        me[0] = boxes[(size_t)cur * 5 + 0];
+        me[1] = boxes[(size_t)cur * 5 + 1];
+        me[2] = boxes[(size_t)cur * 5 + 2];
+        me[3] = boxes[(size_t)cur * 5 + 3];
+        uint64_t bits = 0;
+        const int start = (row_start == col_start) ? (int)threadIdx.x + 1 : 0;
+        for (int i = 0; i < col_size; ++i) {  // uniform trip count: LDS reads broadcast
+            float v = iou_plus1(me, bb + i * 5);
+            if (i >= start && v > thresh) bits |= 1ULL << i;
+        }
+        mask[(size_t)cur * col_blocks + col_start] = bits;
+    }
+}
+
+// Greedy sweep on the device: one 256-thread workgroup walks the 64-box chunks.
+// Per chunk, wave 0 resolves the 64 in-chunk decisions from the diagonal word
+// (a 64-step scalar recurrence over v_readlane), then all waves OR the kept
+// boxes' mask rows into the LDS-resident "removed" bit vector.
+__global__ __launch_bounds__(256) void nms_sweep_kernel(const uint64_t *__restrict__ mask, const int n,
+                                                        const int col_blocks, int64_t *__restrict__ keep,
+                                                        int64_t *__restrict__ num_out, const int max_keep) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint64_t *remv = reinterpret_cast<uint64_t *>(smem_raw);  // [col_blocks]
+    uint64_t *bcast = remv + col_blocks;                       // [2]: kept mask, stop flag
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    for (int i = tid; i < col_blocks; i += 256) remv[i] = 0;
+    if (tid == 0) { bcast[0] = 0; bcast[1] = 0; }
+    __syncthreads();
+
+    int count = 0;  // kept so far (tracked redundantly by every thread)
+    // diagonal word of this lane's box in the chunk being processed (wave 0 only)
+    uint64_t diag = 0;
+    if (tid < 64 && tid < n) diag = mask[(size_t)tid * col_blocks + 0];
+
+    for (int b = 0; b < col_blocks; ++b) {
+        const int base = b * 64;
+        if (tid < 64) {
+            // prefetch next chunk's diagonal words while this chunk is resolved
+            uint64_t next_diag = 0;
+            const int nb = base + 64 + lane;
+            if (b + 1 < col_blocks && nb < n) next_diag = mask[(size_t)nb * col_blocks + (b + 1)];
+
+            const int size = min(n - base, 64);
+            uint64_t removed = remv[b];
+            uint64_t kept = 0;
+            const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
+            for (int j = 0; j < size; ++j) {  // branch-free 64-step recurrence
+                const uint64_t d = ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)dhi, j) << 32) |
+                                   (uint64_t)(unsigned)__builtin_amdgcn_readlane((int)dlo, j);
+                const uint64_t alive = ((removed >> j) & 1ULL) ^ 1ULL;
+                kept |= alive << j;
+                removed |= d & (0ULL - alive);
+            }
+            // truncate to max_keep (indices are emitted in ascending order)
+            int nk = __popcll(kept);
+            if (max_keep > 0 && count + nk > max_keep) {
+                int allow = max_keep - count;
+                uint64_t k2 = kept, out = 0;
+                for (int c = 0; c < allow; ++c) { uint64_t low = k2 & (~k2 + 1); out |= low; k2 ^= low; }
+                kept = out;
+                nk = allow;
+            }
+            if ((kept >> lane) & 1ULL) {
+                int pos = count + __popcll(kept & ((1ULL << lane) - 1ULL));
+                keep[pos] = base + lane;
+            }
+            if (lane == 0) {
+                bcast[0] = kept;
+                bcast[1] = (max_keep > 0 && count + nk >= max_keep) ? 1 : 0;
+            }
+            diag = next_diag;
+        }
+        __syncthreads();
+        const uint64_t kept = bcast[0];
+        const bool stop = bcast[1] != 0;
+        count += __popcll(kept);
+        if (stop) break;
+        // OR the kept rows into remv for the columns still ahead
+        for (int cb = b + 1 + tid; cb < col_blocks; cb += 256) {
+            uint64_t acc = remv[cb];
+            uint64_t k = kept;
+            while (k) {
+                // up to 4 independent row loads in flight per step
+                uint64_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+                int j0 = __ffsll((long long)k) - 1; k &= k - 1;
+                v0 = mask[(size_t)(base + j0) * col_blocks + cb];
+                if (k) { int j = __ffsll((long long)k) - 1; k &= k - 1; v1 = mask[(size_t)(base + j) * col_blocks + cb]; }
+                if (k) { int j = __ffsll((long long)k) - 1; k &= k - 1; v2 = mask[(size_t)(base + j) * col_blocks + cb]; }
+                if (k) { int j = __ffsll((long long)k) - 1; k &= k - 1; v3 = mask[(size_t)(base + j) * col_blocks + cb]; }
+                acc |= v0 | v1 | v2 | v3;
+            }
+            remv[cb] = acc;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) num_out[0] = count;
+}
+
+// ---------------------------------------------------------------------------
+// RoI max pooling.  Reference: extensions/_roi_pooling/src/roi_pooling_kernel.cu
+// ---------------------------------------------------------------------------
+struct RoiRect { int b, sw, sh, ew, eh; };
+
+__device__ __forceinline__ RoiRect roi_rect(const float *roi, float scale) {
+    RoiRect r;
+    r.b = (int)roi[0];
+    r.sw = (int)roundf(roi[1] * scale);  // half away from zero, roi_pooling_kernel.cu:46-49
+    r.sh = (int)roundf(roi[2] * scale);
+    r.ew = (int)roundf(roi[3] * scale);
+    r.eh = (int)roundf(roi[4] * scale);
+    return r;
+}
+
+// One thread per output element (n,c,ph,pw); consecutive threads write
+// consecutive outputs (coalesced 2x 4B streams: value + argmax).  The feature
+// map of config 2 is 4 MB and stays L2-resident, so the window scans hit cache.
+__global__ __launch_bounds__(256) void roi_pool_fwd_kernel(const long long total, const float *__restrict__ feat,
+                                                           const float scale, const int C, const int H, const int W,
+                                                           const int PH, const int PW,
+                                                           const float *__restrict__ rois, float *__restrict__ out,
+                                                           int32_t *__restrict__ argmax) {
+    for (long long index = blockIdx.x * (long long)blockDim.x + threadIdx.x; index < total;
+         index += (long long)blockDim.x * gridDim.x) {
+        const int pw = (int)(index % PW);
+        const int ph = (int)((index / PW) % PH);
+        const int c = (int)((index / PW / PH) % C);
+        const int n = (int)(index / PW / PH / C);
+        const RoiRect r = roi_rect(rois + (size_t)n * 5, scale);
+        const int roi_w = (int)fmaxf((float)(r.ew - r.sw + 1), 1.f);
+        const int roi_h = (int)fmaxf((float)(r.eh - r.sh + 1), 1.f);
+        const float bin_h = __fdiv_rn((float)roi_h, (float)PH);
+        const float bin_w = __fdiv_rn((float)roi_w, (float)PW);
+        int hstart = (int)floorf((float)ph * bin_h);
+        int wstart = (int)floorf((float)pw * bin_w);
+        int hend = (int)ceilf((float)(ph + 1) * bin_h);
+        int wend = (int)ceilf((float)(pw + 1) * bin_w);
+        hstart = min(max(hstart + r.sh, 0), H);
+        hend = min(max(hend + r.sh, 0), H);
+        wstart = min(max(wstart + r.sw, 0), W);
+        wend = min(max(wend + r.sw, 0), W);
+        const bool empty = (hend <= hstart) || (wend <= wstart);
+        float maxval = empty ? 0.f : -FLT_MAX;
+        int maxidx = -1;
+        const int base = (r.b * C + c) * H * W;
+        for (int h = hstart; h < hend; ++h)
+            for (int w = wstart; w < wend; ++w) {
+                const int idx = base + h * W + w;
+                const float v = feat[idx];
+                if (v > maxval) { maxval = v; maxidx = idx; }
+            }
+        out[index] = maxval;
+        if (argmax) argmax[index] = maxidx;
+    }
+}
+
+// Backward, gather form with the reference's summation order (roi, ph, pw
+// ascending) so the fp32 sums are bit-identical.  The integer RoI rectangles
+// are computed once per workgroup into LDS (R x 5 ints) instead of once per
+// (thread, roi) as the reference does.
+__global__ __launch_bounds__(256) void roi_pool_bwd_kernel(const int total, const float *__restrict__ top,
+                                                           const int32_t *__restrict__ argmax, const int R,
+                                                           const float scale, const int C, const int H, const int W,
+                                                           const int PH, const int PW, float *__restrict__ bottom,
+                                                           const float *__restrict__ rois) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    int *rect = reinterpret_cast<int *>(smem_raw);  // [R][5]
+    for (int r = threadIdx.x; r < R; r += blockDim.x) {
+        RoiRect q = roi_rect(rois + (size_t)r * 5, scale);
+        rect[r * 5 + 0] = q.b; rect[r * 5 + 1] = q.sw; rect[r * 5 + 2] = q.sh; rect[r * 5 + 3] = q.ew; rect[r * 5 + 4] = q.eh;
+    }
+    __syncthreads();
+    const int index = blockIdx.x * blockDim.x + threadIdx.x;
+    if (index >= total) return;
+    const int w = index % W;
+    const int h = (index / W) % H;
+    const int c = (index / W / H) % C;
+    const int n = index / W / H / C;
+    float g = 0.f;
+    const int bins = PH * PW;
+    for (int r = 0; r < R; ++r) {
+        const int *q = rect + r * 5;  // uniform address: LDS broadcast
+        if (q[0] != n) continue;
+        const int sw = q[1], sh = q[2], ew = q[3], eh = q[4];
+        if (!(w >= sw && w <= ew && h >= sh && h <= eh)) continue;
+        const int roi_w = (int)fmaxf((float)(ew - sw + 1), 1.f);
+        const int roi_h = (int)fmaxf((float)(eh - sh + 1), 1.f);
+        const float bin_h = __fdiv_rn((float)roi_h, (float)PH);
+        const float bin_w = __fdiv_rn((float)roi_w, (float)PW);
+        int phs = (int)floorf(__fdiv_rn((float)(h - sh), bin_h));
+        int phe = (int)ceilf(__fdiv_rn((float)(h - sh + 1), bin_h));
+        int pws = (int)floorf(__fdiv_rn((float)(w - sw), bin_w));
+        int pwe = (int)ceilf(__fdiv_rn((float)(w - sw + 1), bin_w));
+        phs = min(max(phs, 0), PH); phe = min(max(phe, 0), PH);
+        pws = min(max(pws, 0), PW); pwe = min(max(pwe, 0), PW);
+        const size_t off = ((size_t)r * C + c) * bins;
+        for (int ph = phs; ph < phe; ++ph)
+            for (int pw = pws; pw < pwe; ++pw) {
+                const size_t o = off + ph * PW + pw;
+                if (argmax[o] == index) g += top[o];
+            }
+    }
+    bottom[index] = g;
+}
+
+// ---------------------------------------------------------------------------
+// RoIAlign (old single-sample form).  Reference: extensions/_roi_align/src/roi_align_kernel.cu
+// The reference mixes float and double literals; the double sub-expressions are
+// kept in double so roundings happen where nvcc placed them.
+// ---------------------------------------------------------------------------
+struct RaPoint { bool ok; int upleft; float hr, wr; };
+
+__device__ __forceinline__ RaPoint ra_point(const float *roi, float scale, int C, int H, int W, int AH, int AW, int c,
+                                            int ph, int pw) {
+    RaPoint p; p.ok = false; p.upleft = 0; p.hr = p.wr = 0.f;
+    const float bi = roi[0];
+    const float sw = roi[1] * scale, sh = roi[2] * scale, ew = roi[3] * scale, eh = roi[4] * scale;
+    const float roi_w = fmaxf((float)((double)(ew - sw) + 1.), 0.f);
+    const float roi_h = fmaxf((float)((double)(eh - sh) + 1.), 0.f);
+    const float bin_h = (float)((double)roi_h / ((double)AH - 1.));
+    const float bin_w = (float)((double)roi_w / ((double)AW - 1.));
+    const float h = (float)ph * bin_h + sh;
+    const float w = (float)pw * bin_w + sw;
+    const int hstart = (int)fminf(floorf(h), (float)(H - 2));
+    const int wstart = (int)fminf(floorf(w), (float)(W - 2));
+    const int img_start = (int)(bi * (float)(C * H * W));
+    if (h < 0 || h >= H || w < 0 || w >= W) return p;
+    p.ok = true;
+    p.hr = h - (float)hstart;
+    p.wr = w - (float)wstart;
+    p.upleft = img_start + (c * H + hstart) * W + wstart;
+    return p;
+}
+
+__global__ __launch_bounds__(256) void roi_align_fwd_kernel(const long long total, const float *__restrict__ feat,
+                                                            const float scale, const int C, const int H, const int W,
+                                                            const int AH, const int AW, const float *__restrict__ rois,
+                                                            float *__restrict__ out) {
+    for (long long index = blockIdx.x * (long long)blockDim.x + threadIdx.x; index < total;
+         index += (long long)blockDim.x * gridDim.x) {
+        const int pw = (int)(index % AW);
+        const int ph = (int)((index / AW) % AH);
+        const int c = (int)((index / AW / AH) % C);
+        const int n = (int)(index / AW / AH / C);
+        const RaPoint p = ra_point(rois + (size_t)n * 5, scale, C, H, W, AH, AW, c, ph, pw);
+        if (!p.ok) { out[index] = 0.f; continue; }
+        const double hr = p.hr, wr = p.wr;
+        const double v = (double)feat[p.upleft] * (1. - hr) * (1. - wr) + (double)feat[p.upleft + 1] * (1. - hr) * wr +
+                         (double)feat[p.upleft + W] * hr * (1. - wr) + (double)feat[p.upleft + W + 1] * hr * wr;
+        out[index] = (float)v;
+    }
+}
+
+__global__ __launch_bounds__(256) void roi_align_bwd_kernel(const long long total, const float *__restrict__ top,
+                                                            const float scale, const int C, const int H, const int W,
+                                                            const int AH, const int AW, float *__restrict__ bottom,
+                                                            const float *__restrict__ rois) {
+    for (long long index = blockIdx.x * (long long)blockDim.x + threadIdx.x; index < total;
+         index += (long long)blockDim.x * gridDim.x) {
+        const int pw = (int)(index % AW);
+        const int ph = (int)((index / AW) % AH);
+        const int c = (int)((index / AW / AH) % C);
+        const int n = (int)(index / AW / AH / C);
+        const RaPoint p = ra_point(rois + (size_t)n * 5, scale, C, H, W, AH, AW, c, ph, pw);
+        if (!p.ok) continue;
+        const double hr = p.hr, wr = p.wr, d = top[index];
+        atomicAdd(bottom + p.upleft, (float)(d * (1. - hr) * (1 - wr)));
+        atomicAdd(bottom + p.upleft + 1, (float)(d * (1. - hr) * wr));
+        atomicAdd(bottom + p.upleft + W, (float)(d * hr * (1 - wr)));
+        atomicAdd(bottom + p.upleft + W + 1, (float)(d * hr * wr));
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Focal loss.  Reference: extensions/_focal_loss/src/cuda/focal_loss_{sigmoid,softmax}_kernel.cu
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void focal_sigmoid_fwd_kernel(const int N, const float *__restrict__ logits,
+                                                                const int32_t *__restrict__ targets,
+                                                                const float weight_pos, const float gamma,
+                                                                const float alpha, const int num_classes,
+                                                                float *__restrict__ losses) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += blockDim.x * gridDim.x) {
+        const int d = i % num_classes;
+        const int t = targets[i / num_classes];
+        const float c1 = (t == (d + 1));
+        const float c2 = ((t != -1) & (t != (d + 1)));
+        const float Np = (float)fmax((double)weight_pos, 1.0);
+        const float zn = (float)((1.0 - (double)alpha) / (double)Np);
+        const float zp = alpha / Np;
+        const float x = logits[i];
+        const float p = (float)(1. / (1. + (double)expf(-x)));
+        const float term1 = (float)((double)powf((float)(1. - (double)p), gamma) * (double)logf(fmaxf(p, FLT_MIN)));
+        const float ge = (x >= 0);
+        const float term2 =
+            (float)((double)powf(p, gamma) *
+                    (-1. * (double)x * (double)ge -
+                     (double)logf((float)(1. + (double)expf((float)((double)x - 2. * (double)x * (double)ge))))));
+        float l = 0.0f;
+        l += -c1 * term1 * zp;
+        l += -c2 * term2 * zn;
+        losses[i] = l;
+    }
+}
+
+__global__ __launch_bounds__(256) void focal_sigmoid_bwd_kernel(const int N, const float *__restrict__ logits,
+                                                                const int32_t *__restrict__ targets,
+                                                                float *__restrict__ dX, const float weight_pos,
+                                                                const float gamma, const float alpha,
+                                                                const int num_classes) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += blockDim.x * gridDim.x) {
+        const int d = i % num_classes;
+        const int t = targets[i / num_classes];
+        const float Np = (float)fmax((double)weight_pos, 1.0);
+        const float zn = (float)((1.0 - (double)alpha) / (double)Np);
+        const float zp = alpha / Np;
+        const float c1 = (t == (d + 1));
+        const float c2 = ((t != -1) & (t != (d + 1)));
+        const float x = logits[i];
+        const float p = (float)(1. / (1. + (double)expf(-x)));
+        const float term1 = (float)((double)powf((float)(1. - (double)p), gamma) *
+                                    (1. - (double)p - (double)(p * gamma * logf(fmaxf(p, FLT_MIN)))));
+        const float ge = (x >= 0);
+        const double lg = -1. * (double)x * (double)ge -
+                          (double)logf((float)(1. + (double)expf((float)((double)x - 2. * (double)x * (double)ge))));
+        const float term2 = (float)((double)powf(p, gamma) * (lg * (1. - (double)p) * (double)gamma - (double)p));
+        float g = 0.0f;
+        g += -c1 * zp * term1;
+        g += -c2 * zn * term2;
+        dX[i] = g;
+    }
+}
+
+// softmax + per-row loss fused in one pass (the reference launches two kernels)
+__global__ __launch_bounds__(256) void focal_softmax_fwd_kernel(const int rows, const float *__restrict__ X,
+                                                                const int32_t *__restrict__ targets,
+                                                                const float weight_pos, const float gamma,
+                                                                const float alpha, const int num_classes,
+                                                                float *__restrict__ losses, float *__restrict__ P) {
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += blockDim.x * gridDim.x) {
+        const int base = r * num_classes;
+        float mx = -FLT_MAX;
+        for (int c = 0; c < num_classes; ++c) mx = fmaxf(mx, X[base + c]);
+        float es = 0.0f;
+        for (int c = 0; c < num_classes; ++c) { float e = expf(X[base + c] - mx); P[base + c] = e; es += e; }
+        for (int c = 0; c < num_classes; ++c) P[base + c] = __fdiv_rn(P[base + c], es);
+        const int label = targets[r];
+        const float Np = (float)fmax((double)weight_pos, 1.0);
+        const float z = (label == 0) * (1 - alpha) / Np + (label >= 1) * alpha / Np;
+        float l = 0.0f;
+        if (label >= 0) {
+            const float pl = P[base + label];
+            l = -(powf((float)(1.0 - (double)pl), gamma) * logf(fmaxf(pl, FLT_MIN))) * z;
+        }
+        losses[r] = l;
+    }
+}
+
+__global__ __launch_bounds__(256) void focal_softmax_bwd_weight_kernel(const int rows, const float *__restrict__ P,
+                                                                       const int32_t *__restrict__ targets,
+                                                                       float *__restrict__ buff,
+                                                                       const float weight_pos, const float gamma,
+                                                                       const float alpha, const int num_classes) {
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += blockDim.x * gridDim.x) {
+        const int base = r * num_classes, label = targets[r];
+        const float Np = (float)fmax((double)weight_pos, 1.0);
+        const float z = (label == 0) * (1 - alpha) / Np + (label >= 1) * alpha / Np;
+        float b = 0.0f;
+        if (label >= 0) {
+            const float onemp = (float)(1. - (double)P[base + label]);
+            const float p = P[base + label];
+            b = (-powf(onemp, gamma) + gamma * powf(onemp, gamma - 1) * p * logf(fmaxf(p, FLT_MIN))) * z;
+        }
+        buff[r] = b;
+    }
+}
+
+__global__ __launch_bounds__(256) void focal_softmax_bwd_kernel(const int N, const float *__restrict__ P,
+                                                                const int32_t *__restrict__ targets,
+                                                                const float *__restrict__ buff,
+                                                                float *__restrict__ dX, const int num_classes) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += blockDim.x * gridDim.x) {
+        const int ind = i / num_classes, cls = i % num_classes;
+        const int label = targets[ind];
+        const float c1 = (float)((label >= 0) * 1.0), c2 = (float)((label == cls) * 1.0);
+        dX[i] = c1 * buff[ind] * (c2 - P[i]);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Box overlap matrices
+// ---------------------------------------------------------------------------
+// extensions/_bbox_helper/src/cuda/iou_overlap_kernel.cu:33-65
+__global__ __launch_bounds__(256) void iou_overlaps_kernel(const float *__restrict__ b1, const float *__restrict__ b2,
+                                                           const int sz, const int n1, const int n2,
+                                                           float *__restrict__ out) {
+    const long long total = (long long)n1 * n2;
+    for (long long index = blockIdx.x * (long long)blockDim.x + threadIdx.x; index < total;
+         index += (long long)blockDim.x * gridDim.x) {
+        const int i = (int)(index / n2), j = (int)(index % n2);
+        const float *p = b1 + (size_t)i * sz, *q = b2 + (size_t)j * sz;
+        const float a1 = (p[2] - p[0]) * (p[3] - p[1]), a2 = (q[2] - q[0]) * (q[3] - q[1]);
+        const float left = fmaxf(p[0], q[0]), right = fminf(p[2], q[2]);
+        const float top = fmaxf(p[1], q[1]), bottom = fminf(p[3], q[3]);
+        const float width = fmaxf(right - left, 0.f), height = fmaxf(bottom - top, 0.f);
+        const float interS = width * height;
+        const float unionS = fmaxf(a1 + a2 - interS, 1.0f);
+        out[index] = __fdiv_rn(interS, unionS);
+    }
+}
+
+// extensions/_cython_bbox/cython_bbox.pyx:32-73
+__global__ __launch_bounds__(256) void bbox_overlaps_kernel(const float *__restrict__ boxes, const int N,
+                                                            const float *__restrict__ query, const int K,
+                                                            float *__restrict__ out) {
+    const long long total = (long long)N * K;
+    for (long long index = blockIdx.x * (long long)blockDim.x + threadIdx.x; index < total;
+         index += (long long)blockDim.x * gridDim.x) {
+        const int n = (int)(index / K), k = (int)(index % K);
+        const float *b = boxes + (size_t)n * 4, *q = query + (size_t)k * 4;
+        const float box_area = (q[2] - q[0]) * (q[3] - q[1]);
+        float o = 0.f;
+        const float iw = fminf(b[2], q[2]) - fmaxf(b[0], q[0]);
+        if (iw > 0) {
+            const float ih = fminf(b[3], q[3]) - fmaxf(b[1], q[1]);
+            if (ih > 0) {
+                const float ua = (b[2] - b[0]) * (b[3] - b[1]) + box_area - iw * ih;
+                o = __fdiv_rn(iw * ih, ua);
+            }
+        }
+        out[index] = o;
+    }
+}
+
+}  // namespace scda
+
+using namespace scda;
+
+// ============================= C ABI ========================================
+SCDA_API int scda_version(void) { return 100; }
+
+SCDA_API int scda_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+SCDA_API const char *scda_last_error(void) { return g_err; }
+
+SCDA_API size_t scda_nms_workspace_bytes(int n) {
+    if (n <= 0) return 0;
+    const size_t cb = (size_t)(n + 63) / 64;
+    return (size_t)n * cb * sizeof(uint64_t);
+}
+
+SCDA_API int scda_nms_mask_hip(const float *boxes, int n, float thresh, uint64_t *mask, void *stream) {
+    if (n < 0 || (n > 0 && (!boxes || !mask))) { set_error("scda_nms_mask_hip: bad arguments"); return SCDA_EINVAL; }
+    if (n == 0) return SCDA_OK;
+    const int cb = (n + 63) / 64;
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(cb, cb), dim3(64), 0, as_stream(stream), n, thresh, boxes, mask, cb);
+    return launch_status("nms_mask_kernel");
+}
+
+SCDA_API int scda_nms_hip(const float *boxes, int n, float thresh, void *mask_ws, int64_t *keep, int64_t *num_out,
+                          int max_keep, void *stream) {
+    if (n < 0 || !num_out || (n > 0 && (!boxes || !mask_ws || !keep))) {
+        set_error("scda_nms_hip: bad arguments");
+        return SCDA_EINVAL;
+    }
+    if (n == 0) {
+        hipError_t e = hipMemsetAsync(num_out, 0, sizeof(int64_t), as_stream(stream));
+        return e == hipSuccess ? SCDA_OK : SCDA_ELAUNCH;
+    }
+    const int cb = (n + 63) / 64;
+    int st = scda_nms_mask_hip(boxes, n, thresh, (uint64_t *)mask_ws, stream);
+    if (st) return st;
+    const size_t lds = (size_t)(cb + 2) * sizeof(uint64_t);
+    if (lds > 64 * 1024) { set_error("scda_nms_hip: n=%d too large for the LDS-resident sweep", n); return SCDA_EINVAL; }
+    hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(256), lds, as_stream(stream), (const uint64_t *)mask_ws, n, cb,
+                       keep, num_out, max_keep);
+    return launch_status("nms_sweep_kernel");
+}
+
+SCDA_API int scda_roi_pool_fwd_hip(const float *features, const float *rois, int R, int B, int C, int H, int W, int PH,
+                                   int PW, float spatial_scale, float *out, int32_t *argmax, void *stream) {
+    if (R < 0 || B <= 0 || C <= 0 || H <= 0 || W <= 0 || PH <= 0 || PW <= 0) { set_error("scda_roi_pool_fwd_hip: bad shape"); return SCDA_EINVAL; }
+    if ((long long)B * C * H * W > 0x7fffffffLL) { set_error("scda_roi_pool_fwd_hip: features exceed int32 indexing"); return SCDA_EINVAL; }
+    if (R == 0) return SCDA_OK;
+    if (!features || !rois || !out) { set_error("scda_roi_pool_fwd_hip: null pointer"); return SCDA_EINVAL; }
+    const long long total = (long long)R * C * PH * PW;
+    const int grid = (int)((total + 255) / 256 > 65536 * 4 ? 65536 * 4 : (total + 255) / 256);
+    hipLaunchKernelGGL(roi_pool_fwd_kernel, dim3(grid), dim3(256), 0, as_stream(stream), total, features, spatial_scale,
+                       C, H, W, PH, PW, rois, out, argmax);
+    return launch_status("roi_pool_fwd_kernel");
+}
+
+SCDA_API int scda_roi_pool_bwd_hip(const float *top_grad, const int32_t *argmax, const float *rois, int R, int B, int C,
+                                   int H, int W, int PH, int PW, float spatial_scale, float *bottom_grad,
+                                   void *stream) {
+    if (R < 0 || B <= 0 || C <= 0 || H <= 0 || W <= 0 || PH <= 0 || PW <= 0 || !bottom_grad) { set_error("scda_roi_pool_bwd_hip: bad shape"); return SCDA_EINVAL; }
+    const long long total = (long long)B * C * H * W;
+    if (total > 0x7fffffffLL) { set_error("scda_roi_pool_bwd_hip: features exceed int32 indexing"); return SCDA_EINVAL; }
+    if (R == 0) {
+        hipError_t e = hipMemsetAsync(bottom_grad, 0, (size_t)total * sizeof(float), as_stream(stream));
+        return e == hipSuccess ? SCDA_OK : SCDA_ELAUNCH;
+    }
+    if (!top_grad || !argmax || !rois) { set_error("scda_roi_pool_bwd_hip: null pointer"); return SCDA_EINVAL; }
+    const size_t lds = (size_t)R * 5 * sizeof(int);
+    if (lds > 96 * 1024) { set_error("scda_roi_pool_bwd_hip: R=%d too large", R); return SCDA_EINVAL; }
+    hipLaunchKernelGGL(roi_pool_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), lds, as_stream(stream), (int)total,
+                       top_grad, argmax, R, spatial_scale, C, H, W, PH, PW, bottom_grad, rois);
+    return launch_status("roi_pool_bwd_kernel");
+}
+
+SCDA_API int scda_roi_align_fwd_hip(const float *features, const float *rois, int R, int B, int C, int H, int W, int AH,
+                                    int AW, float spatial_scale, float *out, void *stream) {
+    if (R < 0 || B <= 0 || C <= 0 || H <= 1 || W <= 1 || AH <= 1 || AW <= 1) { set_error("scda_roi_align_fwd_hip: bad shape"); return SCDA_EINVAL; }
+    if (R == 0) return SCDA_OK;
+    if (!features || !rois || !out) { set_error("scda_roi_align_fwd_hip: null pointer"); return SCDA_EINVAL; }
+    const long long total = (long long)R * C * AH * AW;
+    hipLaunchKernelGGL(roi_align_fwd_kernel, dim3(ew_grid(total) * 8), dim3(256), 0, as_stream(stream), total, features,
+                       spatial_scale, C, H, W, AH, AW, rois, out);
+    return launch_status("roi_align_fwd_kernel");
+}
+
+SCDA_API int scda_roi_align_bwd_hip(const float *top_grad, const float *rois, int R, int B, int C, int H, int W, int AH,
+                                    int AW, float spatial_scale, float *bottom_grad, void *stream) {
+    if (R < 0 || B <= 0 || C <= 0 || H <= 1 || W <= 1 || AH <= 1 || AW <= 1) { set_error("scda_roi_align_bwd_hip: bad shape"); return SCDA_EINVAL; }
+    if (R == 0) return SCDA_OK;
+    if (!top_grad || !rois || !bottom_grad) { set_error("scda_roi_align_bwd_hip: null pointer"); return SCDA_EINVAL; }
+    const long long total = (long long)R * C * AH * AW;
+    hipLaunchKernelGGL(roi_align_bwd_kernel, dim3(ew_grid(total) * 8), dim3(256), 0, as_stream(stream), total, top_grad,
+                       spatial_scale, C, H, W, AH, AW, bottom_grad, rois);
+    return launch_status("roi_align_bwd_kernel");
+}
+
+#define FOCAL_CHECK(name)                                                             \
+    if (N < 0 || num_classes <= 0 || (N % num_classes) != 0) { set_error(name ": bad shape"); return SCDA_EINVAL; } \
+    if (N == 0) return SCDA_OK;
+
+SCDA_API int scda_focal_sigmoid_fwd_hip(int N, const float *logits, const int32_t *targets, float weight_pos,
+                                        float gamma, float alpha, int num_classes, float *losses, void *stream) {
+    FOCAL_CHECK("scda_focal_sigmoid_fwd_hip")
+    hipLaunchKernelGGL(focal_sigmoid_fwd_kernel, dim3(ew_grid(N)), dim3(256), 0, as_stream(stream), N, logits, targets,
+                       weight_pos, gamma, alpha, num_classes, losses);
+    return launch_status("focal_sigmoid_fwd_kernel");
+}
+
+SCDA_API int scda_focal_sigmoid_bwd_hip(int N, const float *logits, const int32_t *targets, float *dX,
+                                        float weight_pos, float gamma, float alpha, int num_classes, void *stream) {
+    FOCAL_CHECK("scda_focal_sigmoid_bwd_hip")
+    hipLaunchKernelGGL(focal_sigmoid_bwd_kernel, dim3(ew_grid(N)), dim3(256), 0, as_stream(stream), N, logits, targets,
+                       dX, weight_pos, gamma, alpha, num_classes);
+    return launch_status("focal_sigmoid_bwd_kernel");
+}
+
+SCDA_API int scda_focal_softmax_fwd_hip(int N, const float *logits, const int32_t *targets, float weight_pos,
+                                        float gamma, float alpha, int num_classes, float *losses, float *priors,
+                                        void *stream) {
+    FOCAL_CHECK("scda_focal_softmax_fwd_hip")
+    const int rows = N / num_classes;
+    hipLaunchKernelGGL(focal_softmax_fwd_kernel, dim3(ew_grid(rows)), dim3(256), 0, as_stream(stream), rows, logits,
+                       targets, weight_pos, gamma, alpha, num_classes, losses, priors);
+    return launch_status("focal_softmax_fwd_kernel");
+}
+
+SCDA_API int scda_focal_softmax_bwd_hip(int N, const float *logits, const int32_t *targets, float *dX,
+                                        float weight_pos, float gamma, float alpha, int num_classes,
+                                        const float *priors, float *buff, void *stream) {
+    (void)logits;
+    FOCAL_CHECK("scda_focal_softmax_bwd_hip")
+    const int rows = N / num_classes;
+    hipLaunchKernelGGL(focal_softmax_bwd_weight_kernel, dim3(ew_grid(rows)), dim3(256), 0, as_stream(stream), rows,
+                       priors, targets, buff, weight_pos, gamma, alpha, num_classes);
+    int st = launch_status("focal_softmax_bwd_weight_kernel");
+    if (st) return st;
+    hipLaunchKernelGGL(focal_softmax_bwd_kernel, dim3(ew_grid(N)), dim3(256), 0, as_stream(stream), N, priors, targets,
+                       buff, dX, num_classes);
+    return launch_status("focal_softmax_bwd_kernel");
+}
+
+SCDA_API int scda_iou_overlaps_hip(const float *b1, const float *b2, int size_bbox, int n1, int n2, float *out,
+                                   void *stream) {
+    if (n1 < 0 || n2 < 0 || size_bbox < 4) { set_error("scda_iou_overlaps_hip: bad shape"); return SCDA_EINVAL; }
+    if (n1 == 0 || n2 == 0) return SCDA_OK;
+    hipLaunchKernelGGL(iou_overlaps_kernel, dim3(ew_grid((long long)n1 * n2)), dim3(256), 0, as_stream(stream), b1, b2,
+                       size_bbox, n1, n2, out);
+    return launch_status("iou_overlaps_kernel");
+}
+
+SCDA_API int scda_bbox_overlaps_hip(const float *boxes, int N, const float *query, int K, float *out, void *stream) {
+    if (N < 0 || K < 0) { set_error("scda_bbox_overlaps_hip: bad shape"); return SCDA_EINVAL; }
+    if (N == 0 || K == 0) return SCDA_OK;
+    hipLaunchKernelGGL(bbox_overlaps_kernel, dim3(ew_grid((long long)N * K)), dim3(256), 0, as_stream(stream), boxes, N,
+                       query, K, out);
+    return launch_status("bbox_overlaps_kernel");
+}

@@ -1,0 +1,194 @@
+"""ctypes binding of libscda_ops.so (C ABI declared in include/scda_ops.h).
+
+Every wrapper takes torch CUDA tensors, checks device/dtype/contiguity, passes
+raw device pointers + sizes + the current HIP stream, and raises on a non-zero
+status.  There is no CPU fallback: operators raise if the library or a HIP
+device is missing.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libscda_ops.so")
+
+_lib = None
+
+
+class ScdaNativeError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libscda_ops.so once; fail loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ScdaNativeError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C scda_amd/csrc` (no CPU fallback exists)")
+        _lib = ctypes.CDLL(LIB_PATH)
+        _lib.scda_last_error.restype = ctypes.c_char_p
+        _lib.scda_nms_workspace_bytes.restype = ctypes.c_size_t
+    return _lib
+
+
+def _check(status, what):
+    if status != 0:
+        msg = lib().scda_last_error().decode("utf-8", "replace")
+        raise ScdaNativeError(f"{what} failed with status {status}: {msg}")
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _req(t, name, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a tensor")
+    if not t.is_cuda:
+        raise ScdaNativeError(f"{name} must live on the HIP device (got {t.device}); there is no CPU path")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    return t
+
+
+f32 = ctypes.c_float
+i32 = ctypes.c_int
+
+
+# ----------------------------------------------------------------- NMS ------
+def nms(boxes, thresh, max_keep=0):
+    """boxes [n,5] fp32 CUDA, sorted by score desc -> (keep int64[n] CUDA, num_out int64[1] CUDA)."""
+    _req(boxes, "boxes")
+    n = boxes.shape[0]
+    keep = torch.empty(max(n, 1), dtype=torch.int64, device=boxes.device)
+    num = torch.zeros(1, dtype=torch.int64, device=boxes.device)
+    ws = torch.empty(max(lib().scda_nms_workspace_bytes(i32(n)), 8), dtype=torch.uint8, device=boxes.device)
+    _check(lib().scda_nms_hip(_p(boxes), i32(n), f32(thresh), _p(ws), _p(keep), _p(num), i32(max_keep), _stream()),
+           "scda_nms_hip")
+    return keep, num
+
+
+def nms_mask(boxes, thresh):
+    _req(boxes, "boxes")
+    n = boxes.shape[0]
+    cb = (n + 63) // 64
+    mask = torch.zeros(n, cb, dtype=torch.int64, device=boxes.device)
+    _check(lib().scda_nms_mask_hip(_p(boxes), i32(n), f32(thresh), _p(mask), _stream()), "scda_nms_mask_hip")
+    return mask
+
+
+# ------------------------------------------------------------- RoIPool ------
+def roi_pool_fwd(features, rois, ph, pw, scale):
+    _req(features, "features"); _req(rois, "rois")
+    if rois.dim() != 2 or rois.shape[1] != 5:
+        raise ValueError("rois must be [R,5]")
+    B, C, H, W = features.shape
+    R = rois.shape[0]
+    out = torch.empty(R, C, ph, pw, dtype=torch.float32, device=features.device)
+    arg = torch.empty(R, C, ph, pw, dtype=torch.int32, device=features.device)
+    _check(lib().scda_roi_pool_fwd_hip(_p(features), _p(rois), i32(R), i32(B), i32(C), i32(H), i32(W), i32(ph), i32(pw),
+                                       f32(scale), _p(out), _p(arg), _stream()), "scda_roi_pool_fwd_hip")
+    return out, arg
+
+
+def roi_pool_bwd(top_grad, argmax, rois, feat_shape, ph, pw, scale):
+    _req(top_grad, "top_grad"); _req(argmax, "argmax", torch.int32); _req(rois, "rois")
+    B, C, H, W = feat_shape
+    R = rois.shape[0]
+    gi = torch.empty(B, C, H, W, dtype=torch.float32, device=top_grad.device)
+    _check(lib().scda_roi_pool_bwd_hip(_p(top_grad), _p(argmax), _p(rois), i32(R), i32(B), i32(C), i32(H), i32(W),
+                                       i32(ph), i32(pw), f32(scale), _p(gi), _stream()), "scda_roi_pool_bwd_hip")
+    return gi
+
+
+# ------------------------------------------------------------ RoIAlign ------
+def roi_align_fwd(features, rois, ah, aw, scale):
+    _req(features, "features"); _req(rois, "rois")
+    if rois.dim() != 2 or rois.shape[1] != 5:
+        raise ValueError("rois must be [R,5]")
+    B, C, H, W = features.shape
+    R = rois.shape[0]
+    out = torch.empty(R, C, ah, aw, dtype=torch.float32, device=features.device)
+    _check(lib().scda_roi_align_fwd_hip(_p(features), _p(rois), i32(R), i32(B), i32(C), i32(H), i32(W), i32(ah), i32(aw),
+                                        f32(scale), _p(out), _stream()), "scda_roi_align_fwd_hip")
+    return out
+
+
+def roi_align_bwd(top_grad, rois, feat_shape, ah, aw, scale):
+    _req(top_grad, "top_grad"); _req(rois, "rois")
+    B, C, H, W = feat_shape
+    gi = torch.zeros(B, C, H, W, dtype=torch.float32, device=top_grad.device)
+    _check(lib().scda_roi_align_bwd_hip(_p(top_grad), _p(rois), i32(rois.shape[0]), i32(B), i32(C), i32(H), i32(W),
+                                        i32(ah), i32(aw), f32(scale), _p(gi), _stream()), "scda_roi_align_bwd_hip")
+    return gi
+
+
+# ---------------------------------------------------------- focal loss ------
+def focal_sigmoid_fwd(logits, targets, weight_pos, gamma, alpha, num_classes):
+    _req(logits, "logits"); _req(targets, "targets", torch.int32)
+    losses = torch.empty_like(logits)
+    _check(lib().scda_focal_sigmoid_fwd_hip(i32(logits.numel()), _p(logits), _p(targets), f32(weight_pos), f32(gamma),
+                                            f32(alpha), i32(num_classes), _p(losses), _stream()),
+           "scda_focal_sigmoid_fwd_hip")
+    return losses
+
+
+def focal_sigmoid_bwd(logits, targets, weight_pos, gamma, alpha, num_classes):
+    _req(logits, "logits"); _req(targets, "targets", torch.int32)
+    dx = torch.empty_like(logits)
+    _check(lib().scda_focal_sigmoid_bwd_hip(i32(logits.numel()), _p(logits), _p(targets), _p(dx), f32(weight_pos),
+                                            f32(gamma), f32(alpha), i32(num_classes), _stream()),
+           "scda_focal_sigmoid_bwd_hip")
+    return dx
+
+
+def focal_softmax_fwd(logits, targets, weight_pos, gamma, alpha, num_classes):
+    _req(logits, "logits"); _req(targets, "targets", torch.int32)
+    rows = logits.numel() // num_classes
+    losses = torch.empty(rows, dtype=torch.float32, device=logits.device)
+    priors = torch.empty_like(logits)
+    _check(lib().scda_focal_softmax_fwd_hip(i32(logits.numel()), _p(logits), _p(targets), f32(weight_pos), f32(gamma),
+                                            f32(alpha), i32(num_classes), _p(losses), _p(priors), _stream()),
+           "scda_focal_softmax_fwd_hip")
+    return losses, priors
+
+
+def focal_softmax_bwd(logits, targets, priors, weight_pos, gamma, alpha, num_classes):
+    _req(logits, "logits"); _req(targets, "targets", torch.int32); _req(priors, "priors")
+    rows = logits.numel() // num_classes
+    dx = torch.empty_like(logits)
+    buff = torch.empty(rows, dtype=torch.float32, device=logits.device)
+    _check(lib().scda_focal_softmax_bwd_hip(i32(logits.numel()), _p(logits), _p(targets), _p(dx), f32(weight_pos),
+                                            f32(gamma), f32(alpha), i32(num_classes), _p(priors), _p(buff), _stream()),
+           "scda_focal_softmax_bwd_hip")
+    return dx
+
+
+# -------------------------------------------------------- box overlaps ------
+def iou_overlaps(b1, b2):
+    _req(b1, "b1"); _req(b2, "b2")
+    if b1.shape[1] != b2.shape[1]:
+        raise ValueError("box widths differ")
+    out = torch.empty(b1.shape[0], b2.shape[0], dtype=torch.float32, device=b1.device)
+    _check(lib().scda_iou_overlaps_hip(_p(b1), _p(b2), i32(b1.shape[1]), i32(b1.shape[0]), i32(b2.shape[0]), _p(out),
+                                       _stream()), "scda_iou_overlaps_hip")
+    return out
+
+
+def bbox_overlaps(boxes, query):
+    _req(boxes, "boxes"); _req(query, "query")
+    if boxes.shape[1] != 4 or query.shape[1] != 4:
+        raise ValueError("bbox_overlaps takes [N,4] and [K,4]")
+    out = torch.empty(boxes.shape[0], query.shape[0], dtype=torch.float32, device=boxes.device)
+    _check(lib().scda_bbox_overlaps_hip(_p(boxes), i32(boxes.shape[0]), _p(query), i32(query.shape[0]), _p(out),
+                                        _stream()), "scda_bbox_overlaps_hip")
+    return out

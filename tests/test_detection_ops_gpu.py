@@ -1,0 +1,163 @@
+"""Parity of the HIP detection operators (through the C ABI, scda_amd.native) with the CPU oracle.
+Integer / index results must be bit-exact; focal loss within 1e-6 abs (device expf/logf/powf)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import native_ops as orc
+from test_oracle_golden import rand_boxes, rand_rois
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a, cuda, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(cuda).contiguous()
+
+
+def clustered(rs, n, integer=False):
+    b = rand_boxes(rs, n, integer=integer)
+    if n > 10:
+        b[n // 2:, :4] = b[: n - n // 2, :4] + rs.uniform(-3, 3, (n - n // 2, 4)).astype(np.float32)
+    return b
+
+
+@pytest.mark.parametrize("n,thresh,integer", [(0, .7, False), (1, .7, False), (63, .7, False), (64, .7, True), (65, .5, False),
+                                               (300, .5, False), (2000, .7, True), (6000, .7, False), (12000, .7, False)])
+def test_nms_keep_bit_exact(cuda, n, thresh, integer):
+    from scda_amd import native
+    rs = np.random.RandomState(n + 7)
+    boxes = clustered(rs, n, integer)
+    ref = orc.nms(boxes, thresh)
+    keep, num = native.nms(dev(boxes, cuda) if n else torch.zeros(0, 5, device=cuda), thresh)
+    k = int(num.item())
+    assert k == len(ref)
+    np.testing.assert_array_equal(keep[:k].cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("n,max_keep", [(500, 10), (3000, 300), (12000, 2000), (700, 100000)])
+def test_nms_max_keep_equals_truncation(cuda, n, max_keep):
+    from scda_amd import native
+    rs = np.random.RandomState(n)
+    boxes = clustered(rs, n)
+    ref = orc.nms(boxes, 0.7)[:max_keep]
+    keep, num = native.nms(dev(boxes, cuda), 0.7, max_keep=max_keep)
+    k = int(num.item())
+    assert k == len(ref)
+    np.testing.assert_array_equal(keep[:k].cpu().numpy(), ref)
+
+
+def test_nms_mask_upper_triangle_bit_exact(cuda):
+    from scda_amd import native
+    rs = np.random.RandomState(3)
+    boxes = clustered(rs, 1000)
+    m = native.nms_mask(dev(boxes, cuda), 0.6).cpu().numpy().view(np.uint64)
+    ref = orc.nms_mask(boxes, 0.6)
+    cb = ref.shape[1]
+    rows = np.arange(1000) // 64
+    upper = np.arange(cb)[None, :] >= rows[:, None]
+    np.testing.assert_array_equal(m[upper], ref[upper])
+
+
+def test_nms_rejects_cpu_tensor(cuda):
+    from scda_amd import native
+    with pytest.raises(native.ScdaNativeError):
+        native.nms(torch.zeros(3, 5), 0.5)
+
+
+@pytest.mark.parametrize("shape,R", [((1, 8, 32, 64), 64), ((2, 5, 16, 24), 33), ((1, 512, 32, 64), 512)])
+def test_roi_pool_fwd_bwd_bit_exact(cuda, shape, R):
+    from scda_amd import native
+    rs = np.random.RandomState(R)
+    B, C, H, W = shape
+    feat = rs.randn(*shape).astype(np.float32)
+    feat[0, 0, 1:5, 2:9] = 2.5  # ties
+    rois = rand_rois(rs, R, B=B, W=W * 16, H=H * 16)
+    rois[-1] = [0, -50, -50, W * 16 + 80, H * 16 + 80]
+    eo, ea = orc.roi_pool_fwd(feat, rois, 7, 7, 1 / 16.)
+    out, arg = native.roi_pool_fwd(dev(feat, cuda), dev(rois, cuda), 7, 7, 1 / 16.)
+    np.testing.assert_array_equal(out.cpu().numpy(), eo)
+    np.testing.assert_array_equal(arg.cpu().numpy(), ea)
+    top = rs.randn(*eo.shape).astype(np.float32)
+    if C * R <= 4096:  # the gather oracle is O(B*C*H*W*R); keep the big case to a channel slice
+        eg = orc.roi_pool_bwd(top, ea, rois, shape, 7, 7, 1 / 16.)
+        g = native.roi_pool_bwd(dev(top, cuda), arg, dev(rois, cuda), shape, 7, 7, 1 / 16.)
+        np.testing.assert_array_equal(g.cpu().numpy(), eg)
+    else:
+        g = native.roi_pool_bwd(dev(top, cuda), arg, dev(rois, cuda), shape, 7, 7, 1 / 16.).cpu().numpy()
+        # size-independent property: the gradient is a permutation-sum of top (mass conservation per channel)
+        valid = ea >= 0
+        np.testing.assert_allclose(g.sum(axis=(0, 2, 3)), (top * valid).sum(axis=(0, 2, 3)), rtol=2e-4, atol=1e-3)
+        # exact check on 4 channels through the oracle (channels are independent)
+        sel = [0, 1, 255, 511]
+        fs = np.ascontiguousarray(feat[:, sel]); ts = np.ascontiguousarray(top[:, sel])
+        _, eas = orc.roi_pool_fwd(fs, rois, 7, 7, 1 / 16.)
+        egs = orc.roi_pool_bwd(ts, eas, rois, fs.shape, 7, 7, 1 / 16.)
+        np.testing.assert_array_equal(g[:, sel], egs)
+
+
+def test_roi_pool_empty_rois(cuda):
+    from scda_amd import native
+    feat = torch.randn(1, 4, 8, 8, device=cuda)
+    out, arg = native.roi_pool_fwd(feat, torch.zeros(0, 5, device=cuda), 7, 7, 1 / 16.)
+    assert out.shape == (0, 4, 7, 7)
+    g = native.roi_pool_bwd(torch.zeros(0, 4, 7, 7, device=cuda), arg, torch.zeros(0, 5, device=cuda), (1, 4, 8, 8), 7, 7, 1 / 16.)
+    assert float(g.abs().sum()) == 0.0
+
+
+def test_roi_align_fwd_bwd(cuda):
+    from scda_amd import native
+    rs = np.random.RandomState(21)
+    shape = (2, 16, 50, 84)
+    feat = rs.randn(*shape).astype(np.float32)
+    rois = rand_rois(rs, 64, B=2, W=84 * 16, H=50 * 16)
+    rois[0] = [0, -30, -30, 100, 100]
+    eo = orc.roi_align_fwd(feat, rois, 8, 8, 1 / 16.)
+    out = native.roi_align_fwd(dev(feat, cuda), dev(rois, cuda), 8, 8, 1 / 16.)
+    np.testing.assert_array_equal(out.cpu().numpy(), eo)  # same roundings -> bit exact
+    top = rs.randn(*eo.shape).astype(np.float32)
+    eg = orc.roi_align_bwd(top, rois, shape, 8, 8, 1 / 16.)
+    g = native.roi_align_bwd(dev(top, cuda), dev(rois, cuda), shape, 8, 8, 1 / 16.)
+    np.testing.assert_allclose(g.cpu().numpy(), eg, rtol=1e-5, atol=1e-5)  # atomics: order differs
+
+
+def test_focal_sigmoid(cuda):
+    from scda_amd import native
+    rs = np.random.RandomState(22)
+    rows, C = 30720, 8
+    x = (rs.randn(rows, C) * 3).astype(np.float32)
+    t = rs.randint(-1, C + 1, rows).astype(np.int32)
+    for wp in (0.0, 97.0):
+        l = native.focal_sigmoid_fwd(dev(x, cuda), dev(t, cuda), wp, 2.0, 0.25, C)
+        np.testing.assert_allclose(l.cpu().numpy(), orc.focal_sigmoid_fwd(x, t, wp, 2.0, 0.25, C), atol=1e-6, rtol=1e-5)
+        g = native.focal_sigmoid_bwd(dev(x, cuda), dev(t, cuda), wp, 2.0, 0.25, C)
+        np.testing.assert_allclose(g.cpu().numpy(), orc.focal_sigmoid_bwd(x, t, wp, 2.0, 0.25, C), atol=1e-6, rtol=1e-5)
+
+
+def test_focal_softmax(cuda):
+    from scda_amd import native
+    rs = np.random.RandomState(23)
+    rows, C = 30720, 9
+    x = (rs.randn(rows, C) * 3).astype(np.float32)
+    t = rs.randint(-1, C, rows).astype(np.int32)
+    l, p = native.focal_softmax_fwd(dev(x, cuda), dev(t, cuda), 50.0, 2.0, 0.25, C)
+    el, ep = orc.focal_softmax_fwd(x, t, 50.0, 2.0, 0.25, C)
+    np.testing.assert_allclose(p.cpu().numpy(), ep, atol=1e-6)
+    np.testing.assert_allclose(l.cpu().numpy(), el, atol=1e-6, rtol=1e-5)
+    g = native.focal_softmax_bwd(dev(x, cuda), dev(t, cuda), p, 50.0, 2.0, 0.25, C)
+    np.testing.assert_allclose(g.cpu().numpy(), orc.focal_softmax_bwd(x, t, ep, 50.0, 2.0, 0.25, C), atol=1e-6, rtol=1e-5)
+
+
+def test_box_overlaps_bit_exact(cuda, golden_dir):
+    import os
+    from scda_amd import native
+    g = np.load(os.path.join(golden_dir, "bbox_overlaps.npz"))
+    for case in ("small", "anchors", "degenerate"):
+        out = native.bbox_overlaps(dev(g[case + "_boxes"], cuda), dev(g[case + "_query"], cuda))
+        np.testing.assert_array_equal(out.cpu().numpy(), g[case + "_out"], err_msg=case)  # vs the reference's Cython
+    rs = np.random.RandomState(24)
+    a = rand_boxes(rs, 30720)[:, :4]; b = rand_boxes(rs, 30)[:, :4]
+    np.testing.assert_array_equal(native.iou_overlaps(dev(a, cuda), dev(b, cuda)).cpu().numpy(), orc.iou_overlaps(a, b))
+    np.testing.assert_array_equal(native.bbox_overlaps(dev(a, cuda), dev(b, cuda)).cpu().numpy(), orc.bbox_overlaps(a, b))
