@@ -109,6 +109,38 @@ int scda_iou_overlaps_hip(const float *b1, const float *b2, int size_bbox, int n
  *           extensions/_cython_bbox/cython_bbox.pyx:32-73   (no +1, 0 unless iw>0 and ih>0) */
 int scda_bbox_overlaps_hip(const float *boxes, int N, const float *query, int K, float *out, void *stream);
 
+/* ------------------------------------------------- convolution / GEMM ---- */
+/* The reference reaches these through torch.nn (cuDNN / cuBLAS): nn.Conv2d in
+ * models/faster_rcnn/vgg_adver_expansion_cluster.py:101-114 (VGG body),
+ * models/head.py:13-18 (RPN), models/faster_rcnn/common_net.py:59-80,251-293 (GAN blocks);
+ * nn.Linear in vgg_adver_expansion_cluster.py:46-60 (FC6/FC7/heads).
+ * Here they are fp32-MFMA implicit-GEMM kernels; tensors are NCHW fp32, weights
+ * [Cout,Cin,KH,KW] exactly as the reference's state_dict stores them.
+ * Supported (KH,KW,stride): (3,3,1) (3,3,2) (1,1,1); any padding.
+ * act: 0 none, 1 ReLU, 2 LeakyReLU(slope) fused into the epilogue.
+ * ws: workspace of scda_conv2d_workspace_bytes(...) bytes (split-K slabs).      */
+size_t scda_conv2d_workspace_bytes(int batch, int Cin, int IH, int IW, int Cout, int KH, int KW, int S, int P);
+int scda_conv2d_fwd_hip(const float *x, const float *w, const float *bias /*[Cout] or NULL*/, float *y, int batch,
+                        int Cin, int IH, int IW, int Cout, int KH, int KW, int S, int P, int act, float slope,
+                        void *ws, size_t ws_bytes, void *stream);
+/* wt = w with dims 0 and 1 swapped ([Cin,Cout,KH,KW]); operand of the data-gradient GEMM */
+int scda_conv2d_swap01_hip(const float *w, float *wt, int Cout, int Cin, int KH, int KW, void *stream);
+/* dx [batch,Cin,IH,IW] = conv-transpose of dy [batch,Cout,OH,OW] (fully overwritten) */
+int scda_conv2d_dgrad_hip(const float *dy, const float *wt, float *dx, int batch, int Cin, int IH, int IW, int Cout,
+                          int KH, int KW, int S, int P, void *ws, size_t ws_bytes, void *stream);
+/* dw [Cout,Cin,KH,KW] (+)= sum over batch and pixels; deterministic split-K (no atomics) */
+int scda_conv2d_wgrad_hip(const float *dy, const float *x, float *dw, int batch, int Cin, int IH, int IW, int Cout,
+                          int KH, int KW, int S, int P, int accumulate, void *ws, size_t ws_bytes, void *stream);
+
+/* C[M,N] (row stride ldc) (+)= op(A) op(B) (+ bias) -> act
+ * trans_a = 0: A is [M,K] row-major (lda);  1: A is stored [K,M]
+ * trans_b = 0: B is [N,K] row-major (ldb);  1: B is stored [K,N]
+ * nn.Linear forward  y = x W^T + b : A=x, B=W, trans_a=0, trans_b=0, bias_on_n=1        */
+size_t scda_gemm_workspace_bytes(int M, int N, int K);
+int scda_gemm_hip(const float *A, const float *B, float *C, int M, int N, int K, int lda, int ldb, int ldc,
+                  int trans_a, int trans_b, const float *bias, int bias_on_n, int act, float slope, int accumulate,
+                  void *ws, size_t ws_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

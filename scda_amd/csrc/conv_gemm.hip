@@ -1,0 +1,586 @@
+// conv_gemm.hip -- fp32-MFMA implicit-GEMM convolution (forward, data-gradient,
+// weight-gradient) and dense GEMM for gfx950, behind the C ABI of scda_ops.h.
+//
+// GEMM view (NCHW tensors, no layout change at the boundary):
+//   forward   Y[co][n,oy,ox]   = sum_{ci,kh,kw} W[co][ci,kh,kw] * X[n,ci,oy*S+kh-P,ox*S+kw-P]
+//             M = Cout, N = batch*OH*OW (pixels, contiguous in memory), K = Cin*KH*KW
+//   dgrad     dX[ci][n,iy,ix]  = sum_{co,kh,kw} Wt[ci][co,kh,kw] * dY[n,co,(iy+P-kh)/S,(ix+P-kw)/S]
+//             same kernel, gather predicate differs (DGRAD); Wt = W with dims 0/1 swapped
+//   wgrad     dW[co][ci,kh,kw] = sum_{n,oy,ox} dY[n,co,oy,ox] * X[n,ci,oy*S+kh-P,ox*S+kw-P]
+//             M = Cout, N = Cin*KH*KW, K = batch*OH*OW, always split-K (deterministic
+//             partial slabs + fixed-order reduce, no atomics)
+// The im2col matrix is never materialised: each thread gathers its B elements
+// straight from the activation tensor into registers (prefetch for the next
+// K-step), then stages them in LDS in the k-major layout mfma_tile.h reads.
+#include "mfma_tile.h"
+
+namespace scda {
+
+struct ConvGeom {
+    // tensor the B operand gathers from: [batch, CB, HB, WB]
+    int batch, CB, HB, WB;
+    // pixel grid that indexes N (fwd: output OHxOW; dgrad: input IHxIW)
+    int PH, PW;
+    int pad;
+    int M, N, K;
+    int k_per_split;  // multiple of BK
+    Div dPHW, dPW;
+};
+
+struct Epi {
+    float *out;          // final destination (when splits == 1)
+    float *ws;           // split-K slabs [splits][M][N] (when splits > 1)
+    const float *bias;   // per-M (conv) or per-N (dense); may be null
+    int bias_on_n;
+    int act;
+    float slope;
+    int splits;
+};
+
+// ---------------------------------------------------------------------------
+// conv forward / dgrad
+// ---------------------------------------------------------------------------
+template <int BM, int BN, int KH, int KW, int S, bool DGRAD>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const float *__restrict__ Wm, const float *__restrict__ X,
+                                                         const ConvGeom g, const Epi e) {
+    using T = TileCfg<BM, BN>;
+    __shared__ __attribute__((aligned(16))) float lds[T::LDS_FLOATS];
+    auto As = [&](int b) -> float * { return lds + b * (BK * T::LDA); };
+    auto Bs = [&](int b) -> float * { return lds + 2 * BK * T::LDA + b * (BK * T::LDB); };
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int k_begin = blockIdx.z * g.k_per_split;
+    const int k_end = min(g.K, k_begin + g.k_per_split);
+
+    // A staging: lanes along K (weights are K-contiguous): k = tid%16, rows tid/16 + 16*j
+    const int ka = tid & 15, ra = tid >> 4;
+    // B staging: lanes along N (pixels are contiguous): n = tid%BN, k = tid/BN + KS*j (wave-uniform)
+    constexpr int KS = 256 / BN;
+    const int nb = tid % BN, kb = tid / BN;
+
+    // pixel owned by this thread for the B gather
+    const int n_glob = n0 + nb;
+    const bool n_ok = n_glob < g.N;
+    int img, pix, py, px;
+    g.dPHW.divmod(n_ok ? n_glob : 0, img, pix);
+    g.dPW.divmod(pix, py, px);
+    const float *xb = X + (size_t)img * g.CB * g.HB * g.WB;
+    const int plane = g.HB * g.WB;
+
+    float ar[T::A_ELEMS], br[T::B_ELEMS];
+
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < T::A_ELEMS; ++j) {
+            const int m = m0 + ra + 16 * j, k = k0 + ka;
+            ar[j] = (m < g.M && k < k_end) ? Wm[(size_t)m * g.K + k] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < T::B_ELEMS; ++j) {
+            const int k = k0 + kb + KS * j;  // wave-uniform: the decode below is scalar work
+            const int c = k / (KH * KW);
+            const int rem = k - c * (KH * KW);
+            const int kh = rem / KW, kw = rem - kh * KW;
+            float v = 0.f;
+            if (n_ok && k < k_end) {
+                if (!DGRAD) {
+                    const int iy = py * S + kh - g.pad, ix = px * S + kw - g.pad;
+                    if ((unsigned)iy < (unsigned)g.HB && (unsigned)ix < (unsigned)g.WB)
+                        v = xb[(size_t)c * plane + iy * g.WB + ix];
+                } else {
+                    const int ty = py + g.pad - kh, tx = px + g.pad - kw;
+                    if (ty >= 0 && tx >= 0) {
+                        const int oy = ty / S, ox = tx / S;
+                        if (oy * S == ty && ox * S == tx && oy < g.HB && ox < g.WB)
+                            v = xb[(size_t)c * plane + oy * g.WB + ox];
+                    }
+                }
+            }
+            br[j] = v;
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < T::A_ELEMS; ++j) As(buf)[ka * T::LDA + ra + 16 * j] = ar[j];
+#pragma unroll
+        for (int j = 0; j < T::B_ELEMS; ++j) Bs(buf)[(kb + KS * j) * T::LDB + nb] = br[j];
+    };
+
+    f32x16 acc[T::TM][T::TN];
+    zero_acc<BM, BN>(acc);
+
+    gload(k_begin);
+    sstore(0);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+        const bool more = k0 + BK < k_end;
+        if (more) gload(k0 + BK);  // global loads in flight under the MFMAs
+        mma_slab<BM, BN>(As(buf), Bs(buf), acc, wm, wn, lane);
+        if (more) sstore(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    // epilogue: lanes run along N (pixels) -> 128B coalesced row segments
+    const int lr = lane & 31;
+#pragma unroll
+    for (int j = 0; j < T::TN; ++j) {
+        const int n = n0 + wn * T::WN + j * 32 + lr;
+        if (n >= g.N) continue;
+        int oimg, opix;
+        g.dPHW.divmod(n, oimg, opix);
+#pragma unroll
+        for (int i = 0; i < T::TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * T::WM + i * 32 + frag_row(r, lane);
+                if (m >= g.M) continue;
+                float v = acc[i][j][r];
+                if (e.splits > 1) {
+                    e.ws[((size_t)blockIdx.z * g.M + m) * g.N + n] = v;
+                } else {
+                    if (e.bias) v += e.bias[m];
+                    v = apply_act(v, e.act, e.slope);
+                    e.out[((size_t)oimg * g.M + m) * g.dPHW.d + opix] = v;
+                }
+            }
+        }
+    }
+}
+
+// split-K reduce for conv outputs: fixed summation order s = 0..splits-1
+__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float *__restrict__ ws, const int splits,
+                                                                 const int M, const int N, const Div dPHW,
+                                                                 const float *__restrict__ bias, const int act,
+                                                                 const float slope, float *__restrict__ out) {
+    const long long total = (long long)M * N;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)blockDim.x * gridDim.x) {
+        const int m = (int)(idx / N), n = (int)(idx - (long long)m * N);
+        float v = 0.f;
+        for (int s = 0; s < splits; ++s) v += ws[(size_t)s * total + idx];
+        if (bias) v += bias[m];
+        v = apply_act(v, act, slope);
+        int img, pix;
+        dPHW.divmod(n, img, pix);
+        out[((size_t)img * M + m) * dPHW.d + pix] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// conv weight gradient
+// ---------------------------------------------------------------------------
+struct WgradGeom {
+    int batch, Cin, IH, IW, Cout, OH, OW, pad;
+    int M, N, K;  // Cout, Cin*KH*KW, batch*OH*OW
+    int k_per_split;
+    Div dOHW, dOW;
+};
+
+template <int BM, int BN, int KH, int KW, int S>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict__ dY, const float *__restrict__ X,
+                                                         const WgradGeom g, float *__restrict__ ws) {
+    using T = TileCfg<BM, BN>;
+    __shared__ __attribute__((aligned(16))) float lds[T::LDS_FLOATS];
+    auto As = [&](int b) -> float * { return lds + b * (BK * T::LDA); };
+    auto Bs = [&](int b) -> float * { return lds + 2 * BK * T::LDA + b * (BK * T::LDB); };
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int k_begin = blockIdx.z * g.k_per_split;
+    const int k_end = min(g.K, k_begin + g.k_per_split);
+
+    // both operands are contiguous along K (= output pixels): lanes along K
+    const int kl = tid & 15, rl = tid >> 4;
+    const int ohw = g.dOHW.d, ihw = g.IH * g.IW;
+
+    // per-row constants of the B gather: n -> (ci,kh,kw)
+    int b_coff[T::B_ELEMS], b_dy[T::B_ELEMS], b_dx[T::B_ELEMS];
+#pragma unroll
+    for (int j = 0; j < T::B_ELEMS; ++j) {
+        const int n = n0 + rl + 16 * j;
+        const int c = n / (KH * KW), rem = n - c * (KH * KW);
+        const int kh = rem / KW, kw = rem - kh * KW;
+        b_coff[j] = (n < g.N) ? c * ihw : -1;
+        b_dy[j] = kh - g.pad;
+        b_dx[j] = kw - g.pad;
+    }
+
+    float ar[T::A_ELEMS], br[T::B_ELEMS];
+    auto gload = [&](int k0) {
+        const int k = k0 + kl;
+        const bool k_ok = k < k_end;
+        int img, pix, oy, ox;
+        g.dOHW.divmod(k_ok ? k : 0, img, pix);
+        g.dOW.divmod(pix, oy, ox);
+        const float *dyb = dY + (size_t)img * g.Cout * ohw + pix;
+        const float *xb = X + (size_t)img * g.Cin * ihw;
+#pragma unroll
+        for (int j = 0; j < T::A_ELEMS; ++j) {
+            const int m = m0 + rl + 16 * j;
+            ar[j] = (k_ok && m < g.M) ? dyb[(size_t)m * ohw] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < T::B_ELEMS; ++j) {
+            const int iy = oy * S + b_dy[j], ix = ox * S + b_dx[j];
+            float v = 0.f;
+            if (k_ok && b_coff[j] >= 0 && (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW)
+                v = xb[b_coff[j] + iy * g.IW + ix];
+            br[j] = v;
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < T::A_ELEMS; ++j) As(buf)[kl * T::LDA + rl + 16 * j] = ar[j];
+#pragma unroll
+        for (int j = 0; j < T::B_ELEMS; ++j) Bs(buf)[kl * T::LDB + rl + 16 * j] = br[j];
+    };
+
+    f32x16 acc[T::TM][T::TN];
+    zero_acc<BM, BN>(acc);
+    gload(k_begin);
+    sstore(0);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+        const bool more = k0 + BK < k_end;
+        if (more) gload(k0 + BK);
+        mma_slab<BM, BN>(As(buf), Bs(buf), acc, wm, wn, lane);
+        if (more) sstore(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    const int lr = lane & 31;
+#pragma unroll
+    for (int j = 0; j < T::TN; ++j) {
+        const int n = n0 + wn * T::WN + j * 32 + lr;
+        if (n >= g.N) continue;
+#pragma unroll
+        for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * T::WM + i * 32 + frag_row(r, lane);
+                if (m < g.M) ws[((size_t)blockIdx.z * g.M + m) * g.N + n] = acc[i][j][r];
+            }
+    }
+}
+
+// out[idx] = (accumulate ? out[idx] : 0) + sum_s ws[s][idx] (+ bias[col]) -> act
+__global__ __launch_bounds__(256) void dense_splitk_reduce_kernel(const float *__restrict__ ws, const int splits,
+                                                                  const long long total, const int N,
+                                                                  const float *__restrict__ bias, const int bias_on_n,
+                                                                  const int act, const float slope,
+                                                                  const int accumulate, float *__restrict__ out) {
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)blockDim.x * gridDim.x) {
+        float v = 0.f;
+        for (int s = 0; s < splits; ++s) v += ws[(size_t)s * total + idx];
+        if (bias) v += bias_on_n ? bias[idx % N] : bias[idx / N];
+        v = apply_act(v, act, slope);
+        out[idx] = accumulate ? out[idx] + v : v;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// dense GEMM  C[M][N] = op(A) * op(B)   (FC layers, 1x1 convs handled by conv path)
+//   TA = false: A is [M][K] (K contiguous)   TA = true: A is [K][M] (M contiguous)
+//   TB = false: B is [N][K] (K contiguous)   TB = true: B is [K][N] (N contiguous)
+// ---------------------------------------------------------------------------
+struct GemmGeom {
+    int M, N, K, lda, ldb, ldc;
+    int k_per_split;
+};
+
+template <int BM, int BN, bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_kernel(const float *__restrict__ A, const float *__restrict__ B,
+                                                   const GemmGeom g, const Epi e) {
+    using T = TileCfg<BM, BN>;
+    __shared__ __attribute__((aligned(16))) float lds[T::LDS_FLOATS];
+    auto As = [&](int b) -> float * { return lds + b * (BK * T::LDA); };
+    auto Bs = [&](int b) -> float * { return lds + 2 * BK * T::LDA + b * (BK * T::LDB); };
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int k_begin = blockIdx.z * g.k_per_split;
+    const int k_end = min(g.K, k_begin + g.k_per_split);
+
+    // K-contiguous operand: lanes along K; MN-contiguous operand: lanes along MN
+    const int kl = tid & 15, rl = tid >> 4;
+    constexpr int KSA = 256 / BM, KSB = 256 / BN;
+    const int ma = tid % BM, kma = tid / BM;
+    const int nbb = tid % BN, knb = tid / BN;
+
+    float ar[T::A_ELEMS], br[T::B_ELEMS];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < T::A_ELEMS; ++j) {
+            if (!TA) {
+                const int m = m0 + rl + 16 * j, k = k0 + kl;
+                ar[j] = (m < g.M && k < k_end) ? A[(size_t)m * g.lda + k] : 0.f;
+            } else {
+                const int m = m0 + ma, k = k0 + kma + KSA * j;
+                ar[j] = (m < g.M && k < k_end) ? A[(size_t)k * g.lda + m] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < T::B_ELEMS; ++j) {
+            if (!TB) {
+                const int n = n0 + rl + 16 * j, k = k0 + kl;
+                br[j] = (n < g.N && k < k_end) ? B[(size_t)n * g.ldb + k] : 0.f;
+            } else {
+                const int n = n0 + nbb, k = k0 + knb + KSB * j;
+                br[j] = (n < g.N && k < k_end) ? B[(size_t)k * g.ldb + n] : 0.f;
+            }
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < T::A_ELEMS; ++j) {
+            if (!TA) As(buf)[kl * T::LDA + rl + 16 * j] = ar[j];
+            else As(buf)[(kma + KSA * j) * T::LDA + ma] = ar[j];
+        }
+#pragma unroll
+        for (int j = 0; j < T::B_ELEMS; ++j) {
+            if (!TB) Bs(buf)[kl * T::LDB + rl + 16 * j] = br[j];
+            else Bs(buf)[(knb + KSB * j) * T::LDB + nbb] = br[j];
+        }
+    };
+
+    f32x16 acc[T::TM][T::TN];
+    zero_acc<BM, BN>(acc);
+    gload(k_begin);
+    sstore(0);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+        const bool more = k0 + BK < k_end;
+        if (more) gload(k0 + BK);
+        mma_slab<BM, BN>(As(buf), Bs(buf), acc, wm, wn, lane);
+        if (more) sstore(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    const int lr = lane & 31;
+#pragma unroll
+    for (int j = 0; j < T::TN; ++j) {
+        const int n = n0 + wn * T::WN + j * 32 + lr;
+        if (n >= g.N) continue;
+#pragma unroll
+        for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * T::WM + i * 32 + frag_row(r, lane);
+                if (m >= g.M) continue;
+                float v = acc[i][j][r];
+                if (e.splits > 1) {
+                    e.ws[((size_t)blockIdx.z * g.M + m) * g.N + n] = v;
+                } else {
+                    if (e.bias) v += e.bias_on_n ? e.bias[n] : e.bias[m];
+                    v = apply_act(v, e.act, e.slope);
+                    e.out[(size_t)m * g.ldc + n] = v;
+                }
+            }
+    }
+}
+
+// W[d0][d1][khw] -> Wt[d1][d0][khw]   (weights for the dgrad-as-gather GEMM)
+__global__ __launch_bounds__(256) void swap01_kernel(const float *__restrict__ w, float *__restrict__ wt, const int d0,
+                                                     const int d1, const int khw) {
+    const long long total = (long long)d0 * d1 * khw;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)blockDim.x * gridDim.x) {
+        const int t = (int)(idx % khw);
+        const long long r = idx / khw;
+        const int b = (int)(r % d0), a = (int)(r / d0);  // output index (a in d1, b in d0)
+        wt[idx] = w[((size_t)b * d1 + a) * khw + t];
+    }
+}
+
+// ----------------------------- host-side dispatch --------------------------
+static int pick_splits(long long tiles, int K, int want_blocks = 512) {
+    if (tiles >= 256) return 1;
+    int s = (int)((want_blocks + tiles - 1) / tiles);
+    int max_s = K / (BK * 4);  // at least 4 K-steps per split
+    if (max_s < 1) max_s = 1;
+    if (s > max_s) s = max_s;
+    if (s > 64) s = 64;
+    return s < 1 ? 1 : s;
+}
+
+static int round_k_per_split(int K, int splits) {
+    int kps = (K + splits - 1) / splits;
+    kps = (kps + BK - 1) / BK * BK;
+    return kps;
+}
+
+template <int KH, int KW, int S, bool DGRAD>
+static int launch_conv(const float *Wm, const float *X, const ConvGeom &g0, Epi e, float *ws, size_t ws_bytes,
+                       hipStream_t st) {
+    ConvGeom g = g0;
+    const bool small_m = g.M <= 64;
+    const int BMv = small_m ? 64 : 128, BNv = 128;
+    const long long tiles = (long long)cdiv(g.M, BMv) * cdiv(g.N, BNv);
+    int splits = pick_splits(tiles, g.K);
+    while (splits > 1 && (size_t)splits * g.M * g.N * sizeof(float) > ws_bytes) --splits;
+    g.k_per_split = round_k_per_split(g.K, splits);
+    splits = cdiv(g.K, g.k_per_split);
+    e.splits = splits;
+    e.ws = ws;
+    dim3 grid(cdiv(g.N, BNv), cdiv(g.M, BMv), splits);
+    if (small_m)
+        hipLaunchKernelGGL((conv_igemm_kernel<64, 128, KH, KW, S, DGRAD>), grid, dim3(256), 0, st, Wm, X, g, e);
+    else
+        hipLaunchKernelGGL((conv_igemm_kernel<128, 128, KH, KW, S, DGRAD>), grid, dim3(256), 0, st, Wm, X, g, e);
+    int rc = launch_status("conv_igemm_kernel");
+    if (rc || splits == 1) return rc;
+    hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(ew_grid((long long)g.M * g.N)), dim3(256), 0, st, ws, splits, g.M,
+                       g.N, g.dPHW, e.bias, e.act, e.slope, e.out);
+    return launch_status("conv_splitk_reduce_kernel");
+}
+
+template <int KH, int KW, int S>
+static int launch_wgrad(const float *dY, const float *X, WgradGeom g, float *dW, int accumulate, float *ws,
+                        size_t ws_bytes, hipStream_t st) {
+    const bool small = g.M <= 64;
+    const int BMv = small ? 64 : 128, BNv = (g.N <= 64) ? 64 : 128;
+    const long long tiles = (long long)cdiv(g.M, BMv) * cdiv(g.N, BNv);
+    int splits = pick_splits(tiles, g.K, 768);
+    while (splits > 1 && (size_t)splits * g.M * g.N * sizeof(float) > ws_bytes) --splits;
+    if ((size_t)splits * g.M * g.N * sizeof(float) > ws_bytes) { set_error("conv wgrad: workspace too small"); return SCDA_EINVAL; }
+    g.k_per_split = round_k_per_split(g.K, splits);
+    splits = cdiv(g.K, g.k_per_split);
+    dim3 grid(cdiv(g.N, BNv), cdiv(g.M, BMv), splits);
+    if (small && BNv == 64)
+        hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, KH, KW, S>), grid, dim3(256), 0, st, dY, X, g, ws);
+    else if (small)
+        hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, KH, KW, S>), grid, dim3(256), 0, st, dY, X, g, ws);
+    else if (BNv == 64)
+        hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, KH, KW, S>), grid, dim3(256), 0, st, dY, X, g, ws);
+    else
+        hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, KH, KW, S>), grid, dim3(256), 0, st, dY, X, g, ws);
+    int rc = launch_status("conv_wgrad_kernel");
+    if (rc) return rc;
+    const long long total = (long long)g.M * g.N;
+    hipLaunchKernelGGL(dense_splitk_reduce_kernel, dim3(ew_grid(total)), dim3(256), 0, st, ws, splits, total, g.N,
+                       (const float *)nullptr, 0, (int)ACT_NONE, 0.f, accumulate, dW);
+    return launch_status("dense_splitk_reduce_kernel");
+}
+
+}  // namespace scda
+
+using namespace scda;
+
+#define CONV_DISPATCH(FN, ...)                                                                   \
+    if (KH == 3 && KW == 3 && S == 1) return FN<3, 3, 1 __VA_ARGS__;                              \
+    if (KH == 3 && KW == 3 && S == 2) return FN<3, 3, 2 __VA_ARGS__;                              \
+    if (KH == 1 && KW == 1 && S == 1) return FN<1, 1, 1 __VA_ARGS__;                              \
+    set_error("conv: unsupported kernel %dx%d stride %d (supported: 3x3 s1, 3x3 s2, 1x1 s1)", KH, KW, S); \
+    return SCDA_EINVAL;
+
+static int conv_out_dim(int in, int k, int s, int p) { return (in + 2 * p - k) / s + 1; }
+
+SCDA_API size_t scda_conv2d_workspace_bytes(int batch, int Cin, int IH, int IW, int Cout, int KH, int KW, int S, int P) {
+    // enough for: fwd/dgrad split-K slabs and wgrad slabs (<= 64 splits of the weight matrix,
+    // bounded by 8 output-sized slabs)
+    const int OH = conv_out_dim(IH, KH, S, P), OW = conv_out_dim(IW, KW, S, P);
+    size_t out_elems = (size_t)batch * Cout * OH * OW, in_elems = (size_t)batch * Cin * IH * IW;
+    size_t w_elems = (size_t)Cout * Cin * KH * KW;
+    size_t a = 8 * (out_elems > in_elems ? out_elems : in_elems);
+    size_t b = 64 * w_elems;
+    size_t cap = (size_t)256 << 20;  // slabs never need to exceed 256 MB: pick_splits shrinks to fit
+    size_t need = (a > b ? a : b) * sizeof(float);
+    if (need > cap) need = cap;
+    size_t minimum = 2 * w_elems * sizeof(float);
+    return need > minimum ? need : minimum;
+}
+
+SCDA_API int scda_conv2d_fwd_hip(const float *x, const float *w, const float *bias, float *y, int batch, int Cin, int IH,
+                                 int IW, int Cout, int KH, int KW, int S, int P, int act, float slope, void *ws,
+                                 size_t ws_bytes, void *stream) {
+    if (!x || !w || !y || batch <= 0 || Cin <= 0 || Cout <= 0) { set_error("scda_conv2d_fwd_hip: bad arguments"); return SCDA_EINVAL; }
+    const int OH = conv_out_dim(IH, KH, S, P), OW = conv_out_dim(IW, KW, S, P);
+    if (OH <= 0 || OW <= 0) { set_error("scda_conv2d_fwd_hip: empty output"); return SCDA_EINVAL; }
+    ConvGeom g;
+    g.batch = batch; g.CB = Cin; g.HB = IH; g.WB = IW; g.PH = OH; g.PW = OW; g.pad = P;
+    g.M = Cout; g.N = batch * OH * OW; g.K = Cin * KH * KW; g.k_per_split = 0;
+    g.dPHW = Div(OH * OW); g.dPW = Div(OW);
+    Epi e{y, nullptr, bias, 0, act, slope, 1};
+    CONV_DISPATCH(launch_conv, , false > (w, x, g, e, (float *)ws, ws_bytes, as_stream(stream)))
+}
+
+// dx = dgrad(dy, wt) where wt = swap01(w) is [Cin][Cout][KH][KW] (scda_conv2d_swap01_hip)
+SCDA_API int scda_conv2d_dgrad_hip(const float *dy, const float *wt, float *dx, int batch, int Cin, int IH, int IW,
+                                   int Cout, int KH, int KW, int S, int P, void *ws, size_t ws_bytes, void *stream) {
+    if (!dy || !wt || !dx || batch <= 0) { set_error("scda_conv2d_dgrad_hip: bad arguments"); return SCDA_EINVAL; }
+    const int OH = conv_out_dim(IH, KH, S, P), OW = conv_out_dim(IW, KW, S, P);
+    ConvGeom g;
+    g.batch = batch; g.CB = Cout; g.HB = OH; g.WB = OW; g.PH = IH; g.PW = IW; g.pad = P;
+    g.M = Cin; g.N = batch * IH * IW; g.K = Cout * KH * KW; g.k_per_split = 0;
+    g.dPHW = Div(IH * IW); g.dPW = Div(IW);
+    Epi e{dx, nullptr, nullptr, 0, (int)ACT_NONE, 0.f, 1};
+    CONV_DISPATCH(launch_conv, , true > (wt, dy, g, e, (float *)ws, ws_bytes, as_stream(stream)))
+}
+
+SCDA_API int scda_conv2d_swap01_hip(const float *w, float *wt, int Cout, int Cin, int KH, int KW, void *stream) {
+    if (!w || !wt) { set_error("scda_conv2d_swap01_hip: null pointer"); return SCDA_EINVAL; }
+    const long long total = (long long)Cout * Cin * KH * KW;
+    hipLaunchKernelGGL(swap01_kernel, dim3(ew_grid(total)), dim3(256), 0, as_stream(stream), w, wt, Cout, Cin, KH * KW);
+    return launch_status("swap01_kernel");
+}
+
+SCDA_API int scda_conv2d_wgrad_hip(const float *dy, const float *x, float *dw, int batch, int Cin, int IH, int IW,
+                                   int Cout, int KH, int KW, int S, int P, int accumulate, void *ws, size_t ws_bytes,
+                                   void *stream) {
+    if (!dy || !x || !dw || !ws) { set_error("scda_conv2d_wgrad_hip: bad arguments"); return SCDA_EINVAL; }
+    const int OH = conv_out_dim(IH, KH, S, P), OW = conv_out_dim(IW, KW, S, P);
+    WgradGeom g;
+    g.batch = batch; g.Cin = Cin; g.IH = IH; g.IW = IW; g.Cout = Cout; g.OH = OH; g.OW = OW; g.pad = P;
+    g.M = Cout; g.N = Cin * KH * KW; g.K = batch * OH * OW; g.k_per_split = 0;
+    g.dOHW = Div(OH * OW); g.dOW = Div(OW);
+    CONV_DISPATCH(launch_wgrad, > (dy, x, g, dw, accumulate, (float *)ws, ws_bytes, as_stream(stream)))
+}
+
+SCDA_API size_t scda_gemm_workspace_bytes(int M, int N, int K) {
+    (void)K;
+    return (size_t)16 * M * N * sizeof(float);
+}
+
+// C[M][N] (ldc) = op(A) op(B) (+bias) -> act ; trans_a: A stored [K][M]; trans_b: B stored [K][N]
+SCDA_API int scda_gemm_hip(const float *A, const float *B, float *C, int M, int N, int K, int lda, int ldb, int ldc,
+                           int trans_a, int trans_b, const float *bias, int bias_on_n, int act, float slope,
+                           int accumulate, void *ws, size_t ws_bytes, void *stream) {
+    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) { set_error("scda_gemm_hip: bad arguments"); return SCDA_EINVAL; }
+    hipStream_t st = as_stream(stream);
+    const int BMv = (M <= 64) ? 64 : 128, BNv = (N <= 64) ? 64 : 128;
+    const long long tiles = (long long)cdiv(M, BMv) * cdiv(N, BNv);
+    int splits = pick_splits(tiles, K);
+    if (accumulate && splits == 1 && ws) splits = 2 <= K / BK ? 2 : 1;
+    while (splits > 1 && (size_t)splits * M * N * sizeof(float) > ws_bytes) --splits;
+    if (accumulate && splits == 1) { set_error("scda_gemm_hip: accumulate needs a workspace"); return SCDA_EINVAL; }
+    if (splits > 1 && ldc != N) { set_error("scda_gemm_hip: split-K needs ldc == N"); return SCDA_EINVAL; }
+    GemmGeom g{M, N, K, lda, ldb, ldc, round_k_per_split(K, splits)};
+    splits = cdiv(K, g.k_per_split);
+    Epi e{C, (float *)ws, bias, bias_on_n, act, slope, splits};
+    dim3 grid(cdiv(N, BNv), cdiv(M, BMv), splits);
+#define GEMM_LAUNCH(BM_, BN_)                                                                            \
+    do {                                                                                                 \
+        if (!trans_a && !trans_b) hipLaunchKernelGGL((gemm_kernel<BM_, BN_, false, false>), grid, dim3(256), 0, st, A, B, g, e); \
+        else if (!trans_a && trans_b) hipLaunchKernelGGL((gemm_kernel<BM_, BN_, false, true>), grid, dim3(256), 0, st, A, B, g, e); \
+        else if (trans_a && !trans_b) hipLaunchKernelGGL((gemm_kernel<BM_, BN_, true, false>), grid, dim3(256), 0, st, A, B, g, e); \
+        else hipLaunchKernelGGL((gemm_kernel<BM_, BN_, true, true>), grid, dim3(256), 0, st, A, B, g, e);  \
+    } while (0)
+    if (BMv == 64 && BNv == 64) GEMM_LAUNCH(64, 64);
+    else if (BMv == 64) GEMM_LAUNCH(64, 128);
+    else if (BNv == 64) GEMM_LAUNCH(128, 64);
+    else GEMM_LAUNCH(128, 128);
+    int rc = launch_status("gemm_kernel");
+    if (rc || splits == 1) return rc;
+    const long long total = (long long)M * N;
+    hipLaunchKernelGGL(dense_splitk_reduce_kernel, dim3(ew_grid(total)), dim3(256), 0, st, (const float *)ws, splits,
+                       total, N, bias, bias_on_n, act, slope, accumulate, C);
+    return launch_status("dense_splitk_reduce_kernel");
+}

@@ -192,3 +192,126 @@ def bbox_overlaps(boxes, query):
     _check(lib().scda_bbox_overlaps_hip(_p(boxes), i32(boxes.shape[0]), _p(query), i32(query.shape[0]), _p(out),
                                         _stream()), "scda_bbox_overlaps_hip")
     return out
+
+
+# ------------------------------------------------- convolution / GEMM -------
+_WS = {}
+
+
+def workspace(nbytes, device):
+    """Grow-only per-device scratch buffer (split-K slabs); never freed during a run."""
+    key = (device.type, device.index)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _WS[key] = buf
+    return buf
+
+
+ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+_sz = ctypes.c_size_t
+
+
+def _conv_ws(batch, cin, ih, iw, cout, kh, kw, s, p, device):
+    L = lib()
+    L.scda_conv2d_workspace_bytes.restype = ctypes.c_size_t
+    n = L.scda_conv2d_workspace_bytes(i32(batch), i32(cin), i32(ih), i32(iw), i32(cout), i32(kh), i32(kw), i32(s), i32(p))
+    return workspace(n, device), n
+
+
+def conv2d_fwd(x, w, bias, stride, pad, act=ACT_NONE, slope=0.01):
+    _req(x, "x"); _req(w, "w")
+    if bias is not None:
+        _req(bias, "bias")
+    B, Cin, IH, IW = x.shape
+    Cout, Cin2, KH, KW = w.shape
+    if Cin2 != Cin:
+        raise ValueError(f"conv2d: input has {Cin} channels, weight expects {Cin2}")
+    OH = (IH + 2 * pad - KH) // stride + 1
+    OW = (IW + 2 * pad - KW) // stride + 1
+    y = torch.empty(B, Cout, OH, OW, dtype=torch.float32, device=x.device)
+    ws, n = _conv_ws(B, Cin, IH, IW, Cout, KH, KW, stride, pad, x.device)
+    _check(lib().scda_conv2d_fwd_hip(_p(x), _p(w), _p(bias), _p(y), i32(B), i32(Cin), i32(IH), i32(IW), i32(Cout), i32(KH),
+                                     i32(KW), i32(stride), i32(pad), i32(act), f32(slope), _p(ws), _sz(n), _stream()),
+           "scda_conv2d_fwd_hip")
+    return y
+
+
+def conv2d_swap01(w):
+    _req(w, "w")
+    Cout, Cin, KH, KW = w.shape
+    wt = torch.empty(Cin, Cout, KH, KW, dtype=torch.float32, device=w.device)
+    _check(lib().scda_conv2d_swap01_hip(_p(w), _p(wt), i32(Cout), i32(Cin), i32(KH), i32(KW), _stream()),
+           "scda_conv2d_swap01_hip")
+    return wt
+
+
+def conv2d_dgrad(dy, w, x_shape, stride, pad, wt=None):
+    _req(dy, "dy"); _req(w, "w")
+    B, Cin, IH, IW = x_shape
+    Cout, _, KH, KW = w.shape
+    if wt is None:
+        wt = conv2d_swap01(w)
+    dx = torch.empty(B, Cin, IH, IW, dtype=torch.float32, device=dy.device)
+    ws, n = _conv_ws(B, Cin, IH, IW, Cout, KH, KW, stride, pad, dy.device)
+    _check(lib().scda_conv2d_dgrad_hip(_p(dy), _p(wt), _p(dx), i32(B), i32(Cin), i32(IH), i32(IW), i32(Cout), i32(KH),
+                                       i32(KW), i32(stride), i32(pad), _p(ws), _sz(n), _stream()), "scda_conv2d_dgrad_hip")
+    return dx
+
+
+def conv2d_wgrad(dy, x, w_shape, stride, pad, out=None):
+    """dw = wgrad(dy, x); with `out` given, accumulates into it."""
+    _req(dy, "dy"); _req(x, "x")
+    B, Cin, IH, IW = x.shape
+    Cout, _, KH, KW = w_shape
+    acc = 0
+    if out is None:
+        out = torch.empty(tuple(w_shape), dtype=torch.float32, device=x.device)
+    else:
+        _req(out, "out"); acc = 1
+    ws, n = _conv_ws(B, Cin, IH, IW, Cout, KH, KW, stride, pad, x.device)
+    _check(lib().scda_conv2d_wgrad_hip(_p(dy), _p(x), _p(out), i32(B), i32(Cin), i32(IH), i32(IW), i32(Cout), i32(KH),
+                                       i32(KW), i32(stride), i32(pad), i32(acc), _p(ws), _sz(n), _stream()),
+           "scda_conv2d_wgrad_hip")
+    return out
+
+
+def gemm(a, b, M, N, K, lda, ldb, trans_a=False, trans_b=False, bias=None, bias_on_n=True, act=ACT_NONE, slope=0.01,
+         out=None, accumulate=False):
+    """C[M,N] (+)= op(A) op(B) (+bias) -> act.  See include/scda_ops.h for the operand layouts."""
+    _req(a, "a"); _req(b, "b")
+    if out is None:
+        if accumulate:
+            raise ValueError("accumulate needs out")
+        out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    else:
+        _req(out, "out")
+    L = lib()
+    L.scda_gemm_workspace_bytes.restype = ctypes.c_size_t
+    n = L.scda_gemm_workspace_bytes(i32(M), i32(N), i32(K))
+    ws = workspace(n, a.device)
+    _check(L.scda_gemm_hip(_p(a), _p(b), _p(out), i32(M), i32(N), i32(K), i32(lda), i32(ldb), i32(N), i32(int(trans_a)),
+                           i32(int(trans_b)), _p(bias), i32(int(bias_on_n)), i32(act), f32(slope), i32(int(accumulate)),
+                           _p(ws), _sz(n), _stream()), "scda_gemm_hip")
+    return out
+
+
+def linear_fwd(x, w, bias, act=ACT_NONE):
+    """y[M,out] = x[M,in] @ w[out,in]^T + b"""
+    M, K = x.shape
+    N = w.shape[0]
+    return gemm(x, w, M, N, K, K, K, False, False, bias, True, act)
+
+
+def linear_dgrad(dy, w):
+    """dx[M,in] = dy[M,out] @ w[out,in]"""
+    M, K = dy.shape
+    N = w.shape[1]
+    return gemm(dy, w, M, N, K, K, N, False, True)
+
+
+def linear_wgrad(dy, x, out=None):
+    """dw[out,in] (+)= dy[M,out]^T @ x[M,in]"""
+    Kb, M = dy.shape
+    N = x.shape[1]
+    return gemm(dy, x, M, N, Kb, M, N, True, True, out=out, accumulate=out is not None)

@@ -1,0 +1,108 @@
+"""fp32-MFMA conv / GEMM kernels vs a plain PyTorch fp32 CPU reference of the same op.
+Tolerance: the kernels are exact-fp32 FMA chains in a different summation order than the CPU
+reference; checked as max|err| / max|ref| < 2e-4 on outputs of O(1) magnitude."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def close(a, b, tol=2e-4):
+    a = a.detach().cpu().double(); b = b.detach().cpu().double()
+    assert a.shape == b.shape
+    scale = b.abs().max().item() + 1e-12
+    err = (a - b).abs().max().item() / scale
+    assert err < tol, f"relative-to-max error {err:.3e}"
+
+
+CONV_CASES = [
+    # B, Cin, H, W, Cout, k, s, p
+    (1, 3, 32, 64, 64, 3, 1, 1),      # conv1_1-like: K=27 (ragged K), M=64
+    (1, 64, 32, 48, 64, 3, 1, 1),
+    (2, 16, 20, 28, 40, 3, 1, 1),     # ragged everything, batch 2, non-pow2 extents
+    (1, 128, 16, 32, 256, 3, 1, 1),   # M=256 (two 128 tiles)
+    (1, 512, 8, 16, 512, 3, 1, 1),    # split-K path (few tiles)
+    (4, 3, 64, 64, 32, 3, 2, 1),      # discriminator stride 2
+    (4, 32, 32, 32, 64, 3, 2, 1),
+    (4, 128, 16, 16, 1, 1, 1, 0),     # 1x1 -> 1 channel
+    (1, 512, 8, 16, 30, 1, 1, 0),     # RPN cls head
+    (4, 32, 32, 32, 3, 1, 1, 0),      # decoder's final 1x1
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_conv2d_fwd(cuda, case, act):
+    from scda_amd import native
+    B, Cin, H, W, Cout, k, s, p = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x, w, b, stride=s, padding=p)
+    ref = [lambda t: t, F.relu, lambda t: F.leaky_relu(t, 0.01)][act](ref)
+    y = native.conv2d_fwd(x.to(cuda), w.to(cuda), b.to(cuda), s, p, act, 0.01)
+    close(y, ref)
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_dgrad_wgrad(cuda, case):
+    from scda_amd import native
+    B, Cin, H, W, Cout, k, s, p = case
+    g = torch.Generator().manual_seed(sum(case) + 1)
+    x = torch.randn(B, Cin, H, W, generator=g, requires_grad=True)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).requires_grad_()
+    y = F.conv2d(x, w, None, stride=s, padding=p)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    dx = native.conv2d_dgrad(dy.to(cuda), w.detach().to(cuda), x.shape, s, p)
+    close(dx, x.grad)
+    dw = native.conv2d_wgrad(dy.to(cuda), x.detach().to(cuda), w.shape, s, p)
+    close(dw, w.grad)
+    dw2 = native.conv2d_wgrad(dy.to(cuda), x.detach().to(cuda), w.shape, s, p, out=dw.clone())
+    close(dw2, 2 * w.grad)
+
+
+def test_conv_identity_asymmetric(cuda):
+    """A = I with an asymmetric B catches a transposed C/D fragment mapping."""
+    from scda_amd import native
+    C = 64
+    w = torch.zeros(C, C, 1, 1)
+    w[torch.arange(C), torch.arange(C), 0, 0] = 1.0
+    x = torch.arange(C * 8 * 16, dtype=torch.float32).reshape(1, C, 8, 16) * 1e-3
+    y = native.conv2d_fwd(x.to(cuda), w.to(cuda), None, 1, 0)
+    assert torch.equal(y.cpu(), x)
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 4096, 1024), (512, 9, 4096), (512, 36, 4096), (37, 50, 70), (128, 128, 16),
+                                   (512, 4096, 25088 // 8)])
+def test_linear_fwd_bwd(cuda, M, N, K):
+    from scda_amd import native
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g, requires_grad=True)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).requires_grad_()
+    b = torch.randn(N, generator=g)
+    y = F.linear(x, w, b)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    close(native.linear_fwd(x.detach().to(cuda), w.detach().to(cuda), b.to(cuda)), y)
+    close(native.linear_fwd(x.detach().to(cuda), w.detach().to(cuda), b.to(cuda), act=1), F.relu(y))
+    close(native.linear_dgrad(dy.to(cuda), w.detach().to(cuda)), x.grad)
+    dw = native.linear_wgrad(dy.to(cuda), x.detach().to(cuda))
+    close(dw, w.grad)
+    close(native.linear_wgrad(dy.to(cuda), x.detach().to(cuda), out=dw.clone()), 2 * w.grad)
+
+
+def test_conv_full_size_linearity(cuda):
+    """Size-independent property at BASELINE size (conv1_2, 512x1024): conv(a*x1 + x2) == a*conv(x1) + conv(x2)."""
+    from scda_amd import native
+    torch.manual_seed(0)
+    x1 = torch.randn(1, 64, 512, 1024, device=cuda); x2 = torch.randn(1, 64, 512, 1024, device=cuda)
+    w = torch.randn(64, 64, 3, 3, device=cuda) / 24
+    y1 = native.conv2d_fwd(x1, w, None, 1, 1)
+    y = native.conv2d_fwd(2.5 * x1 + x2, w, None, 1, 1)
+    y12 = 2.5 * y1 + native.conv2d_fwd(x2, w, None, 1, 1)
+    close(y, y12, tol=1e-4)
+    ref = F.conv2d(x1[:, :, :10, :66].cpu(), w.cpu(), None, padding=1)
+    close(y1[:, :, :9, :65], ref[:, :, :9, :65])
