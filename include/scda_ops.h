@@ -141,6 +141,65 @@ int scda_gemm_hip(const float *A, const float *B, float *C, int M, int N, int K,
                   int trans_a, int trans_b, const float *bias, int bias_on_n, int act, float slope, int accumulate,
                   void *ws, size_t ws_bytes, void *stream);
 
+/* ------------------------------------------------------ layer kernels ---- */
+/* HBM-bound pieces the reference reaches through torch.nn / torch.nn.functional.
+ * `grad_scalar` arguments are DEVICE pointers to the upstream scalar gradient so
+ * that no loss value ever has to visit the host.                                */
+/* nn.MaxPool2d(2,2): vgg_adver_expansion_cluster.py:106.  idx uint8 = winner 0..3 */
+int scda_maxpool2x2_fwd_hip(const float *x, float *y, uint8_t *idx, int planes, int H, int W, void *stream);
+int scda_maxpool2x2_bwd_hip(const float *dy, const uint8_t *idx, float *dx, int planes, int H, int W, void *stream);
+/* mode: 0 ReLU, 1 LeakyReLU(slope), 2 tanh, 3 sigmoid; backward takes the forward OUTPUT y */
+int scda_act_fwd_hip(const float *x, float *y, long long n, int mode, float slope, void *stream);
+int scda_act_bwd_hip(const float *dy, const float *y, float *dx, long long n, int mode, float slope, void *stream);
+/* y = alpha*a + beta*b (b may be NULL) */
+int scda_axpby_hip(const float *a, const float *b, float *y, long long n, float alpha, float beta, void *stream);
+/* nn.Dropout(p): mask[i] = keep ? 1 : 0 from a counter-based generator; y = mask ? x*scale : 0 */
+int scda_dropout_mask_hip(uint8_t *mask, long long n, float p, uint64_t seed, void *stream);
+int scda_dropout_apply_hip(const float *x, const uint8_t *mask, float *y, long long n, float scale, void *stream);
+int scda_bias_grad_nchw_hip(const float *dy, float *db, int B, int C, int HW, int accumulate, void *stream);
+int scda_colsum_hip(const float *dy, float *db, int M, int N, int accumulate, void *stream);
+/* F.cross_entropy(ignore_index), mean over valid rows (faster_rcnn_adver_expansion_reweight_cluster.py:49,63)
+ * out2[0] = loss, out2[1] = number of valid rows; probs [R,C] is kept for the backward */
+int scda_softmax_ce_fwd_hip(const float *logits, const int64_t *targets, int R, int C, int ignore_index, float *probs,
+                            float *out2, void *stream);
+int scda_softmax_ce_bwd_hip(const float *probs, const int64_t *targets, int R, int C, int ignore_index,
+                            const float *fwd_out2, const float *grad_scalar, float *dlogits, void *stream);
+int scda_row_softmax_hip(const float *x, float *y, int R, int C, void *stream);
+/* top-1 accuracy in percent over rows whose target != ignore_index (...reweight_cluster.py:249-267) */
+int scda_accuracy_hip(const float *logits, const int64_t *targets, int R, int C, int ignore_index, float *out1,
+                      void *stream);
+/* smooth_l1_loss_with_sigma(pred*mask, target, sigma) * scale  (...reweight_cluster.py:238-246; mask may be NULL) */
+size_t scda_smooth_l1_workspace_bytes(void);
+int scda_smooth_l1_fwd_hip(const float *pred, const float *mask, const float *target, long long n, float sigma,
+                           float scale, float *partial_ws, float *out1, void *stream);
+int scda_smooth_l1_bwd_hip(const float *pred, const float *mask, const float *target, long long n, float sigma,
+                           float scale, const float *grad_scalar, float *dpred, void *stream);
+/* nn.InstanceNorm2d(affine=False) with optional fused activation (act 0/1/2 as for conv) : common_net.py:69-72,288-290 */
+int scda_instnorm_fwd_hip(const float *x, float *y, float *mean, float *rstd, int planes, int HW, float eps, int act,
+                          float slope, void *stream);
+int scda_instnorm_bwd_hip(const float *dy, const float *x, const float *mean, const float *rstd, float *dx, int planes,
+                          int HW, int act, float slope, void *stream);
+/* nn.BatchNorm2d, training mode, with optional fused activation : common_net.py:214-223 */
+int scda_batchnorm_fwd_hip(const float *x, float *y, const float *gamma, const float *beta, float *running_mean,
+                           float *running_var, float *save_mean, float *save_rstd, int B, int C, int HW, float eps,
+                           float momentum, int act, float slope, void *stream);
+int scda_batchnorm_bwd_hip(const float *dy, const float *x, const float *gamma, const float *beta,
+                           const float *save_mean, const float *save_rstd, float *dx /*may be NULL*/, float *dgamma,
+                           float *dbeta, int B, int C, int HW, int act, float slope, int accumulate, void *stream);
+/* Interpolate(scale_factor=2, 'bilinear', align_corners=True) : common_net.py:160-170 */
+int scda_upsample2x_fwd_hip(const float *x, float *y, int planes, int IH, int IW, void *stream);
+int scda_upsample2x_bwd_hip(const float *dy, float *dx, int planes, int IH, int IW, void *stream);
+/* F.binary_cross_entropy(p, t), mean : tools/faster_rcnn_train_val.py:584-600,627-628,675-687,723-732 */
+int scda_bce_fwd_hip(const float *p, const float *t, int n, float *out1, void *stream);
+int scda_bce_bwd_hip(const float *p, const float *t, int n, const float *grad_scalar, float *dp, void *stream);
+/* nn.AvgPool2d(full extent) and torch.mean(x, 1) */
+int scda_gap_fwd_hip(const float *x, float *y, int planes, int HW, void *stream);
+int scda_gap_bwd_hip(const float *dy, float *dx, int planes, int HW, void *stream);
+int scda_row_mean_hip(const float *x, float *y, int R, int C, void *stream);
+/* torch.optim.Adam step on one flat bucket (tools/faster_rcnn_train_val.py:305-316); step counts from 1 */
+int scda_adam_hip(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long long n, float lr,
+                  float beta1, float beta2, float eps, float weight_decay, int step, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

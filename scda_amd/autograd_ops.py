@@ -1,0 +1,294 @@
+"""torch.autograd.Function wrappers around the HIP kernels (scda_amd.native).
+
+PyTorch is plumbing here: it owns device memory, the stream and the backward
+graph walk; every forward/backward body below is one or more calls through the
+C ABI of libscda_ops.so.  No Function has a CPU branch.
+"""
+import torch
+from torch.autograd import Function
+
+from . import native as N
+
+ACT_NONE, ACT_RELU, ACT_LEAKY = N.ACT_NONE, N.ACT_RELU, N.ACT_LEAKY
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+class Conv2dFn(Function):
+    """conv (+bias) (+ReLU/LeakyReLU) in one MFMA kernel; backward = act' -> dgrad, wgrad, bias-grad."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad, act, slope):
+        x = _c(x); w = _c(w)
+        y = N.conv2d_fwd(x, w, b, stride, pad, act, slope)
+        ctx.cfg = (stride, pad, act, slope)
+        ctx.has_bias = b is not None
+        ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        stride, pad, act, slope = ctx.cfg
+        dy = _c(dy)
+        if act != ACT_NONE:
+            dy = N.act_bwd(dy, y, 0 if act == ACT_RELU else 1, slope)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = N.conv2d_dgrad(dy, w, x.shape, stride, pad)
+        if ctx.needs_input_grad[1]:
+            dw = N.conv2d_wgrad(dy, x, w.shape, stride, pad)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = N.bias_grad_nchw(dy)
+        return dx, dw, db, None, None, None, None
+
+
+class LinearFn(Function):
+    @staticmethod
+    def forward(ctx, x, w, b, act):
+        x = _c(x); w = _c(w)
+        y = N.linear_fwd(x, w, b, act)
+        ctx.act = act
+        ctx.has_bias = b is not None
+        ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        dy = _c(dy)
+        if ctx.act != ACT_NONE:
+            dy = N.act_bwd(dy, y, 0, 0.0)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = N.linear_dgrad(dy, w)
+        if ctx.needs_input_grad[1]:
+            dw = N.linear_wgrad(dy, x)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = N.colsum(dy)
+        return dx, dw, db, None
+
+
+class MaxPool2x2Fn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        y, idx = N.maxpool2x2_fwd(x)
+        ctx.save_for_backward(idx)
+        ctx.xshape = tuple(x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        return N.maxpool2x2_bwd(_c(dy), idx, ctx.xshape)
+
+
+class ActFn(Function):
+    """stand-alone ReLU / LeakyReLU / tanh / sigmoid (mode = N.ACT_MODE[...])"""
+
+    @staticmethod
+    def forward(ctx, x, mode, slope):
+        y = N.act_fwd(_c(x), mode, slope)
+        ctx.cfg = (mode, slope)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        mode, slope = ctx.cfg
+        return N.act_bwd(_c(dy), y, mode, slope), None, None
+
+
+class DropoutFn(Function):
+    @staticmethod
+    def forward(ctx, x, mask, scale):
+        ctx.save_for_backward(mask)
+        ctx.scale = scale
+        return N.dropout_apply(_c(x), mask, scale)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (mask,) = ctx.saved_tensors
+        return N.dropout_apply(_c(dy), mask, ctx.scale), None, None
+
+
+class AddFn(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        return N.axpby(_c(a), _c(b), 1.0, 1.0)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+class RoIPoolFn(Function):
+    """extensions/_roi_pooling/functions/roi_pool.py:6-42 (differentiable w.r.t. features only)"""
+
+    @staticmethod
+    def forward(ctx, features, rois, ph, pw, scale):
+        if not features.is_contiguous() or not rois.is_contiguous():
+            raise AssertionError("RoIPool needs contiguous features and rois")  # roi_pool.py:25-26
+        out, arg = N.roi_pool_fwd(features, rois, ph, pw, scale)
+        ctx.save_for_backward(rois, arg)
+        ctx.cfg = (tuple(features.shape), ph, pw, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        rois, arg = ctx.saved_tensors
+        shape, ph, pw, scale = ctx.cfg
+        return N.roi_pool_bwd(_c(dy), arg, rois, shape, ph, pw, scale), None, None, None, None
+
+
+class RoIAlignFn(Function):
+    """extensions/_roi_align/functions/roi_align.py:7-51"""
+
+    @staticmethod
+    def forward(ctx, features, rois, ah, aw, scale):
+        if not features.is_contiguous() or not rois.is_contiguous():
+            raise AssertionError("RoIAlign needs contiguous features and rois")
+        ctx.save_for_backward(rois)
+        ctx.cfg = (tuple(features.shape), ah, aw, scale)
+        return N.roi_align_fwd(features, rois, ah, aw, scale)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (rois,) = ctx.saved_tensors
+        shape, ah, aw, scale = ctx.cfg
+        return N.roi_align_bwd(_c(dy), rois, shape, ah, aw, scale), None, None, None, None
+
+
+class SoftmaxCEFn(Function):
+    """F.cross_entropy(logits, targets, ignore_index) -> 0-dim loss"""
+
+    @staticmethod
+    def forward(ctx, logits, targets, ignore_index):
+        out2, probs = N.softmax_ce_fwd(_c(logits), _c(targets), ignore_index)
+        ctx.save_for_backward(probs, targets, out2)
+        ctx.ignore = ignore_index
+        return out2[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        probs, targets, out2 = ctx.saved_tensors
+        return N.softmax_ce_bwd(probs, targets, out2, _c(g).reshape(1), ctx.ignore), None, None
+
+
+class SmoothL1Fn(Function):
+    """smooth_l1_loss_with_sigma(pred*mask, target, sigma) * scale -> 0-dim loss"""
+
+    @staticmethod
+    def forward(ctx, pred, mask, target, sigma, scale):
+        pred = _c(pred)
+        ctx.save_for_backward(pred, mask, target)
+        ctx.cfg = (sigma, scale)
+        return N.smooth_l1_fwd(pred, mask, target, sigma, scale)[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, mask, target = ctx.saved_tensors
+        sigma, scale = ctx.cfg
+        return N.smooth_l1_bwd(pred, mask, target, sigma, scale, _c(g).reshape(1)), None, None, None, None
+
+
+class InstanceNormFn(Function):
+    @staticmethod
+    def forward(ctx, x, eps, act, slope):
+        x = _c(x)
+        y, mean, rstd = N.instnorm_fwd(x, eps, act, slope)
+        ctx.save_for_backward(x, mean, rstd)
+        ctx.cfg = (act, slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd = ctx.saved_tensors
+        act, slope = ctx.cfg
+        return N.instnorm_bwd(_c(dy), x, mean, rstd, act, slope), None, None, None
+
+
+class BatchNormTrainFn(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, run_mean, run_var, eps, momentum, act, slope):
+        x = _c(x)
+        y, mean, rstd = N.batchnorm_fwd(x, gamma, beta, run_mean, run_var, eps, momentum, act, slope)
+        ctx.save_for_backward(x, gamma, beta, mean, rstd)
+        ctx.cfg = (act, slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, mean, rstd = ctx.saved_tensors
+        act, slope = ctx.cfg
+        dx, dg, db = N.batchnorm_bwd(_c(dy), x, gamma, beta, mean, rstd, act, slope, need_dx=ctx.needs_input_grad[0])
+        return dx, dg, db, None, None, None, None, None, None
+
+
+class Upsample2xFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        return N.upsample2x_fwd(_c(x))
+
+    @staticmethod
+    def backward(ctx, dy):
+        return N.upsample2x_bwd(_c(dy))
+
+
+class BCEFn(Function):
+    """F.binary_cross_entropy(p, t) (mean) -> 0-dim loss; differentiable w.r.t. p only"""
+
+    @staticmethod
+    def forward(ctx, p, t):
+        p = _c(p); t = _c(t)
+        ctx.save_for_backward(p, t)
+        return N.bce_fwd(p, t)[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        p, t = ctx.saved_tensors
+        return N.bce_bwd(p, t, _c(g).reshape(1)), None
+
+
+class GlobalAvgPoolFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.xshape = tuple(x.shape)
+        return N.gap_fwd(_c(x))
+
+    @staticmethod
+    def backward(ctx, dy):
+        return N.gap_bwd(_c(dy), ctx.xshape)
+
+
+# functional front-ends -------------------------------------------------------
+def conv2d(x, w, b=None, stride=1, padding=0, act=ACT_NONE, slope=0.01):
+    return Conv2dFn.apply(x, w, b, stride, padding, act, slope)
+
+
+def linear(x, w, b=None, act=ACT_NONE):
+    return LinearFn.apply(x, w, b, act)
+
+
+def cross_entropy(logits, targets, ignore_index=-100):
+    return SoftmaxCEFn.apply(logits, targets, ignore_index)
+
+
+def smooth_l1_sum(pred, mask, target, sigma=3.0, scale=1.0):
+    return SmoothL1Fn.apply(pred, mask, target, sigma, scale)
+
+
+def binary_cross_entropy(p, t):
+    return BCEFn.apply(p, t)
+
+
+def sigmoid(x):
+    return ActFn.apply(x, N.ACT_MODE["sigmoid"], 0.0)
+
+
+def tanh(x):
+    return ActFn.apply(x, N.ACT_MODE["tanh"], 0.0)

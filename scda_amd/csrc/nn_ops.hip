@@ -1,0 +1,782 @@
+// nn_ops.hip -- the HBM-bound layer kernels of the SCDA step for gfx950:
+// max-pool, activation gradients, bias gradients, dropout, soft-max cross-entropy,
+// smooth-L1, instance / batch norm, bilinear x2 up-sampling, tanh / sigmoid, BCE,
+// global average pool and the fused Adam update.  All reductions are
+// deterministic (fixed-shape trees, no float atomics).
+#include <float.h>
+
+#include "common.h"
+
+namespace scda {
+
+// ------------------------------------------------------------ reductions ----
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// sum over the workgroup; result valid in every thread. blockDim.x multiple of 64, <= 1024
+__device__ __forceinline__ float block_sum(float v, float *red /* >= 16 floats of LDS */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    v = wave_sum(v);
+    __syncthreads();  // protect red[] against a previous use
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += red[i];  // fixed order -> deterministic
+    return t;
+}
+
+// ------------------------------------------------------------- max pool -----
+// 2x2 stride 2 (models/faster_rcnn/vgg_adver_expansion_cluster.py:106). idx: 0..3 = winner (dy*2+dx)
+__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                           uint8_t *__restrict__ idx, const long long total,
+                                                           const int H, const int W, const int OH, const int OW) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)blockDim.x * gridDim.x) {
+        const int ox = (int)(i % OW);
+        const long long r = i / OW;
+        const int oy = (int)(r % OH);
+        const long long pc = r / OH;
+        const float *p = x + (pc * H + 2 * oy) * W + 2 * ox;
+        const float2 a = *reinterpret_cast<const float2 *>(p);
+        const float2 b = *reinterpret_cast<const float2 *>(p + W);
+        float m = a.x; int k = 0;
+        if (a.y > m || a.y != a.y) { m = a.y; k = 1; }
+        if (b.x > m || b.x != b.x) { m = b.x; k = 2; }
+        if (b.y > m || b.y != b.y) { m = b.y; k = 3; }
+        y[i] = m;
+        idx[i] = (uint8_t)k;
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float *__restrict__ dy, const uint8_t *__restrict__ idx,
+                                                           float *__restrict__ dx, const long long total, const int H,
+                                                           const int W, const int OH, const int OW) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)blockDim.x * gridDim.x) {
+        const int ox = (int)(i % OW);
+        const long long r = i / OW;
+        const int oy = (int)(r % OH);
+        const long long pc = r / OH;
+        const float g = dy[i];
+        const int k = idx[i];
+        float *p = dx + (pc * H + 2 * oy) * W + 2 * ox;
+        *reinterpret_cast<float2 *>(p) = make_float2(k == 0 ? g : 0.f, k == 1 ? g : 0.f);
+        *reinterpret_cast<float2 *>(p + W) = make_float2(k == 2 ? g : 0.f, k == 3 ? g : 0.f);
+    }
+}
+
+// ----------------------------------------------------------- elementwise ----
+// mode 0: relu'(y) ; 1: leaky'(y, slope) ; 2: tanh'(y) = 1-y^2 ; 3: sigmoid'(y) = y(1-y)
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ y,
+                                                      float *__restrict__ dx, const long long n, const int mode,
+                                                      const float slope) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)blockDim.x * gridDim.x) {
+        const float g = dy[i], v = y[i];
+        float d;
+        if (mode == 0) d = v > 0.f ? g : 0.f;
+        else if (mode == 1) d = v > 0.f ? g : g * slope;
+        else if (mode == 2) d = g * (1.f - v * v);
+        else d = g * v * (1.f - v);
+        dx[i] = d;
+    }
+}
+
+// mode 0 relu, 1 leaky, 2 tanh, 3 sigmoid (forward)
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                      const long long n, const int mode, const float slope) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)blockDim.x * gridDim.x) {
+        const float v = x[i];
+        float o;
+        if (mode == 0) o = v > 0.f ? v : 0.f;
+        else if (mode == 1) o = v > 0.f ? v : v * slope;
+        else if (mode == 2) o = tanhf(v);
+        else o = 1.f / (1.f + expf(-v));
+        y[i] = o;
+    }
+}
+
+// y = alpha*a + beta*b   (b may be null)
+__global__ __launch_bounds__(256) void axpby_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                    float *__restrict__ y, const long long n, const float alpha,
+                                                    const float beta) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)blockDim.x * gridDim.x)
+        y[i] = alpha * a[i] + (b ? beta * b[i] : 0.f);
+}
+
+// counter-based dropout mask: keep with probability (1-p).  splitmix64 of (seed, index).
+__device__ __forceinline__ uint32_t mix_hash(uint64_t seed, uint64_t i) {
+    uint64_t z = seed + (i + 1) * 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    z = z ^ (z >> 31);
+    return (uint32_t)(z >> 32);
+}
+
+__global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t *__restrict__ mask, const long long n, const float p,
+                                                           const uint64_t seed) {
+    const uint32_t thr = (uint32_t)((double)p * 4294967296.0 > 4294967295.0 ? 4294967295.0 : (double)p * 4294967296.0);
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)blockDim.x * gridDim.x)
+        mask[i] = mix_hash(seed, (uint64_t)i) >= thr ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void dropout_apply_kernel(const float *__restrict__ x, const uint8_t *__restrict__ mask,
+                                                            float *__restrict__ y, const long long n,
+                                                            const float scale) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)blockDim.x * gridDim.x)
+        y[i] = mask[i] ? x[i] * scale : 0.f;
+}
+
+// ------------------------------------------------------- bias gradients -----
+// db[c] (+)= sum_{b,p} dy[b][c][p]     one workgroup per channel
+__global__ __launch_bounds__(256) void bias_grad_nchw_kernel(const float *__restrict__ dy, float *__restrict__ db,
+                                                             const int B, const int C, const int HW,
+                                                             const int accumulate) {
+    __shared__ float red[16];
+    const int c = blockIdx.x;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float *p = dy + ((size_t)b * C + c) * HW;
+        for (int i = threadIdx.x; i < HW; i += blockDim.x) s += p[i];
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) db[c] = accumulate ? db[c] + s : s;
+}
+
+// db[n] (+)= sum_m dy[m][n]    (linear bias): one thread per column, rows in order
+__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ dy, float *__restrict__ db, const int M,
+                                                     const int N, const int accumulate) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int m = 0; m < M; ++m) s += dy[(size_t)m * N + n];
+    db[n] = accumulate ? db[n] + s : s;
+}
+
+// ------------------------------------------- soft-max cross entropy (mean) --
+// F.cross_entropy(logits[R,C], targets[R], ignore_index) -- faster_rcnn_adver_expansion_reweight_cluster.py:49,63
+// single workgroup: R <= ~1e5 rows, C small.  out[0] = mean loss, out[1] = #valid rows, probs[R,C] saved.
+__global__ __launch_bounds__(1024) void softmax_ce_fwd_kernel(const float *__restrict__ x, const int64_t *__restrict__ t,
+                                                              const int R, const int C, const int ignore,
+                                                              float *__restrict__ probs, float *__restrict__ out) {
+    __shared__ float red[16];
+    float ls = 0.f, cnt = 0.f;
+    for (int r = threadIdx.x; r < R; r += blockDim.x) {
+        const float *row = x + (size_t)r * C;
+        float mx = -FLT_MAX;
+        for (int c = 0; c < C; ++c) mx = fmaxf(mx, row[c]);
+        float es = 0.f;
+        for (int c = 0; c < C; ++c) es += expf(row[c] - mx);
+        const float lse = logf(es);
+        for (int c = 0; c < C; ++c) probs[(size_t)r * C + c] = expf(row[c] - mx - lse);
+        const int tt = (int)t[r];
+        if (tt != ignore) { ls += -(row[tt] - mx - lse); cnt += 1.f; }
+    }
+    ls = block_sum(ls, red);
+    cnt = block_sum(cnt, red);
+    if (threadIdx.x == 0) { out[0] = ls / cnt; out[1] = cnt; }
+}
+
+// dlogits = (probs - onehot) * g / count for valid rows, 0 otherwise.  g: device scalar (upstream grad)
+__global__ __launch_bounds__(256) void softmax_ce_bwd_kernel(const float *__restrict__ probs, const int64_t *__restrict__ t,
+                                                             const int R, const int C, const int ignore,
+                                                             const float *__restrict__ fwd_out, const float *__restrict__ g,
+                                                             float *__restrict__ dx) {
+    const float scale = g[0] / fwd_out[1];
+    const long long n = (long long)R * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)blockDim.x * gridDim.x) {
+        const int r = (int)(i / C), c = (int)(i - (long long)r * C);
+        const int tt = (int)t[r];
+        dx[i] = (tt == ignore) ? 0.f : (probs[i] - (c == tt ? 1.f : 0.f)) * scale;
+    }
+}
+
+// row soft-max (RPN objectness, C = 2), not differentiated (used through .data in the reference)
+__global__ __launch_bounds__(256) void row_softmax_kernel(const float *__restrict__ x, float *__restrict__ y, const int R,
+                                                          const int C) {
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < R; r += blockDim.x * gridDim.x) {
+        const float *row = x + (size_t)r * C;
+        float mx = -FLT_MAX;
+        for (int c = 0; c < C; ++c) mx = fmaxf(mx, row[c]);
+        float es = 0.f;
+        for (int c = 0; c < C; ++c) es += expf(row[c] - mx);
+        for (int c = 0; c < C; ++c) y[(size_t)r * C + c] = expf(row[c] - mx) / es;
+    }
+}
+
+// top-1 accuracy in percent over rows with target != ignore (reweight_cluster.py:249-267)
+__global__ __launch_bounds__(1024) void accuracy_kernel(const float *__restrict__ x, const int64_t *__restrict__ t,
+                                                        const int R, const int C, const int ignore,
+                                                        float *__restrict__ out) {
+    __shared__ float red[16];
+    float ok = 0.f, cnt = 0.f;
+    for (int r = threadIdx.x; r < R; r += blockDim.x) {
+        const int tt = (int)t[r];
+        if (tt == ignore) continue;
+        const float *row = x + (size_t)r * C;
+        int best = 0; float bv = row[0];
+        for (int c = 1; c < C; ++c) if (row[c] > bv) { bv = row[c]; best = c; }
+        ok += (best == tt) ? 1.f : 0.f;
+        cnt += 1.f;
+    }
+    ok = block_sum(ok, red);
+    cnt = block_sum(cnt, red);
+    if (threadIdx.x == 0) out[0] = ok * (100.0f / cnt);
+}
+
+// ---------------------------------------------------------- smooth L1 -------
+// smooth_l1_loss_with_sigma(pred*mask, target, sigma) (reweight_cluster.py:238-246): SUM over elements.
+// two-stage deterministic reduction: per-block partials then a 1-block finish.
+__global__ __launch_bounds__(256) void smooth_l1_fwd_kernel(const float *__restrict__ pred, const float *__restrict__ mask,
+                                                            const float *__restrict__ target, const long long n,
+                                                            const float sigma2, float *__restrict__ partial) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)blockDim.x * gridDim.x) {
+        const float d = pred[i] * (mask ? mask[i] : 1.f) - target[i];
+        const float a = fabsf(d);
+        s += (a < 1.f / sigma2) ? d * d * sigma2 * 0.5f : a - 0.5f / sigma2;
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void finish_sum_kernel(const float *__restrict__ partial, const int np, const float scale,
+                                                         float *__restrict__ out) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < np; i += blockDim.x) s += partial[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) out[0] = s * scale;
+}
+
+__global__ __launch_bounds__(256) void smooth_l1_bwd_kernel(const float *__restrict__ pred, const float *__restrict__ mask,
+                                                            const float *__restrict__ target, const long long n,
+                                                            const float sigma2, const float scale,
+                                                            const float *__restrict__ g, float *__restrict__ dpred) {
+    const float gs = g[0] * scale;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)blockDim.x * gridDim.x) {
+        const float m = mask ? mask[i] : 1.f;
+        const float d = pred[i] * m - target[i];
+        const float a = fabsf(d);
+        const float dl = (a < 1.f / sigma2) ? d * sigma2 : (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+        dpred[i] = dl * m * gs;
+    }
+}
+
+// ------------------------------------------------------ instance norm -------
+// nn.InstanceNorm2d(affine=False, eps) (+ optional fused ReLU / LeakyReLU), one workgroup per (b,c) plane.
+// common_net.py:69-72 (INSResBlock), :288-289 (LeakyReLUConvTranspose2d_2)
+__global__ __launch_bounds__(256) void instnorm_fwd_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                           float *__restrict__ mean_out, float *__restrict__ rstd_out,
+                                                           const int HW, const float eps, const int act,
+                                                           const float slope) {
+    __shared__ float red[16];
+    const size_t base = (size_t)blockIdx.x * HW;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < HW; i += blockDim.x) s += x[base + i];
+    const float mean = block_sum(s, red) / (float)HW;
+    float v = 0.f;
+    for (int i = threadIdx.x; i < HW; i += blockDim.x) { const float d = x[base + i] - mean; v += d * d; }
+    const float var = block_sum(v, red) / (float)HW;
+    const float rstd = 1.f / sqrtf(var + eps);
+    for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+        float o = (x[base + i] - mean) * rstd;
+        if (act == 1) o = o > 0.f ? o : 0.f;
+        else if (act == 2) o = o > 0.f ? o : o * slope;
+        y[base + i] = o;
+    }
+    if (threadIdx.x == 0) { mean_out[blockIdx.x] = mean; rstd_out[blockIdx.x] = rstd; }
+}
+
+__global__ __launch_bounds__(256) void instnorm_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ x,
+                                                           const float *__restrict__ mean_in,
+                                                           const float *__restrict__ rstd_in, float *__restrict__ dx,
+                                                           const int HW, const int act, const float slope) {
+    __shared__ float red[16];
+    const size_t base = (size_t)blockIdx.x * HW;
+    const float mean = mean_in[blockIdx.x], rstd = rstd_in[blockIdx.x];
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+        const float xh = (x[base + i] - mean) * rstd;
+        float g = dy[base + i];
+        if (act == 1) g = xh > 0.f ? g : 0.f;
+        else if (act == 2) g = xh > 0.f ? g : g * slope;
+        s1 += g;
+        s2 += g * xh;
+    }
+    const float m1 = block_sum(s1, red) / (float)HW;
+    const float m2 = block_sum(s2, red) / (float)HW;
+    for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+        const float xh = (x[base + i] - mean) * rstd;
+        float g = dy[base + i];
+        if (act == 1) g = xh > 0.f ? g : 0.f;
+        else if (act == 2) g = xh > 0.f ? g : g * slope;
+        dx[base + i] = rstd * (g - m1 - xh * m2);
+    }
+}
+
+// --------------------------------------------------------- batch norm -------
+// nn.BatchNorm2d in training mode (+ fused LeakyReLU): common_net.py:214-223 (ResDis_cluster).
+// one workgroup per channel, statistics over (B, HW).
+__global__ __launch_bounds__(256) void batchnorm_fwd_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                            const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                            float *__restrict__ run_mean, float *__restrict__ run_var,
+                                                            float *__restrict__ mean_out, float *__restrict__ rstd_out,
+                                                            const int B, const int C, const int HW, const float eps,
+                                                            const float momentum, const int act, const float slope) {
+    __shared__ float red[16];
+    const int c = blockIdx.x;
+    const float n = (float)B * (float)HW;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float *p = x + ((size_t)b * C + c) * HW;
+        for (int i = threadIdx.x; i < HW; i += blockDim.x) s += p[i];
+    }
+    const float mean = block_sum(s, red) / n;
+    float v = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float *p = x + ((size_t)b * C + c) * HW;
+        for (int i = threadIdx.x; i < HW; i += blockDim.x) { const float d = p[i] - mean; v += d * d; }
+    }
+    const float var = block_sum(v, red) / n;
+    const float rstd = 1.f / sqrtf(var + eps);
+    const float ga = gamma[c], be = beta[c];
+    for (int b = 0; b < B; ++b) {
+        const float *p = x + ((size_t)b * C + c) * HW;
+        float *q = y + ((size_t)b * C + c) * HW;
+        for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+            float o = (p[i] - mean) * rstd * ga + be;
+            if (act == 2) o = o > 0.f ? o : o * slope;
+            else if (act == 1) o = o > 0.f ? o : 0.f;
+            q[i] = o;
+        }
+    }
+    if (threadIdx.x == 0) {
+        mean_out[c] = mean; rstd_out[c] = rstd;
+        if (run_mean) {
+            run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean;
+            run_var[c] = (1.f - momentum) * run_var[c] + momentum * var * (n / (n - 1.f));
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void batchnorm_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ x,
+                                                            const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                            const float *__restrict__ mean_in, const float *__restrict__ rstd_in,
+                                                            float *__restrict__ dx, float *__restrict__ dgamma,
+                                                            float *__restrict__ dbeta, const int B, const int C,
+                                                            const int HW, const int act, const float slope,
+                                                            const int accumulate) {
+    __shared__ float red[16];
+    const int c = blockIdx.x;
+    const float n = (float)B * (float)HW;
+    const float mean = mean_in[c], rstd = rstd_in[c], ga = gamma[c], be = beta[c];
+    float s1 = 0.f, s2 = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const size_t off = ((size_t)b * C + c) * HW;
+        for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+            const float xh = (x[off + i] - mean) * rstd;
+            const float pre = xh * ga + be;
+            float g = dy[off + i];
+            if (act == 2) g = pre > 0.f ? g : g * slope;
+            else if (act == 1) g = pre > 0.f ? g : 0.f;
+            s1 += g; s2 += g * xh;
+        }
+    }
+    const float sum1 = block_sum(s1, red), sum2 = block_sum(s2, red);
+    const float m1 = sum1 / n, m2 = sum2 / n;
+    if (dx) {
+        for (int b = 0; b < B; ++b) {
+            const size_t off = ((size_t)b * C + c) * HW;
+            for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+                const float xh = (x[off + i] - mean) * rstd;
+                const float pre = xh * ga + be;
+                float g = dy[off + i];
+                if (act == 2) g = pre > 0.f ? g : g * slope;
+                else if (act == 1) g = pre > 0.f ? g : 0.f;
+                dx[off + i] = ga * rstd * (g - m1 - xh * m2);
+            }
+        }
+    }
+    if (threadIdx.x == 0) {
+        dgamma[c] = accumulate ? dgamma[c] + sum2 : sum2;
+        dbeta[c] = accumulate ? dbeta[c] + sum1 : sum1;
+    }
+}
+
+// ------------------------------------------- bilinear x2, align_corners -----
+// Interpolate(scale_factor=2, mode='bilinear', align_corners=True): common_net.py:160-170
+__global__ __launch_bounds__(256) void upsample2_fwd_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                            const long long total, const int IH, const int IW,
+                                                            const int OH, const int OW, const float sh, const float sw) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)blockDim.x * gridDim.x) {
+        const int ox = (int)(i % OW);
+        const long long r = i / OW;
+        const int oy = (int)(r % OH);
+        const long long pc = r / OH;
+        const float fy = sh * (float)oy, fx = sw * (float)ox;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < IH - 1 ? 1 : 0), x1 = x0 + (x0 < IW - 1 ? 1 : 0);
+        const float ly1 = fminf(fmaxf(fy - (float)y0, 0.f), 1.f), lx1 = fminf(fmaxf(fx - (float)x0, 0.f), 1.f);
+        const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+        const float *p = x + pc * IH * IW;
+        y[i] = ly0 * (lx0 * p[y0 * IW + x0] + lx1 * p[y0 * IW + x1]) + ly1 * (lx0 * p[y1 * IW + x0] + lx1 * p[y1 * IW + x1]);
+    }
+}
+
+// gather-form backward: input pixel (iy,ix) collects from the output rows/cols whose
+// (y0|y1) equals iy -- deterministic, no atomics.
+__device__ __forceinline__ void up2_candidates(int i, int In, int On, float s, int &lo, int &hi) {
+    // outputs o with floor(s*o) in {i-1, i}:  o in [ceil((i-1)/s), floor((i+1)/s)] (clamped), checked exactly by the caller
+    lo = (int)floorf((float)(i - 1) / s) - 1;
+    hi = (int)ceilf((float)(i + 1) / s) + 1;
+    if (lo < 0) lo = 0;
+    if (hi > On - 1) hi = On - 1;
+    (void)In;
+}
+
+__global__ __launch_bounds__(256) void upsample2_bwd_kernel(const float *__restrict__ dy, float *__restrict__ dx,
+                                                            const long long total, const int IH, const int IW,
+                                                            const int OH, const int OW, const float sh, const float sw) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)blockDim.x * gridDim.x) {
+        const int ix = (int)(i % IW);
+        const long long r = i / IW;
+        const int iy = (int)(r % IH);
+        const long long pc = r / IH;
+        int ylo, yhi, xlo, xhi;
+        up2_candidates(iy, IH, OH, sh, ylo, yhi);
+        up2_candidates(ix, IW, OW, sw, xlo, xhi);
+        const float *g = dy + pc * OH * OW;
+        float acc = 0.f;
+        for (int oy = ylo; oy <= yhi; ++oy) {
+            const float fy = sh * (float)oy;
+            const int y0 = (int)fy;
+            const int y1 = y0 + (y0 < IH - 1 ? 1 : 0);
+            const float ly1 = fminf(fmaxf(fy - (float)y0, 0.f), 1.f), ly0 = 1.f - ly1;
+            const float wy = (y0 == iy ? ly0 : 0.f) + (y1 == iy ? ly1 : 0.f);
+            if (wy == 0.f) continue;
+            for (int ox = xlo; ox <= xhi; ++ox) {
+                const float fx = sw * (float)ox;
+                const int x0 = (int)fx;
+                const int x1 = x0 + (x0 < IW - 1 ? 1 : 0);
+                const float lx1 = fminf(fmaxf(fx - (float)x0, 0.f), 1.f), lx0 = 1.f - lx1;
+                const float wx = (x0 == ix ? lx0 : 0.f) + (x1 == ix ? lx1 : 0.f);
+                if (wx != 0.f) acc += wy * wx * g[oy * OW + ox];
+            }
+        }
+        dx[i] = acc;
+    }
+}
+
+// ------------------------------------------------------------- BCE ----------
+// F.binary_cross_entropy(p, t) mean with the log clamp at -100 (torch semantics);
+// faster_rcnn_train_val.py:584-600,627-628,675-687,723-732.  single workgroup (n <= ~1e5).
+__global__ __launch_bounds__(1024) void bce_fwd_kernel(const float *__restrict__ p, const float *__restrict__ t,
+                                                       const int n, float *__restrict__ out) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float pi = p[i], ti = t[i];
+        const float lp = fmaxf(logf(pi), -100.f), l1p = fmaxf(logf(1.f - pi), -100.f);
+        s += -(ti * lp + (1.f - ti) * l1p);
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) out[0] = s / (float)n;
+}
+
+__global__ __launch_bounds__(256) void bce_bwd_kernel(const float *__restrict__ p, const float *__restrict__ t, const int n,
+                                                      const float *__restrict__ g, float *__restrict__ dp) {
+    const float gs = g[0] / (float)n;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += blockDim.x * gridDim.x) {
+        const float pi = p[i];
+        dp[i] = (pi - t[i]) / fmaxf((1.f - pi) * pi, 1e-12f) * gs;
+    }
+}
+
+// ------------------------------------------------- global average pool ------
+// nn.AvgPool2d(full extent) : common_net.py:239.  y[bc] = mean_p x[bc][p]
+__global__ __launch_bounds__(256) void gap_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, const int HW) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < HW; i += blockDim.x) s += x[(size_t)blockIdx.x * HW + i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) y[blockIdx.x] = s / (float)HW;
+}
+
+__global__ __launch_bounds__(256) void gap_bwd_kernel(const float *__restrict__ dy, float *__restrict__ dx,
+                                                      const long long total, const int HW) {
+    const float inv = 1.f / (float)HW;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)blockDim.x * gridDim.x)
+        dx[i] = dy[i / HW] * inv;
+}
+
+// mean over the last dim: y[r] = mean_c x[r][c]   (x_target_patch_pro_mean, faster_rcnn_train_val.py:591)
+__global__ __launch_bounds__(256) void row_mean_kernel(const float *__restrict__ x, float *__restrict__ y, const int C) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < C; i += blockDim.x) s += x[(size_t)blockIdx.x * C + i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) y[blockIdx.x] = s / (float)C;
+}
+
+// ------------------------------------------------------------- Adam ---------
+// torch.optim.Adam(betas, eps=1e-8, weight_decay) with L2-coupled decay (faster_rcnn_train_val.py:305-316):
+//   g += wd*p ; m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
+// one pass over a flat parameter bucket: 4 reads + 3 writes of 4 B per parameter.
+__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+                                                   float *__restrict__ v, const long long n, const float lr,
+                                                   const float b1, const float b2, const float eps, const float wd,
+                                                   const float bc1, const float bc2_sqrt) {
+    const float step = lr / bc1;
+    const long long n4 = n / 4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)blockDim.x * gridDim.x) {
+        float4 pp = reinterpret_cast<float4 *>(p)[i];
+        const float4 gg = reinterpret_cast<const float4 *>(g)[i];
+        float4 mm = reinterpret_cast<float4 *>(m)[i], vv = reinterpret_cast<float4 *>(v)[i];
+#define ADAM1(P, G, M, V)                                   \
+    {                                                       \
+        const float gr = G + wd * P;                        \
+        M = b1 * M + (1.f - b1) * gr;                       \
+        V = b2 * V + (1.f - b2) * gr * gr;                  \
+        P = P - step * (M / (sqrtf(V) / bc2_sqrt + eps));   \
+    }
+        ADAM1(pp.x, gg.x, mm.x, vv.x) ADAM1(pp.y, gg.y, mm.y, vv.y) ADAM1(pp.z, gg.z, mm.z, vv.z) ADAM1(pp.w, gg.w, mm.w, vv.w)
+        reinterpret_cast<float4 *>(p)[i] = pp;
+        reinterpret_cast<float4 *>(m)[i] = mm;
+        reinterpret_cast<float4 *>(v)[i] = vv;
+    }
+    for (long long i = n4 * 4 + blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)blockDim.x * gridDim.x) {
+        float P = p[i], M = m[i], V = v[i];
+        const float G = g[i];
+        ADAM1(P, G, M, V)
+        p[i] = P; m[i] = M; v[i] = V;
+    }
+#undef ADAM1
+}
+
+}  // namespace scda
+
+using namespace scda;
+
+#define NN_CHECK(cond, name)                                      \
+    if (!(cond)) { set_error(name ": bad arguments"); return SCDA_EINVAL; }
+
+SCDA_API int scda_maxpool2x2_fwd_hip(const float *x, float *y, uint8_t *idx, int planes, int H, int W, void *stream) {
+    NN_CHECK(x && y && idx && planes > 0 && H >= 2 && W >= 2 && (W % 2) == 0, "scda_maxpool2x2_fwd_hip")
+    const int OH = H / 2, OW = W / 2;
+    const long long total = (long long)planes * OH * OW;
+    hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(ew_grid(total) * 4), dim3(256), 0, as_stream(stream), x, y, idx, total, H, W, OH, OW);
+    return launch_status("maxpool2_fwd_kernel");
+}
+
+SCDA_API int scda_maxpool2x2_bwd_hip(const float *dy, const uint8_t *idx, float *dx, int planes, int H, int W,
+                                     void *stream) {
+    NN_CHECK(dy && dx && idx && planes > 0 && (H % 2) == 0 && (W % 2) == 0, "scda_maxpool2x2_bwd_hip")
+    const int OH = H / 2, OW = W / 2;
+    const long long total = (long long)planes * OH * OW;
+    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(ew_grid(total) * 4), dim3(256), 0, as_stream(stream), dy, idx, dx, total, H, W, OH, OW);
+    return launch_status("maxpool2_bwd_kernel");
+}
+
+SCDA_API int scda_act_fwd_hip(const float *x, float *y, long long n, int mode, float slope, void *stream) {
+    NN_CHECK(x && y && n >= 0 && mode >= 0 && mode <= 3, "scda_act_fwd_hip")
+    if (n == 0) return SCDA_OK;
+    hipLaunchKernelGGL(act_fwd_kernel, dim3(ew_grid(n) * 4), dim3(256), 0, as_stream(stream), x, y, n, mode, slope);
+    return launch_status("act_fwd_kernel");
+}
+
+SCDA_API int scda_act_bwd_hip(const float *dy, const float *y, float *dx, long long n, int mode, float slope,
+                              void *stream) {
+    NN_CHECK(dy && y && dx && n >= 0 && mode >= 0 && mode <= 3, "scda_act_bwd_hip")
+    if (n == 0) return SCDA_OK;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_grid(n) * 4), dim3(256), 0, as_stream(stream), dy, y, dx, n, mode, slope);
+    return launch_status("act_bwd_kernel");
+}
+
+SCDA_API int scda_axpby_hip(const float *a, const float *b, float *y, long long n, float alpha, float beta, void *stream) {
+    NN_CHECK(a && y && n >= 0, "scda_axpby_hip")
+    if (n == 0) return SCDA_OK;
+    hipLaunchKernelGGL(axpby_kernel, dim3(ew_grid(n) * 4), dim3(256), 0, as_stream(stream), a, b, y, n, alpha, beta);
+    return launch_status("axpby_kernel");
+}
+
+SCDA_API int scda_dropout_mask_hip(uint8_t *mask, long long n, float p, uint64_t seed, void *stream) {
+    NN_CHECK(mask && n >= 0 && p >= 0.f && p < 1.f, "scda_dropout_mask_hip")
+    if (n == 0) return SCDA_OK;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(ew_grid(n) * 4), dim3(256), 0, as_stream(stream), mask, n, p, seed);
+    return launch_status("dropout_mask_kernel");
+}
+
+SCDA_API int scda_dropout_apply_hip(const float *x, const uint8_t *mask, float *y, long long n, float scale, void *stream) {
+    NN_CHECK(x && mask && y && n >= 0, "scda_dropout_apply_hip")
+    if (n == 0) return SCDA_OK;
+    hipLaunchKernelGGL(dropout_apply_kernel, dim3(ew_grid(n) * 4), dim3(256), 0, as_stream(stream), x, mask, y, n, scale);
+    return launch_status("dropout_apply_kernel");
+}
+
+SCDA_API int scda_bias_grad_nchw_hip(const float *dy, float *db, int B, int C, int HW, int accumulate, void *stream) {
+    NN_CHECK(dy && db && B > 0 && C > 0 && HW > 0, "scda_bias_grad_nchw_hip")
+    hipLaunchKernelGGL(bias_grad_nchw_kernel, dim3(C), dim3(256), 0, as_stream(stream), dy, db, B, C, HW, accumulate);
+    return launch_status("bias_grad_nchw_kernel");
+}
+
+SCDA_API int scda_colsum_hip(const float *dy, float *db, int M, int N, int accumulate, void *stream) {
+    NN_CHECK(dy && db && M > 0 && N > 0, "scda_colsum_hip")
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 256)), dim3(256), 0, as_stream(stream), dy, db, M, N, accumulate);
+    return launch_status("colsum_kernel");
+}
+
+SCDA_API int scda_softmax_ce_fwd_hip(const float *logits, const int64_t *targets, int R, int C, int ignore_index,
+                                     float *probs, float *out2, void *stream) {
+    NN_CHECK(logits && targets && probs && out2 && R > 0 && C > 0, "scda_softmax_ce_fwd_hip")
+    hipLaunchKernelGGL(softmax_ce_fwd_kernel, dim3(1), dim3(1024), 0, as_stream(stream), logits, targets, R, C, ignore_index, probs, out2);
+    return launch_status("softmax_ce_fwd_kernel");
+}
+
+SCDA_API int scda_softmax_ce_bwd_hip(const float *probs, const int64_t *targets, int R, int C, int ignore_index,
+                                     const float *fwd_out2, const float *grad_scalar, float *dlogits, void *stream) {
+    NN_CHECK(probs && targets && fwd_out2 && grad_scalar && dlogits && R > 0 && C > 0, "scda_softmax_ce_bwd_hip")
+    hipLaunchKernelGGL(softmax_ce_bwd_kernel, dim3(ew_grid((long long)R * C)), dim3(256), 0, as_stream(stream), probs, targets, R, C,
+                       ignore_index, fwd_out2, grad_scalar, dlogits);
+    return launch_status("softmax_ce_bwd_kernel");
+}
+
+SCDA_API int scda_row_softmax_hip(const float *x, float *y, int R, int C, void *stream) {
+    NN_CHECK(x && y && R > 0 && C > 0, "scda_row_softmax_hip")
+    hipLaunchKernelGGL(row_softmax_kernel, dim3(ew_grid(R)), dim3(256), 0, as_stream(stream), x, y, R, C);
+    return launch_status("row_softmax_kernel");
+}
+
+SCDA_API int scda_accuracy_hip(const float *logits, const int64_t *targets, int R, int C, int ignore_index, float *out1,
+                               void *stream) {
+    NN_CHECK(logits && targets && out1 && R > 0 && C > 0, "scda_accuracy_hip")
+    hipLaunchKernelGGL(accuracy_kernel, dim3(1), dim3(1024), 0, as_stream(stream), logits, targets, R, C, ignore_index, out1);
+    return launch_status("accuracy_kernel");
+}
+
+#define SL1_BLOCKS 512
+SCDA_API size_t scda_smooth_l1_workspace_bytes(void) { return SL1_BLOCKS * sizeof(float); }
+
+SCDA_API int scda_smooth_l1_fwd_hip(const float *pred, const float *mask, const float *target, long long n, float sigma,
+                                    float scale, float *partial_ws, float *out1, void *stream) {
+    NN_CHECK(pred && target && partial_ws && out1 && n > 0, "scda_smooth_l1_fwd_hip")
+    int blocks = ew_grid(n);
+    if (blocks > SL1_BLOCKS) blocks = SL1_BLOCKS;
+    hipLaunchKernelGGL(smooth_l1_fwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), pred, mask, target, n, sigma * sigma, partial_ws);
+    int rc = launch_status("smooth_l1_fwd_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(finish_sum_kernel, dim3(1), dim3(256), 0, as_stream(stream), (const float *)partial_ws, blocks, scale, out1);
+    return launch_status("finish_sum_kernel");
+}
+
+SCDA_API int scda_smooth_l1_bwd_hip(const float *pred, const float *mask, const float *target, long long n, float sigma,
+                                    float scale, const float *grad_scalar, float *dpred, void *stream) {
+    NN_CHECK(pred && target && grad_scalar && dpred && n > 0, "scda_smooth_l1_bwd_hip")
+    hipLaunchKernelGGL(smooth_l1_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, as_stream(stream), pred, mask, target, n, sigma * sigma, scale,
+                       grad_scalar, dpred);
+    return launch_status("smooth_l1_bwd_kernel");
+}
+
+SCDA_API int scda_instnorm_fwd_hip(const float *x, float *y, float *mean, float *rstd, int planes, int HW, float eps,
+                                   int act, float slope, void *stream) {
+    NN_CHECK(x && y && mean && rstd && planes > 0 && HW > 0, "scda_instnorm_fwd_hip")
+    hipLaunchKernelGGL(instnorm_fwd_kernel, dim3(planes), dim3(256), 0, as_stream(stream), x, y, mean, rstd, HW, eps, act, slope);
+    return launch_status("instnorm_fwd_kernel");
+}
+
+SCDA_API int scda_instnorm_bwd_hip(const float *dy, const float *x, const float *mean, const float *rstd, float *dx,
+                                   int planes, int HW, int act, float slope, void *stream) {
+    NN_CHECK(dy && x && mean && rstd && dx && planes > 0 && HW > 0, "scda_instnorm_bwd_hip")
+    hipLaunchKernelGGL(instnorm_bwd_kernel, dim3(planes), dim3(256), 0, as_stream(stream), dy, x, mean, rstd, dx, HW, act, slope);
+    return launch_status("instnorm_bwd_kernel");
+}
+
+SCDA_API int scda_batchnorm_fwd_hip(const float *x, float *y, const float *gamma, const float *beta, float *running_mean,
+                                    float *running_var, float *save_mean, float *save_rstd, int B, int C, int HW,
+                                    float eps, float momentum, int act, float slope, void *stream) {
+    NN_CHECK(x && y && gamma && beta && save_mean && save_rstd && B > 0 && C > 0 && HW > 0, "scda_batchnorm_fwd_hip")
+    hipLaunchKernelGGL(batchnorm_fwd_kernel, dim3(C), dim3(256), 0, as_stream(stream), x, y, gamma, beta, running_mean, running_var,
+                       save_mean, save_rstd, B, C, HW, eps, momentum, act, slope);
+    return launch_status("batchnorm_fwd_kernel");
+}
+
+SCDA_API int scda_batchnorm_bwd_hip(const float *dy, const float *x, const float *gamma, const float *beta,
+                                    const float *save_mean, const float *save_rstd, float *dx, float *dgamma,
+                                    float *dbeta, int B, int C, int HW, int act, float slope, int accumulate,
+                                    void *stream) {
+    NN_CHECK(dy && x && gamma && beta && save_mean && save_rstd && dgamma && dbeta && B > 0 && C > 0 && HW > 0, "scda_batchnorm_bwd_hip")
+    hipLaunchKernelGGL(batchnorm_bwd_kernel, dim3(C), dim3(256), 0, as_stream(stream), dy, x, gamma, beta, save_mean, save_rstd, dx,
+                       dgamma, dbeta, B, C, HW, act, slope, accumulate);
+    return launch_status("batchnorm_bwd_kernel");
+}
+
+static float up_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
+
+SCDA_API int scda_upsample2x_fwd_hip(const float *x, float *y, int planes, int IH, int IW, void *stream) {
+    NN_CHECK(x && y && planes > 0 && IH > 0 && IW > 0, "scda_upsample2x_fwd_hip")
+    const int OH = IH * 2, OW = IW * 2;
+    const long long total = (long long)planes * OH * OW;
+    hipLaunchKernelGGL(upsample2_fwd_kernel, dim3(ew_grid(total) * 4), dim3(256), 0, as_stream(stream), x, y, total, IH, IW, OH, OW,
+                       up_scale(IH, OH), up_scale(IW, OW));
+    return launch_status("upsample2_fwd_kernel");
+}
+
+SCDA_API int scda_upsample2x_bwd_hip(const float *dy, float *dx, int planes, int IH, int IW, void *stream) {
+    NN_CHECK(dy && dx && planes > 0 && IH > 1 && IW > 1, "scda_upsample2x_bwd_hip")
+    const int OH = IH * 2, OW = IW * 2;
+    const long long total = (long long)planes * IH * IW;
+    hipLaunchKernelGGL(upsample2_bwd_kernel, dim3(ew_grid(total) * 4), dim3(256), 0, as_stream(stream), dy, dx, total, IH, IW, OH, OW,
+                       up_scale(IH, OH), up_scale(IW, OW));
+    return launch_status("upsample2_bwd_kernel");
+}
+
+SCDA_API int scda_bce_fwd_hip(const float *p, const float *t, int n, float *out1, void *stream) {
+    NN_CHECK(p && t && out1 && n > 0, "scda_bce_fwd_hip")
+    hipLaunchKernelGGL(bce_fwd_kernel, dim3(1), dim3(1024), 0, as_stream(stream), p, t, n, out1);
+    return launch_status("bce_fwd_kernel");
+}
+
+SCDA_API int scda_bce_bwd_hip(const float *p, const float *t, int n, const float *grad_scalar, float *dp, void *stream) {
+    NN_CHECK(p && t && grad_scalar && dp && n > 0, "scda_bce_bwd_hip")
+    hipLaunchKernelGGL(bce_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, as_stream(stream), p, t, n, grad_scalar, dp);
+    return launch_status("bce_bwd_kernel");
+}
+
+SCDA_API int scda_gap_fwd_hip(const float *x, float *y, int planes, int HW, void *stream) {
+    NN_CHECK(x && y && planes > 0 && HW > 0, "scda_gap_fwd_hip")
+    hipLaunchKernelGGL(gap_fwd_kernel, dim3(planes), dim3(256), 0, as_stream(stream), x, y, HW);
+    return launch_status("gap_fwd_kernel");
+}
+
+SCDA_API int scda_gap_bwd_hip(const float *dy, float *dx, int planes, int HW, void *stream) {
+    NN_CHECK(dy && dx && planes > 0 && HW > 0, "scda_gap_bwd_hip")
+    const long long total = (long long)planes * HW;
+    hipLaunchKernelGGL(gap_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, as_stream(stream), dy, dx, total, HW);
+    return launch_status("gap_bwd_kernel");
+}
+
+SCDA_API int scda_row_mean_hip(const float *x, float *y, int R, int C, void *stream) {
+    NN_CHECK(x && y && R > 0 && C > 0, "scda_row_mean_hip")
+    hipLaunchKernelGGL(row_mean_kernel, dim3(R), dim3(256), 0, as_stream(stream), x, y, C);
+    return launch_status("row_mean_kernel");
+}
+
+SCDA_API int scda_adam_hip(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long long n, float lr,
+                           float beta1, float beta2, float eps, float weight_decay, int step, void *stream) {
+    NN_CHECK(param && grad && exp_avg && exp_avg_sq && n >= 0 && step >= 1, "scda_adam_hip")
+    if (n == 0) return SCDA_OK;
+    if ((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) != 0) {
+        set_error("scda_adam_hip: buffers must be 16-byte aligned");
+        return SCDA_EINVAL;
+    }
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n / 4 + 1) * 2), dim3(256), 0, as_stream(stream), param, grad, exp_avg, exp_avg_sq, n, lr,
+                       beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2));
+    return launch_status("adam_kernel");
+}

@@ -1,0 +1,50 @@
+"""Which implementation the host-side box logic calls for IoU and NMS.
+
+Default: the HIP kernels (through the C ABI).  Tests and the CPU oracle may
+plug the C oracle in with `use(...)` to exercise the host logic on a machine
+without a GPU; the product never does.
+"""
+import numpy as np
+import torch
+
+from scda_amd import native
+
+_impl = {}
+
+
+def _hip_bbox_overlaps(boxes, query):
+    dev = torch.device("cuda", torch.cuda.current_device())
+    b = torch.from_numpy(np.ascontiguousarray(boxes[:, :4], dtype=np.float32)).to(dev)
+    q = torch.from_numpy(np.ascontiguousarray(query[:, :4], dtype=np.float32)).to(dev)
+    return native.bbox_overlaps(b, q).cpu().numpy()
+
+
+def _hip_nms(dets, thresh, max_keep=0):
+    """dets: float tensor [N,5] sorted by score (any device) -> CPU LongTensor of kept indices."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    d = dets.to(dev, torch.float32).contiguous()
+    keep, num = native.nms(d, float(thresh), max_keep)
+    return keep[: int(num.item())].cpu().contiguous()
+
+
+def use(bbox_overlaps=None, nms=None):
+    if bbox_overlaps is not None:
+        _impl["bbox_overlaps"] = bbox_overlaps
+    if nms is not None:
+        _impl["nms"] = nms
+
+
+def reset():
+    _impl.clear()
+
+
+def bbox_overlaps(boxes, query):
+    return _impl.get("bbox_overlaps", _hip_bbox_overlaps)(boxes, query)
+
+
+def nms(dets, thresh, max_keep=0):
+    f = _impl.get("nms")
+    if f is None:
+        return _hip_nms(dets, thresh, max_keep)
+    k = f(dets, thresh)
+    return k[:max_keep] if max_keep and max_keep > 0 else k

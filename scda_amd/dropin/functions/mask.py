@@ -1,0 +1,45 @@
+"""Cluster-region generator -- the contract of functions/mask.py:183-237: k-means over RoI centres, then per cluster
+the first `threshold` member RoIs (or a with-replacement resample when the cluster is smaller) are stacked into
+[N_cluster, threshold, F].  The k-means is sklearn's (third-party, as in the reference: KMeans(n_clusters,
+random_state=0)); what changes here is the data path: the RoI features never leave the MI355X -- only the 512 RoI
+boxes (already on the host) feed the clustering, and the gather runs on the device.
+
+As in the reference the result is a NEW leaf tensor: no gradient flows back into the detector through it
+(functions/mask.py:202-203,234 round-trip through numpy)."""
+import numpy as np
+import torch
+
+
+def _np(x):
+    if x is None:
+        return None
+    return x.detach().cpu().numpy() if torch.is_tensor(x) else x
+
+
+def proposals_to_centers(proposals):
+    """[N,>=5] (b,x1,y1,x2,y2) -> [N,2] (cx, cy)"""
+    return np.stack([(proposals[:, 3] + proposals[:, 1]) / 2.0, (proposals[:, 4] + proposals[:, 2]) / 2.0], axis=1)
+
+
+def cluster_indices(proposals_np, N_cluster=4, threshold=128):
+    """-> (index int64 [N_cluster, threshold] into the RoI list, centres float64 [N_cluster, 2])"""
+    from sklearn.cluster import KMeans
+    km = KMeans(n_clusters=N_cluster, random_state=0).fit(proposals_to_centers(proposals_np))
+    rows = []
+    for c in range(N_cluster):
+        member = np.where(km.labels_[:] == c)[0]
+        if member.shape[0] < threshold:
+            member = member[np.random.choice(member.shape[0], threshold, replace=True)]
+        else:
+            member = member[0:threshold]
+        rows.append(member)
+    return np.stack(rows, axis=0).astype(np.int64), km.cluster_centers_
+
+
+def compute_cluster_targets(proposals, features, N_cluster=4, threshold=128):
+    """proposals [N,>=5], features [N,F] -> (cluster features [N_cluster, threshold, F] (leaf), centres [N_cluster,2])"""
+    idx, centres = cluster_indices(_np(proposals), N_cluster, threshold)
+    flat = torch.from_numpy(idx.reshape(-1)).to(features.device)
+    with torch.no_grad():
+        gathered = features.detach().index_select(0, flat).view(N_cluster, threshold, features.shape[1]).contiguous()
+    return gathered.float(), centres

@@ -1,0 +1,47 @@
+"""RPN proposal generation -- the contract of functions/rpn_proposal.py:17-74: top-k by objectness, decode,
+clip, min-size filter, NMS, keep post_nms_top_n.  Ordering uses the same numpy selection calls as the reference
+(np.argpartition / np.argsort tie behaviour is part of the result); NMS + greedy sweep run on the MI355X and stop
+as soon as post_nms_top_n boxes are kept."""
+import numpy as np
+import torch
+
+from scda_amd.dropin import backend
+from scda_amd.dropin.utils import anchor_helper, bbox_helper
+
+
+def compute_rpn_proposals(conv_cls, conv_loc, cfg, image_info):
+    """conv_cls [B, A*2, h, w] (soft-maxed), conv_loc [B, A*4, h, w] -> CPU float tensor [N,6] (b,x1,y1,x2,y2,score)"""
+    B, A4, fh, fw = conv_loc.shape
+    A = A4 // 4
+    assert A * 4 == A4
+    anchors = anchor_helper.get_anchors_over_plane(fh, fw, cfg['anchor_ratios'], cfg['anchor_scales'], cfg['anchor_stride'])
+    KA = fh * fw * A
+    cls = conv_cls.permute(0, 2, 3, 1).contiguous().view(B, KA, -1).cpu().numpy()
+    loc = conv_loc.permute(0, 2, 3, 1).contiguous().view(B, KA, 4).cpu().numpy()
+    if torch.is_tensor(image_info):
+        image_info = image_info.cpu().numpy()
+
+    top_n, keep_n = cfg['pre_nms_top_n'], cfg['post_nms_top_n']
+    out = []
+    for b in range(B):
+        score = cls[b, :, -1]
+        if top_n <= 0 or top_n > score.shape[0]:
+            order = score.argsort()[::-1]
+        else:
+            cand = np.argpartition(-score, top_n)[:top_n]
+            order = cand[np.argsort(-score[cand])]
+        score = score[order]
+        boxes = bbox_helper.compute_loc_bboxes(anchors[order, :], loc[b, order, :])
+        boxes = bbox_helper.clip_bbox(boxes, image_info[b])
+        props = np.hstack([boxes, score[:, None]])
+        big = (props[:, 2] - props[:, 0] + 1 >= cfg['roi_min_size']) & (props[:, 3] - props[:, 1] + 1 >= cfg['roi_min_size'])
+        props = props[big]
+        keep = backend.nms(torch.from_numpy(props).float(), cfg['nms_iou_thresh'], max_keep=max(keep_n, 0)).numpy()
+        if keep_n > 0:
+            keep = keep[:keep_n]
+        props = props[keep]
+        out.append(np.hstack([np.full((len(keep), 1), b), props]))
+    res = torch.from_numpy(np.vstack(out)).float()
+    if res.dim() < 2:
+        res = res.unsqueeze(0)
+    return res

@@ -1,0 +1,158 @@
+"""nn.Module layers whose forward/backward run on the HIP kernels.
+
+They subclass the torch.nn classes the reference uses so that parameter names,
+shapes, `state_dict()` keys and initialisation are identical (checkpoints and
+torchvision's vgg16-397923af.pth load unchanged), but none of them calls a
+torch compute kernel: forward dispatches to scda_amd.autograd_ops.
+"""
+import itertools
+
+import torch
+import torch.nn as nn
+
+from . import autograd_ops as A
+from . import native as N
+
+
+class Conv2d(nn.Conv2d):
+    """nn.Conv2d with an optional activation fused into the MFMA kernel's epilogue."""
+
+    def __init__(self, *args, fused_act=A.ACT_NONE, slope=0.01, **kw):
+        super().__init__(*args, **kw)
+        if self.groups != 1 or self.dilation != (1, 1) or self.padding_mode != "zeros":
+            raise NotImplementedError("scda_amd.Conv2d: groups/dilation/padding_mode are not part of the SCDA path")
+        if self.stride[0] != self.stride[1] or self.padding[0] != self.padding[1]:
+            raise NotImplementedError("scda_amd.Conv2d: anisotropic stride/padding")
+        self.fused_act = fused_act
+        self.slope = slope
+
+    def forward(self, x):
+        return A.conv2d(x, self.weight, self.bias, self.stride[0], self.padding[0], self.fused_act, self.slope)
+
+    def extra_repr(self):
+        s = super().extra_repr()
+        return s + (f", fused_act={self.fused_act}" if self.fused_act else "")
+
+
+class ConvTranspose1x1(nn.ConvTranspose2d):
+    """nn.ConvTranspose2d(kernel_size=1, stride=1): a 1x1 conv with the [in,out,1,1] weight read transposed."""
+
+    def __init__(self, cin, cout, **kw):
+        super().__init__(cin, cout, kernel_size=1, stride=1, padding=0, **kw)
+
+    def forward(self, x):
+        w = self.weight.transpose(0, 1).contiguous()  # [out,in,1,1]; 96 floats -- autograd handles the permutation
+        return A.conv2d(x, w, self.bias, 1, 0)
+
+
+class FusedAct(nn.Module):
+    """Placeholder that keeps nn.Sequential indices where the reference has nn.ReLU(inplace=True) /
+    nn.LeakyReLU(inplace=True) directly after a conv/linear/norm whose kernel already applied it."""
+
+    def __init__(self, name="ReLU"):
+        super().__init__()
+        self.name = name
+
+    def forward(self, x):
+        return x
+
+    def extra_repr(self):
+        return f"{self.name} (fused into the producer's epilogue)"
+
+
+class Linear(nn.Linear):
+    def __init__(self, *args, fused_act=A.ACT_NONE, **kw):
+        super().__init__(*args, **kw)
+        self.fused_act = fused_act
+
+    def forward(self, x):
+        return A.linear(x, self.weight, self.bias, self.fused_act)
+
+
+class MaxPool2x2(nn.Module):
+    def forward(self, x):
+        return A.MaxPool2x2Fn.apply(x)
+
+    def extra_repr(self):
+        return "kernel_size=2, stride=2"
+
+
+class Activation(nn.Module):
+    def __init__(self, mode, slope=0.01):
+        super().__init__()
+        self.mode = N.ACT_MODE[mode]
+        self.slope = slope
+
+    def forward(self, x):
+        return A.ActFn.apply(x, self.mode, self.slope)
+
+
+_dropout_counter = itertools.count(1)
+
+
+class Dropout(nn.Module):
+    """nn.Dropout(p).  The keep-mask comes from the library's counter-based generator, seeded from
+    torch.initial_seed() and a per-call counter; tests inject masks through `mask_source` so that the
+    CPU oracle and the device see the same Bernoulli draws."""
+
+    mask_source = None  # callable(shape, p, device) -> uint8 mask, or None
+
+    def __init__(self, p=0.5):
+        super().__init__()
+        self.p = float(p)
+
+    def forward(self, x):
+        if not self.training or self.p == 0.0:
+            return x
+        if Dropout.mask_source is not None:
+            mask = Dropout.mask_source(tuple(x.shape), self.p, x.device)
+        else:
+            seed = (torch.initial_seed() * 0x9E3779B1 + next(_dropout_counter)) & 0xFFFFFFFFFFFFFFFF
+            mask = N.dropout_mask(tuple(x.shape), self.p, seed, x.device)
+        return A.DropoutFn.apply(x, mask, 1.0 / (1.0 - self.p))
+
+    def extra_repr(self):
+        return f"p={self.p}"
+
+
+class InstanceNorm2d(nn.Module):
+    """nn.InstanceNorm2d(C) (affine=False, track_running_stats=False) with optional fused activation."""
+
+    def __init__(self, num_features, eps=1e-5, fused_act=A.ACT_NONE, slope=0.01):
+        super().__init__()
+        self.num_features = num_features
+        self.eps = eps
+        self.fused_act = fused_act
+        self.slope = slope
+
+    def forward(self, x):
+        return A.InstanceNormFn.apply(x, self.eps, self.fused_act, self.slope)
+
+
+class BatchNorm2d(nn.BatchNorm2d):
+    """nn.BatchNorm2d; training-mode statistics + running-stat update in one kernel, optional fused LeakyReLU."""
+
+    def __init__(self, num_features, fused_act=A.ACT_NONE, slope=0.01, **kw):
+        super().__init__(num_features, **kw)
+        self.fused_act = fused_act
+        self.slope = slope
+
+    def forward(self, x):
+        if not self.training:
+            raise NotImplementedError("scda_amd.BatchNorm2d: eval mode is not on the SCDA training path")
+        if self.num_batches_tracked is not None:
+            self.num_batches_tracked.add_(1)
+        return A.BatchNormTrainFn.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
+                                        self.momentum, self.fused_act, self.slope)
+
+
+class Upsample2x(nn.Module):
+    """Interpolate(scale_factor=2, mode='bilinear', align_corners=True)"""
+
+    def forward(self, x):
+        return A.Upsample2xFn.apply(x)
+
+
+class GlobalAvgPool(nn.Module):
+    def forward(self, x):
+        return A.GlobalAvgPoolFn.apply(x)

@@ -315,3 +315,240 @@ def linear_wgrad(dy, x, out=None):
     Kb, M = dy.shape
     N = x.shape[1]
     return gemm(dy, x, M, N, Kb, M, N, True, True, out=out, accumulate=out is not None)
+
+
+# ------------------------------------------------------ layer kernels -------
+i64 = ctypes.c_longlong
+u64 = ctypes.c_uint64
+
+
+def maxpool2x2_fwd(x):
+    _req(x, "x")
+    B, C, H, W = x.shape
+    y = torch.empty(B, C, H // 2, W // 2, dtype=torch.float32, device=x.device)
+    idx = torch.empty(B, C, H // 2, W // 2, dtype=torch.uint8, device=x.device)
+    _check(lib().scda_maxpool2x2_fwd_hip(_p(x), _p(y), _p(idx), i32(B * C), i32(H), i32(W), _stream()), "scda_maxpool2x2_fwd_hip")
+    return y, idx
+
+
+def maxpool2x2_bwd(dy, idx, x_shape):
+    _req(dy, "dy"); _req(idx, "idx", torch.uint8)
+    B, C, H, W = x_shape
+    dx = torch.empty(B, C, H, W, dtype=torch.float32, device=dy.device)
+    _check(lib().scda_maxpool2x2_bwd_hip(_p(dy), _p(idx), _p(dx), i32(B * C), i32(H), i32(W), _stream()), "scda_maxpool2x2_bwd_hip")
+    return dx
+
+
+ACT_MODE = {"relu": 0, "leaky": 1, "tanh": 2, "sigmoid": 3}
+
+
+def act_fwd(x, mode, slope=0.01):
+    _req(x, "x")
+    y = torch.empty_like(x)
+    _check(lib().scda_act_fwd_hip(_p(x), _p(y), i64(x.numel()), i32(mode), f32(slope), _stream()), "scda_act_fwd_hip")
+    return y
+
+
+def act_bwd(dy, y, mode, slope=0.01):
+    _req(dy, "dy"); _req(y, "y")
+    dx = torch.empty_like(dy)
+    _check(lib().scda_act_bwd_hip(_p(dy), _p(y), _p(dx), i64(dy.numel()), i32(mode), f32(slope), _stream()), "scda_act_bwd_hip")
+    return dx
+
+
+def axpby(a, b, alpha=1.0, beta=1.0):
+    _req(a, "a")
+    if b is not None:
+        _req(b, "b")
+    y = torch.empty_like(a)
+    _check(lib().scda_axpby_hip(_p(a), _p(b), _p(y), i64(a.numel()), f32(alpha), f32(beta), _stream()), "scda_axpby_hip")
+    return y
+
+
+def dropout_mask(shape, p, seed, device):
+    mask = torch.empty(shape, dtype=torch.uint8, device=device)
+    _check(lib().scda_dropout_mask_hip(_p(mask), i64(mask.numel()), f32(p), u64(seed & 0xFFFFFFFFFFFFFFFF), _stream()),
+           "scda_dropout_mask_hip")
+    return mask
+
+
+def dropout_apply(x, mask, scale):
+    _req(x, "x"); _req(mask, "mask", torch.uint8)
+    y = torch.empty_like(x)
+    _check(lib().scda_dropout_apply_hip(_p(x), _p(mask), _p(y), i64(x.numel()), f32(scale), _stream()), "scda_dropout_apply_hip")
+    return y
+
+
+def bias_grad_nchw(dy):
+    _req(dy, "dy")
+    B, C = dy.shape[0], dy.shape[1]
+    HW = dy.numel() // (B * C)
+    db = torch.empty(C, dtype=torch.float32, device=dy.device)
+    _check(lib().scda_bias_grad_nchw_hip(_p(dy), _p(db), i32(B), i32(C), i32(HW), i32(0), _stream()), "scda_bias_grad_nchw_hip")
+    return db
+
+
+def colsum(dy):
+    _req(dy, "dy")
+    M, N = dy.shape
+    db = torch.empty(N, dtype=torch.float32, device=dy.device)
+    _check(lib().scda_colsum_hip(_p(dy), _p(db), i32(M), i32(N), i32(0), _stream()), "scda_colsum_hip")
+    return db
+
+
+def softmax_ce_fwd(logits, targets, ignore_index=-100):
+    _req(logits, "logits"); _req(targets, "targets", torch.int64)
+    R, C = logits.shape
+    probs = torch.empty_like(logits)
+    out2 = torch.empty(2, dtype=torch.float32, device=logits.device)
+    _check(lib().scda_softmax_ce_fwd_hip(_p(logits), _p(targets), i32(R), i32(C), i32(ignore_index), _p(probs), _p(out2), _stream()),
+           "scda_softmax_ce_fwd_hip")
+    return out2, probs
+
+
+def softmax_ce_bwd(probs, targets, out2, g, ignore_index=-100):
+    _req(probs, "probs"); _req(g, "g")
+    R, C = probs.shape
+    dx = torch.empty_like(probs)
+    _check(lib().scda_softmax_ce_bwd_hip(_p(probs), _p(targets), i32(R), i32(C), i32(ignore_index), _p(out2), _p(g), _p(dx), _stream()),
+           "scda_softmax_ce_bwd_hip")
+    return dx
+
+
+def row_softmax(x):
+    _req(x, "x")
+    R, C = x.shape
+    y = torch.empty_like(x)
+    _check(lib().scda_row_softmax_hip(_p(x), _p(y), i32(R), i32(C), _stream()), "scda_row_softmax_hip")
+    return y
+
+
+def accuracy(logits, targets, ignore_index=-1):
+    _req(logits, "logits"); _req(targets, "targets", torch.int64)
+    R, C = logits.shape
+    out = torch.empty(1, dtype=torch.float32, device=logits.device)
+    _check(lib().scda_accuracy_hip(_p(logits), _p(targets), i32(R), i32(C), i32(ignore_index), _p(out), _stream()), "scda_accuracy_hip")
+    return out
+
+
+def smooth_l1_fwd(pred, mask, target, sigma, scale):
+    _req(pred, "pred"); _req(target, "target")
+    if mask is not None:
+        _req(mask, "mask")
+    L = lib()
+    L.scda_smooth_l1_workspace_bytes.restype = ctypes.c_size_t
+    ws = torch.empty(L.scda_smooth_l1_workspace_bytes() // 4, dtype=torch.float32, device=pred.device)
+    out = torch.empty(1, dtype=torch.float32, device=pred.device)
+    _check(L.scda_smooth_l1_fwd_hip(_p(pred), _p(mask), _p(target), i64(pred.numel()), f32(sigma), f32(scale), _p(ws), _p(out), _stream()),
+           "scda_smooth_l1_fwd_hip")
+    return out
+
+
+def smooth_l1_bwd(pred, mask, target, sigma, scale, g):
+    dp = torch.empty_like(pred)
+    _check(lib().scda_smooth_l1_bwd_hip(_p(pred), _p(mask), _p(target), i64(pred.numel()), f32(sigma), f32(scale), _p(g), _p(dp), _stream()),
+           "scda_smooth_l1_bwd_hip")
+    return dp
+
+
+def instnorm_fwd(x, eps, act, slope):
+    _req(x, "x")
+    B, C, H, W = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(B * C, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(B * C, dtype=torch.float32, device=x.device)
+    _check(lib().scda_instnorm_fwd_hip(_p(x), _p(y), _p(mean), _p(rstd), i32(B * C), i32(H * W), f32(eps), i32(act), f32(slope), _stream()),
+           "scda_instnorm_fwd_hip")
+    return y, mean, rstd
+
+
+def instnorm_bwd(dy, x, mean, rstd, act, slope):
+    _req(dy, "dy"); _req(x, "x")
+    B, C, H, W = x.shape
+    dx = torch.empty_like(x)
+    _check(lib().scda_instnorm_bwd_hip(_p(dy), _p(x), _p(mean), _p(rstd), _p(dx), i32(B * C), i32(H * W), i32(act), f32(slope), _stream()),
+           "scda_instnorm_bwd_hip")
+    return dx
+
+
+def batchnorm_fwd(x, gamma, beta, run_mean, run_var, eps, momentum, act, slope):
+    _req(x, "x"); _req(gamma, "gamma"); _req(beta, "beta")
+    B, C, H, W = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(C, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(C, dtype=torch.float32, device=x.device)
+    _check(lib().scda_batchnorm_fwd_hip(_p(x), _p(y), _p(gamma), _p(beta), _p(run_mean), _p(run_var), _p(mean), _p(rstd), i32(B), i32(C),
+                                        i32(H * W), f32(eps), f32(momentum), i32(act), f32(slope), _stream()), "scda_batchnorm_fwd_hip")
+    return y, mean, rstd
+
+
+def batchnorm_bwd(dy, x, gamma, beta, mean, rstd, act, slope, need_dx=True):
+    _req(dy, "dy"); _req(x, "x")
+    B, C, H, W = x.shape
+    dx = torch.empty_like(x) if need_dx else None
+    dg = torch.empty(C, dtype=torch.float32, device=x.device)
+    db = torch.empty(C, dtype=torch.float32, device=x.device)
+    _check(lib().scda_batchnorm_bwd_hip(_p(dy), _p(x), _p(gamma), _p(beta), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db), i32(B), i32(C),
+                                        i32(H * W), i32(act), f32(slope), i32(0), _stream()), "scda_batchnorm_bwd_hip")
+    return dx, dg, db
+
+
+def upsample2x_fwd(x):
+    _req(x, "x")
+    B, C, H, W = x.shape
+    y = torch.empty(B, C, 2 * H, 2 * W, dtype=torch.float32, device=x.device)
+    _check(lib().scda_upsample2x_fwd_hip(_p(x), _p(y), i32(B * C), i32(H), i32(W), _stream()), "scda_upsample2x_fwd_hip")
+    return y
+
+
+def upsample2x_bwd(dy):
+    _req(dy, "dy")
+    B, C, OH, OW = dy.shape
+    dx = torch.empty(B, C, OH // 2, OW // 2, dtype=torch.float32, device=dy.device)
+    _check(lib().scda_upsample2x_bwd_hip(_p(dy), _p(dx), i32(B * C), i32(OH // 2), i32(OW // 2), _stream()), "scda_upsample2x_bwd_hip")
+    return dx
+
+
+def bce_fwd(p, t):
+    _req(p, "p"); _req(t, "t")
+    if p.numel() != t.numel():
+        raise ValueError("bce: shape mismatch")
+    out = torch.empty(1, dtype=torch.float32, device=p.device)
+    _check(lib().scda_bce_fwd_hip(_p(p), _p(t), i32(p.numel()), _p(out), _stream()), "scda_bce_fwd_hip")
+    return out
+
+
+def bce_bwd(p, t, g):
+    dp = torch.empty_like(p)
+    _check(lib().scda_bce_bwd_hip(_p(p), _p(t), i32(p.numel()), _p(g), _p(dp), _stream()), "scda_bce_bwd_hip")
+    return dp
+
+
+def gap_fwd(x):
+    _req(x, "x")
+    B, C, H, W = x.shape
+    y = torch.empty(B, C, dtype=torch.float32, device=x.device)
+    _check(lib().scda_gap_fwd_hip(_p(x), _p(y), i32(B * C), i32(H * W), _stream()), "scda_gap_fwd_hip")
+    return y
+
+
+def gap_bwd(dy, x_shape):
+    _req(dy, "dy")
+    B, C, H, W = x_shape
+    dx = torch.empty(B, C, H, W, dtype=torch.float32, device=dy.device)
+    _check(lib().scda_gap_bwd_hip(_p(dy), _p(dx), i32(B * C), i32(H * W), _stream()), "scda_gap_bwd_hip")
+    return dx
+
+
+def row_mean(x):
+    _req(x, "x")
+    R, C = x.shape
+    y = torch.empty(R, dtype=torch.float32, device=x.device)
+    _check(lib().scda_row_mean_hip(_p(x), _p(y), i32(R), i32(C), _stream()), "scda_row_mean_hip")
+    return y
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step):
+    _req(param, "param"); _req(grad, "grad"); _req(exp_avg, "exp_avg"); _req(exp_avg_sq, "exp_avg_sq")
+    _check(lib().scda_adam_hip(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), i64(param.numel()), f32(lr), f32(beta1), f32(beta2),
+                               f32(eps), f32(weight_decay), i32(step), _stream()), "scda_adam_hip")
