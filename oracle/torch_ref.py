@@ -1,0 +1,486 @@
+"""Model-level CPU oracle: a plain PyTorch fp32 restatement of the SCDA detector, GAN nets and the four-phase
+training iteration -- TEST INFRASTRUCTURE ONLY (checker for tests/, smoke() and bench.py's cpu_baseline leg).
+
+It follows the reference graph op for op, INCLUDING the work the reference later discards (retain_graph
+backward passes into nets whose optimiser is not stepping), so that timing it is timing the reference's CPU path:
+  detector   models/faster_rcnn/vgg_adver_expansion_cluster.py:30-98, models/head.py:3-32,
+             models/faster_rcnn/faster_rcnn_adver_expansion_reweight_cluster.py:36-68,106-267
+  GAN nets   ...reweight_cluster.py:270-399, models/faster_rcnn/common_net.py:59-80,107-130,160-170,205-293
+  iteration  tools/faster_rcnn_train_val.py:411-458 (crops, labels), :507-750 (the four phases)
+Pinned against the reference itself: tests/golden/train_step_*.npz holds the outputs of the reference's own
+train() (imported unmodified) on seeded inputs; tests/test_oracle_model.py replays them through this file.
+
+Native ops come from oracle/liboracle.so (RoIPool, NMS, IoU); the host-side box logic is the product's numpy code
+(scda_amd/dropin/functions), itself pinned bit-exactly against reference vectors, with the oracle's C kernels
+plugged in as its IoU/NMS backend.
+"""
+import ctypes
+import functools
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import native_ops as orc
+
+
+def use_cpu_backend():
+    """route the host-side box logic's IoU / NMS to the C oracle (no GPU involved)"""
+    from scda_amd.dropin import backend
+    backend.use(bbox_overlaps=lambda b, q: orc.bbox_overlaps(b[:, :4], q[:, :4]),
+                nms=lambda d, t: torch.from_numpy(orc.nms(d.numpy(), t)))
+
+
+def reset_backend():
+    from scda_amd.dropin import backend
+    backend.reset()
+
+
+# ------------------------------------------------------------------ layers --
+class _RoIPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, rois, ph, pw, scale):
+        out, arg = orc.roi_pool_fwd(feat.detach().numpy(), rois.detach().numpy(), ph, pw, scale)
+        ctx.save_for_backward(rois)
+        ctx.arg, ctx.cfg = arg, (tuple(feat.shape), ph, pw, scale)
+        return torch.from_numpy(out)
+
+    @staticmethod
+    def backward(ctx, g):
+        (rois,) = ctx.saved_tensors
+        shape, ph, pw, scale = ctx.cfg
+        gi = orc.roi_pool_bwd(g.contiguous().numpy(), ctx.arg, rois.numpy(), shape, ph, pw, scale)
+        return torch.from_numpy(gi), None, None, None, None
+
+
+class RefRoIPool(nn.Module):
+    def __init__(self, ph, pw, scale):
+        super().__init__()
+        self.ph, self.pw, self.scale = int(ph), int(pw), float(scale)
+
+    def forward(self, feat, rois):
+        assert rois.shape[1] == 5
+        return _RoIPoolFn.apply(feat.contiguous(), rois.contiguous(), self.ph, self.pw, self.scale)
+
+
+class RecordingDropout(nn.Module):
+    """nn.Dropout on CPU == x * bernoulli_(1-p)/(1-p) on a fresh empty_like tensor (ATen _dropout_impl); spelled
+    out so that the keep-masks can be recorded and replayed on the device under test."""
+    tape = None  # list to append uint8 masks to, or None
+
+    def __init__(self, p=0.5):
+        super().__init__()
+        self.p = p
+
+    def forward(self, x):
+        if not self.training or self.p == 0:
+            return x
+        noise = torch.empty_like(x).bernoulli_(1 - self.p)
+        if RecordingDropout.tape is not None:
+            RecordingDropout.tape.append(noise.to(torch.uint8))
+        return x * noise.div_(1 - self.p)
+
+
+def gaussian_weights_init(m):
+    if m.__class__.__name__.find('Conv') == 0:
+        m.weight.data.normal_(0.0, 0.02)
+
+
+VGG_D = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512, 'M']
+
+
+class RefRpnHead(nn.Module):
+    def __init__(self, inplanes, num_classes, num_anchors):
+        super().__init__()
+        self.conv3x3 = nn.Conv2d(inplanes, 512, 3, 1, 1)
+        self.relu3x3 = nn.ReLU(inplace=True)
+        self.conv_cls = nn.Conv2d(512, num_anchors * num_classes, 1, 1)
+        self.conv_loc = nn.Conv2d(512, num_anchors * 4, 1, 1)
+
+    def forward(self, x):
+        x = self.relu3x3(self.conv3x3(x))
+        return self.conv_cls(x), self.conv_loc(x)
+
+
+def smooth_l1_sum(pred, targets, sigma=3.0):
+    s2 = sigma ** 2
+    d = pred - targets
+    a = d.abs()
+    near = (a < 1. / s2).detach().float()
+    return (d.pow(2) * s2 / 2. * near + (a - 0.5 / s2) * (1. - near)).sum()
+
+
+def top1(output, target, ignore_index=-1):
+    keep = torch.nonzero(target != ignore_index).squeeze()
+    t, o = target[keep], output[keep]
+    pred = o.topk(1, 1, True, True)[1].t()
+    return pred.eq(t.view(1, -1)).view(-1).float().sum(0, keepdim=True).mul_(100.0 / t.size(0))
+
+
+class RefDetector(nn.Module):
+    """VGG-16 Faster R-CNN with the SCDA source/target forward"""
+
+    def __init__(self, cfg):
+        super().__init__()
+        layers, cin = [], 3
+        for v in VGG_D[:-1]:  # last pool dropped: stride 16
+            if v == 'M':
+                layers.append(nn.MaxPool2d(2, 2))
+            else:
+                layers += [nn.Conv2d(cin, v, 3, padding=1), nn.ReLU(inplace=True)]
+                cin = v
+        self.features = nn.Sequential(*layers)
+        A = len(cfg['anchor_scales']) * len(cfg['anchor_ratios'])
+        self.rpn_head = RefRpnHead(512, 2, A)
+        self.roipooling = RefRoIPool(7, 7, 1.0 / cfg['anchor_stride'])
+        self.classifier = nn.Sequential(nn.Linear(512 * 7 * 7, 4096), nn.ReLU(True), RecordingDropout(),
+                                        nn.Linear(4096, 4096), nn.ReLU(True), RecordingDropout())
+        self.fc_rcnn_cls = nn.Linear(4096, cfg['num_classes'])
+        self.fc_rcnn_loc = nn.Linear(4096, cfg['num_classes'] * 4)
+
+    def rcnn(self, x, rois):
+        x = self.roipooling(x, rois)
+        fea = self.classifier(x.view(x.size(0), -1))
+        return fea, self.fc_rcnn_cls(fea), self.fc_rcnn_loc(fea)
+
+    def forward(self, inp, target=None):
+        from scda_amd.dropin.functions.anchor_target import compute_anchor_targets
+        from scda_amd.dropin.functions.mask import compute_cluster_targets
+        from scda_amd.dropin.functions.predict_bbox import compute_predicted_bboxes
+        from scda_amd.dropin.functions.proposal_target import compute_proposal_targets
+        from scda_amd.dropin.functions.rpn_proposal import compute_rpn_proposals
+        cfg, gts, info = inp['cfg'], inp['ground_truth_bboxes'], inp['image_info']
+
+        def objectness(c):
+            c = c.permute(0, 2, 3, 1).contiguous()
+            return F.softmax(c.view(-1, 2), dim=1).view_as(c).permute(0, 3, 1, 2)
+
+        out = {'losses': [], 'predict': [], 'accuracy': []}
+        x = self.features(inp['image'])
+        rpn_cls, rpn_loc = self.rpn_head(x)
+        if not self.training:
+            props = compute_rpn_proposals(objectness(rpn_cls).data, rpn_loc.data, cfg['test_rpn_proposal_cfg'], info)
+            rois = props[:, :5].contiguous()
+            _, cls, loc = self.rcnn(x, rois)
+            bb = compute_predicted_bboxes(rois, F.softmax(cls, dim=1), loc, info, cfg['test_predict_bbox_cfg'])
+            out['predict'] = [rois, bb]
+            return out
+        ct, lt, lm, norm = compute_anchor_targets(rpn_loc.size(), cfg['train_anchor_target_cfg'], gts, info, None)
+        logits = rpn_cls.permute(0, 2, 3, 1).contiguous().view(-1, 2)
+        flat_t = ct.permute(0, 2, 3, 1).contiguous().view(-1)
+        rpn_loss_cls = F.cross_entropy(logits, flat_t, ignore_index=-1)
+        rpn_loss_loc = smooth_l1_sum(rpn_loc * lm, lt) / norm
+        rpn_acc = top1(logits.data, flat_t.data)
+        props = compute_rpn_proposals(objectness(rpn_cls).data, rpn_loc.data, cfg['train_rpn_proposal_cfg'], info)
+        rois, cls_t, loc_t, loc_w = compute_proposal_targets(props, cfg['train_proposal_target_cfg'], gts, info, None)
+        fea, cls, loc = self.rcnn(x, rois)
+        clu, ctr = compute_cluster_targets(rois, fea, N_cluster=inp['cluster_num'], threshold=inp['threshold'])
+        # target image (graph is built, as in the reference, although nothing differentiates through it)
+        xg = self.features(target)
+        gcls, gloc = self.rpn_head(xg)
+        props_g = compute_rpn_proposals(objectness(gcls).data, gloc.data, cfg['train_rpn_proposal_cfg'], info)
+        rois_g = props_g[0:512, :5].contiguous()
+        fea_g, _, _ = self.rcnn(xg, rois_g)
+        clu_g, ctr_g = compute_cluster_targets(rois_g, fea_g, N_cluster=inp['cluster_num'], threshold=inp['threshold'])
+        rcnn_loss_cls = F.cross_entropy(cls, cls_t)
+        rcnn_loss_loc = smooth_l1_sum(loc * loc_w, loc_t) / cls_t.shape[0]
+        rcnn_acc = top1(cls, cls_t)
+        out['losses'] = [rpn_loss_cls, rpn_loss_loc, rcnn_loss_cls, rcnn_loss_loc]
+        out['accuracy'] = [rpn_acc, rcnn_acc]
+        out['predict'] = [props]
+        if fea_g.size(0) != 512:
+            out['cluster_features'], out['cluster_centers'] = [clu, clu], [ctr, ctr]
+        else:
+            out['cluster_features'], out['cluster_centers'] = [clu, clu_g], [ctr, ctr_g]
+        out['_debug'] = {'rois': rois, 'rois_t': rois_g, 'feat': x, 'x_fea': fea}
+        return out
+
+
+class RefINSResBlock(nn.Module):
+    def __init__(self, c, dropout):
+        super().__init__()
+        seq = [nn.Conv2d(c, c, 3, 1, 1), nn.InstanceNorm2d(c), nn.ReLU(inplace=True), nn.Conv2d(c, c, 3, 1, 1),
+               nn.InstanceNorm2d(c)]
+        if dropout > 0:
+            seq.append(RecordingDropout(dropout))
+        self.model = nn.Sequential(*seq)
+
+    def forward(self, x):
+        out = self.model(x)
+        out += x
+        return out
+
+
+class _View(nn.Module):
+    def __init__(self, *shape):
+        super().__init__()
+        self.shape = shape
+
+    def forward(self, x):
+        return x.view(*self.shape)
+
+
+class _Up2(nn.Module):
+    def forward(self, x):
+        return F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=True)
+
+
+class _Wrap(nn.Module):
+    """gives the `model.<i>` prefix the reference's wrapper classes have"""
+
+    def __init__(self, *mods):
+        super().__init__()
+        self.model = nn.Sequential(*mods)
+
+    def forward(self, x):
+        return self.model(x)
+
+
+class _WrapInterp(nn.Module):
+    def __init__(self):
+        super().__init__()
+
+    def forward(self, x):
+        return F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=True)
+
+
+def _up_block(cin, cout):
+    return _Wrap(_WrapInterp(), nn.Conv2d(cin, cout, 3, padding=1, stride=1, bias=True), nn.InstanceNorm2d(cout),
+                 nn.LeakyReLU(inplace=True))
+
+
+class RefDecoder(nn.Module):
+    def __init__(self, ch=128, n_res=3, n_front=3, dropout=0.5, clusters=4, w=64, h=64):
+        super().__init__()
+
+        def branch():
+            seq = [_View(clusters, ch, w, h)] + [RefINSResBlock(ch, dropout) for _ in range(n_res)]
+            c = ch
+            for _ in range(n_front - 1):
+                seq.append(_up_block(c, c // 2))
+                c //= 2
+            seq += [nn.ConvTranspose2d(c, 3, 1, 1, 0), nn.Tanh()]
+            return nn.Sequential(*seq)
+
+        self.decode_B = branch()
+        self.decode_A = branch()
+        self.apply(gaussian_weights_init)
+
+    def forward(self, a, b):
+        return self.decode_A(a), self.decode_B(b)
+
+
+def _lrelu_conv(cin, cout):
+    return _Wrap(nn.Conv2d(cin, cout, 3, 2, 1, bias=True), nn.LeakyReLU(inplace=True))
+
+
+class RefDis(nn.Module):
+    def __init__(self, ch=32, n_layer=3):
+        super().__init__()
+
+        def net():
+            seq, c = [_lrelu_conv(3, ch)], ch
+            for _ in range(n_layer - 1):
+                seq.append(_lrelu_conv(c, c * 2))
+                c *= 2
+            seq.append(nn.Conv2d(c, 1, 1, 1, 0))
+            return nn.Sequential(*seq)
+
+        self.model_A = net()
+        self.model_B = net()
+        self.apply(gaussian_weights_init)
+
+    def forward(self, a, b):
+        oa, ob = self.model_A(a), self.model_B(b)
+        return oa.view(oa.size(0), -1), ob.view(ob.size(0), -1)
+
+
+class _ResDis(nn.Module):
+    def __init__(self, n_in, n_out, clusters):
+        super().__init__()
+        self.clusters, self.n_in = clusters, n_in
+        self.model = nn.Sequential(
+            nn.Conv2d(n_in, n_out, 3, 2, 1, bias=False), nn.BatchNorm2d(n_out), nn.LeakyReLU(inplace=True),
+            nn.Conv2d(n_in * 2, n_out * 2, 3, 2, 1, bias=False), nn.BatchNorm2d(n_out * 2), nn.LeakyReLU(inplace=True),
+            nn.Conv2d(n_out * 2, n_out * 2, 3, 2, 1, bias=False))
+
+    def forward(self, x):
+        t = self.model(x.view(self.clusters, self.n_in, 64, 64))
+        return torch.squeeze(nn.AvgPool2d(t.size()[2:])(t))
+
+
+class RefDisPatch(nn.Module):
+    def __init__(self, n_in=128, n_out=256, clusters=4):
+        super().__init__()
+        self.model_A_patch = nn.Sequential(_ResDis(n_in, n_out, clusters))
+        self.apply(gaussian_weights_init)
+
+    def forward(self, x):
+        return torch.sigmoid(self.model_A_patch(x))
+
+
+def init_detector(m):
+    import math
+    for mod in m.modules():
+        if isinstance(mod, nn.Conv2d):
+            n = mod.kernel_size[0] * mod.kernel_size[1] * mod.out_channels
+            mod.weight.data.normal_(0, math.sqrt(2. / n))
+            mod.bias.data.zero_()
+        elif isinstance(mod, nn.Linear):
+            mod.weight.data.normal_(0, 0.01)
+            mod.bias.data.zero_()
+
+
+def build_models(cfg, cluster_num=4, threshold=128, recon_size=256):
+    size2layers = {256: 3, 512: 4, 128: 2}
+    det = RefDetector(cfg['shared'])
+    init_detector(det)
+    dis = RefDis(32, size2layers[recon_size])
+    dec = RefDecoder(threshold, 3, size2layers[recon_size], 0.5, cluster_num)
+    dis_patch = RefDisPatch(threshold, threshold * 2, cluster_num)
+    return det, dec, dis, dis_patch
+
+
+# --------------------------------------------------------------- iteration --
+def corners(center, recon, new_w, new_h):
+    half, out = recon // 2, []
+    for i in range(center.shape[0]):
+        cx, cy = int(center[i][0]), int(center[i][1])
+        x1, y1 = max(cx - half, 0), max(cy - half, 0)
+        if x1 == 0:
+            x2 = recon
+        else:
+            x2 = min(cx + half, new_w)
+            if x2 == new_w:
+                x1 = new_w - recon
+        if y1 == 0:
+            y2 = recon
+        else:
+            y2 = min(cy + half, new_h)
+            if y2 == new_h:
+                y1 = new_h - recon
+        out.append([x1, y1, x2, y2])
+    return out
+
+
+def _label(lo, hi, ref):
+    return torch.from_numpy(np.random.uniform(lo, hi, size=ref.size())).float()
+
+
+class RefTrainer:
+    """faithful CPU replay of one train() iteration (dead gradients included), torch.optim.Adam x4"""
+
+    def __init__(self, cfg, models, lr=1.25e-5, cluster_num=4, threshold=128, recon_size=256, new_w=1024, new_h=512,
+                 world_size=1):
+        self.cfg = cfg
+        self.model, self.dec, self.dis, self.dis_patch = models
+        for m in models:
+            m.train()
+        mk = lambda m: torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr, betas=(0.9, 0.999),  # noqa: E731
+                                        weight_decay=0.0001)
+        self.opt, self.opt_dec, self.opt_dis, self.opt_patch = mk(self.model), mk(self.dec), mk(self.dis), mk(self.dis_patch)
+        self.cluster_num, self.threshold, self.recon = cluster_num, threshold, recon_size
+        self.new_w, self.new_h, self.ws = new_w, new_h, world_size
+        self.trace = {}
+        self.capture = False
+
+    def _grab(self, name, module):
+        """gradients of the phase that is about to step (name -> {param name: grad clone})"""
+        if self.capture:
+            self.trace[name] = {k: p.grad.detach().clone() for k, p in module.named_parameters() if p.grad is not None}
+
+    def step(self, image, gts, image_info, target):
+        bce, ws = F.binary_cross_entropy, self.ws
+        x = {'cfg': self.cfg, 'image': image, 'image_info': image_info, 'ground_truth_bboxes': gts,
+             'ignore_regions': None, 'cluster_num': self.cluster_num, 'threshold': self.threshold}
+        outputs = self.model(x, target)
+        cs, ct = outputs['cluster_centers']
+        crop = lambda img, cc: torch.cat([img[:, :, y1:y2, x1:x2] for x1, y1, x2, y2 in  # noqa: E731
+                                          corners(cc, self.recon, self.new_w, self.new_h)], 0)
+        x_small, t_small = crop(image, cs), crop(target, ct)
+        src_patch, tgt_patch = outputs['cluster_features']
+        src_recon, tgt_recon = self.dec(src_patch, tgt_patch)
+
+        # (1) discriminators
+        self.opt_dis.zero_grad()
+        sd, td = self.dis(src_recon, tgt_recon)
+        sr, tr = self.dis(x_small, t_small)
+        sd, td, sr, tr = torch.sigmoid(sd), torch.sigmoid(td), torch.sigmoid(sr), torch.sigmoid(tr)
+        sdc, src_ = torch.split(sd, 1, dim=0), torch.split(sr, 1, dim=0)
+        s1 = _label(0.8, 1.0, src_[0])
+        s0 = _label(0.0, 0.3, sdc[0])
+        ad_src = 0.0
+        for c in range(len(sdc)):
+            ad_src += bce(sdc[c], s1) + bce(src_[c], s0)
+        tpro = self.dis_patch(tgt_patch)
+        tmean = torch.mean(tpro, 1)
+        spro = self.dis_patch(src_patch)
+        tdc, trc = torch.split(td, 1, dim=0), torch.split(tr, 1, dim=0)
+        ad_tgt = 0.0
+        for c in range(len(tdc)):
+            ad_tgt += tmean[c] * bce(tdc[c], s0) + bce(trc[c], s1)
+        adloss = (ad_src + ad_tgt) / ws
+        adloss.backward(retain_graph=True)
+        self._grab('dis', self.dis)
+        self.opt_dis.step()
+
+        # (2) patch discriminator
+        self.opt_patch.zero_grad()
+        s0p = _label(0.0, 0.3, tpro)
+        s1p = _label(0.8, 1.0, spro)
+        dis_patch_loss = (bce(spro, s1p) + bce(tpro, s0p)) / ws
+        dis_patch_loss.backward(retain_graph=True)
+        self._grab('dis_patch', self.dis_patch)
+        self.opt_patch.step()
+
+        # (3) decoders
+        self.opt_dec.zero_grad()
+        sd, td = self.dis(src_recon, tgt_recon)
+        sd = torch.sigmoid(sd)
+        sr, tr = self.dis(x_small, t_small)
+        sr, tr = torch.sigmoid(sr), torch.sigmoid(tr)
+        tpro2 = self.dis_patch(tgt_patch)
+        tds = torch.sigmoid(td)
+        tmean2 = torch.mean(tpro2, 1)
+        tds = torch.split(tds, 1, dim=0)
+        one_t = _label(1.0, 1.0, tds[0])
+        trs = torch.split(tr, 1, dim=0)
+        zero_t = _label(0.0, 0.0, trs[0])
+        f1t = 0.0
+        for c in range(len(tds)):
+            f1t += tmean2[c] * (bce(tds[c], one_t) + bce(trs[c], zero_t))
+        sds = torch.split(sd, 1, dim=0)
+        one_s = _label(1.0, 1.0, sds[0])
+        srs = torch.split(sr, 1, dim=0)
+        zero_s = _label(0.0, 0.0, srs[0])
+        f1s = 0.0
+        for c in range(len(sds)):
+            f1s += bce(sds[c], one_s) + bce(srs[c], zero_s)
+        recon_loss = (f1s + f1t) / ws
+        recon_loss.backward(retain_graph=True)
+        self._grab('dec', self.dec)
+        self.opt_dec.step()
+
+        # (4) detector
+        sw_s, sw_t = self.dec(tgt_patch, src_patch)
+        qs, qt = self.dis(sw_s, sw_t)
+        qtp = torch.sigmoid(qt)
+        ones_all = _label(1.0, 1.0, qtp)
+        fake_src = bce(qtp, ones_all)
+        qsp = torch.split(torch.sigmoid(qs), 1, dim=0)
+        ones_row = torch.ones(qsp[0].size()).float()
+        fake_tgt = 0.0
+        for c in range(len(qsp)):
+            fake_tgt += tmean2[c] * bce(qsp[c], ones_row)
+        a, b, c_, d = outputs['losses']
+        loss = (a + b + c_ + d + 0.1 * (fake_src + fake_tgt)) / ws
+        self.opt.zero_grad()
+        loss.backward()
+        self._grab('det', self.model)
+        self.opt.step()
+        return {'loss': loss.detach() * ws, 'rpn_cls': a.detach(), 'rpn_loc': b.detach(), 'rcnn_cls': c_.detach(),
+                'rcnn_loc': d.detach(), 'rpn_acc': outputs['accuracy'][0], 'rcnn_acc': outputs['accuracy'][1],
+                'fake_loss_target': fake_tgt.detach(), 'fake_loss_source': fake_src.detach(),
+                'recon_loss': recon_loss.detach(), 'adloss': adloss.detach(), 'dis_patch_loss': dis_patch_loss.detach(),
+                'fake_loss1_source': f1s.detach(), '_outputs': outputs}

@@ -1,0 +1,98 @@
+"""GAN building blocks with the class names / constructor arguments / parameter names of
+models/faster_rcnn/common_net.py (only the blocks the SCDA path instantiates: :59-80, :107-130, :160-170,
+:205-245, :251-293).  Every conv / norm / activation runs on the HIP kernels; norm+activation pairs are one
+kernel, conv+LeakyReLU pairs are the conv's epilogue.  nn.Sequential indices (hence state_dict keys such as
+`model.0.weight`, `model.3.weight`) are identical to the reference's."""
+import torch.nn as nn
+
+from scda_amd import layers as L
+from scda_amd.autograd_ops import ACT_LEAKY, ACT_NONE, ACT_RELU, AddFn
+from scda_amd.dropin.models.faster_rcnn.init import gaussian_weights_init, xavier_weights_init  # noqa: F401
+
+
+class INSResBlock(nn.Module):
+    """x + [conv3x3 - IN - ReLU - conv3x3 - IN - (Dropout)](x)"""
+
+    def conv3x3(self, inplanes, out_planes, stride=1):
+        return L.Conv2d(inplanes, out_planes, kernel_size=3, stride=stride, padding=1)
+
+    def __init__(self, inplanes, planes, stride=1, dropout=0.0):
+        super().__init__()
+        seq = [self.conv3x3(inplanes, planes, stride), L.InstanceNorm2d(planes, fused_act=ACT_RELU), L.FusedAct("ReLU"),
+               self.conv3x3(planes, planes), L.InstanceNorm2d(planes)]
+        if dropout > 0:
+            seq.append(L.Dropout(p=dropout))
+        self.model = nn.Sequential(*seq)
+        self.model.apply(gaussian_weights_init)
+
+    def forward(self, x):
+        return AddFn.apply(self.model(x), x)
+
+
+class LinUnsRes_cluster(nn.Module):
+    """pure reshape [cluster_num, channel, w*h] -> [cluster_num, channel, w, h]"""
+
+    def __init__(self, channel=128, w=64, h=64, cluster_num=4):
+        super().__init__()
+        self.channel, self.w, self.h, self.cluster_num = channel, w, h, cluster_num
+
+    def forward(self, x):
+        return x.view(self.cluster_num, self.channel, self.w, self.h)
+
+
+class Interpolate(nn.Module):
+    def __init__(self, scale_factor, mode):
+        super().__init__()
+        if scale_factor != 2 or mode != 'bilinear':
+            raise NotImplementedError("only the x2 bilinear (align_corners=True) form is on the SCDA path")
+        self.scale_factor, self.mode = scale_factor, mode
+        self.up = L.Upsample2x()
+
+    def forward(self, x):
+        return self.up(x)
+
+
+class ResDis_cluster(nn.Module):
+    """patch discriminator trunk: [conv s2 - BN - LReLU] x2 - conv s2 - global average pool -> [cluster_num, n_out*2]"""
+
+    def __init__(self, n_in=128, n_out=256, kernel_size=3, stride=2, padding=1, w=64, h=64, cluster_num=4):
+        super().__init__()
+        self.w, self.h, self.cluster_num, self.channel = w, h, cluster_num, n_in
+        k = dict(kernel_size=kernel_size, stride=stride, padding=padding, bias=False)
+        self.model = nn.Sequential(
+            L.Conv2d(n_in, n_out, **k), L.BatchNorm2d(n_out, fused_act=ACT_LEAKY), L.FusedAct("LeakyReLU"),
+            L.Conv2d(n_in * 2, n_out * 2, **k), L.BatchNorm2d(n_out * 2, fused_act=ACT_LEAKY), L.FusedAct("LeakyReLU"),
+            L.Conv2d(n_out * 2, n_out * 2, **k))
+        self.model.apply(gaussian_weights_init)
+        self.pool = L.GlobalAvgPool()
+
+    def forward(self, x1):
+        t = self.model(x1.view(self.cluster_num, self.channel, self.w, self.h))
+        return self.pool(t)  # [cluster_num, C]  (reference: AvgPool2d(full) then squeeze)
+
+
+class LeakyReLUConv2d(nn.Module):
+    def __init__(self, n_in, n_out, kernel_size, stride, padding=0):
+        super().__init__()
+        self.model = nn.Sequential(
+            L.Conv2d(n_in, n_out, kernel_size=kernel_size, stride=stride, padding=padding, bias=True, fused_act=ACT_LEAKY),
+            L.FusedAct("LeakyReLU"))
+        self.model.apply(gaussian_weights_init)
+
+    def forward(self, x):
+        return self.model(x)
+
+
+class LeakyReLUConvTranspose2d_2(nn.Module):
+    """bilinear x2 - conv3x3 - IN - LeakyReLU (despite the name there is no transposed conv: common_net.py:279-293)"""
+
+    def __init__(self, n_in, n_out, kernel_size, stride, padding=0, output_padding=0):
+        super().__init__()
+        self.model = nn.Sequential(
+            Interpolate(scale_factor=2, mode='bilinear'),
+            L.Conv2d(n_in, n_out, kernel_size=kernel_size, padding=padding, stride=1, bias=True),
+            L.InstanceNorm2d(n_out, fused_act=ACT_LEAKY), L.FusedAct("LeakyReLU"))
+        self.model.apply(gaussian_weights_init)
+
+    def forward(self, x):
+        return self.model(x)

@@ -1,0 +1,224 @@
+"""Detector base class and SCDA adversarial nets -- module API of
+models/faster_rcnn/faster_rcnn_adver_expansion_reweight_cluster.py (FasterRCNN_AdEx :19-235, smooth-L1 :238-246,
+accuracy :249-267, GAN_dis_AE :270-308, GAN_dis_AE_patch :312-333, GAN_decoder_AE :336-399).
+
+forward(input, target) returns the same dict (losses / accuracy / predict / cluster_features / cluster_centers).
+Differences are all in *where* work runs: losses, soft-max, RoIPool, FC and convs are HIP kernels; the target image
+goes through the backbone under no_grad (the reference builds an autograd graph for it that nothing ever
+back-propagates: reweight_cluster.py:171-186), so its activations are not retained."""
+import functools
+import logging
+
+import torch
+import torch.nn as nn
+
+from scda_amd import autograd_ops as A
+from scda_amd import layers as L
+from scda_amd import native as N
+from scda_amd.dropin.functions.anchor_target import compute_anchor_targets
+from scda_amd.dropin.functions.mask import compute_cluster_targets
+from scda_amd.dropin.functions.predict_bbox import compute_predicted_bboxes
+from scda_amd.dropin.functions.proposal_target import compute_proposal_targets
+from scda_amd.dropin.functions.rpn_proposal import compute_rpn_proposals
+from scda_amd.dropin.models.faster_rcnn.common_net import (INSResBlock, LeakyReLUConv2d, LeakyReLUConvTranspose2d_2,
+                                                           LinUnsRes_cluster, ResDis_cluster, gaussian_weights_init)
+
+logger = logging.getLogger('global')
+
+
+def smooth_l1_loss_with_sigma(pred, targets, sigma=3.0):
+    """SUM of smooth-L1(pred - targets) with transition at 1/sigma^2"""
+    return A.smooth_l1_sum(pred, None, targets.contiguous(), sigma, 1.0)
+
+
+def accuracy(output, target, topk=(1,), ignore_index=-1):
+    """top-1 precision (percent) over rows whose target != ignore_index; returns [1-element tensor] like the reference"""
+    if tuple(topk) != (1,):
+        raise NotImplementedError("only top-1 is used on the SCDA path")
+    return [N.accuracy(output.detach().contiguous(), target.contiguous(), ignore_index)]
+
+
+def _objectness(rpn_pred_cls):
+    """soft-max over (bg, fg) per anchor, returned in the conv layout [B, 2A, h, w]"""
+    nhwc = rpn_pred_cls.detach().permute(0, 2, 3, 1).contiguous()
+    prob = N.row_softmax(nhwc.view(-1, 2)).view_as(nhwc)
+    return prob.permute(0, 3, 1, 2)
+
+
+class FasterRCNN_AdEx(nn.Module):
+    def __init__(self, gan_model_flag):
+        super().__init__()
+
+    def feature_extractor(self, x):
+        raise NotImplementedError
+
+    def rpn(self, x):
+        raise NotImplementedError
+
+    def rcnn(self, x, rois):
+        raise NotImplementedError
+
+    def _add_rpn_loss(self, compute_anchor_targets_fn, rpn_pred_cls, rpn_pred_loc):
+        cls_targets, loc_targets, loc_masks, loc_normalizer = compute_anchor_targets_fn(rpn_pred_loc.size())
+        logits = rpn_pred_cls.permute(0, 2, 3, 1).contiguous().view(-1, 2)
+        flat_t = cls_targets.permute(0, 2, 3, 1).contiguous().view(-1)
+        rpn_loss_cls = A.cross_entropy(logits, flat_t, ignore_index=-1)
+        # smooth-L1 of (pred * mask - target), summed, / #sampled anchors -- one fused kernel
+        rpn_loss_loc = A.smooth_l1_sum(rpn_pred_loc, loc_masks, loc_targets, 3.0, 1.0 / loc_normalizer)
+        acc = accuracy(logits, flat_t)[0]
+        return rpn_loss_cls, rpn_loss_loc, acc
+
+    def _add_rcnn_loss(self, rcnn_pred_cls, rcnn_pred_loc, cls_targets, loc_targets, loc_weights):
+        rcnn_loss_cls = A.cross_entropy(rcnn_pred_cls, cls_targets)
+        rcnn_loss_loc = A.smooth_l1_sum(rcnn_pred_loc, loc_weights, loc_targets, 3.0, 1.0 / cls_targets.shape[0])
+        acc = accuracy(rcnn_pred_cls, cls_targets)[0]
+        return rcnn_loss_cls, rcnn_loss_loc, acc
+
+    def _pin_args_to_fn(self, cfg, ground_truth_bboxes, image_info, ignore_regions):
+        fn = {}
+        if self.training:
+            fn['anchor_target_fn'] = functools.partial(compute_anchor_targets, cfg=cfg['train_anchor_target_cfg'],
+                                                       ground_truth_bboxes=ground_truth_bboxes,
+                                                       ignore_regions=ignore_regions, image_info=image_info)
+            fn['proposal_target_fn'] = functools.partial(compute_proposal_targets, cfg=cfg['train_proposal_target_cfg'],
+                                                         ground_truth_bboxes=ground_truth_bboxes,
+                                                         ignore_regions=ignore_regions, image_info=image_info)
+            fn['rpn_proposal_fn'] = functools.partial(compute_rpn_proposals, cfg=cfg['train_rpn_proposal_cfg'],
+                                                      image_info=image_info)
+        else:
+            fn['rpn_proposal_fn'] = functools.partial(compute_rpn_proposals, cfg=cfg['test_rpn_proposal_cfg'],
+                                                      image_info=image_info)
+            fn['predict_bbox_fn'] = functools.partial(compute_predicted_bboxes, image_info=image_info,
+                                                      cfg=cfg['test_predict_bbox_cfg'])
+        return fn
+
+    def forward(self, input, target=None):
+        """input: dict(cfg, image [b,3,h,w], ground_truth_bboxes [b,G,5]|None, image_info [b,3], ignore_regions,
+        cluster_num, threshold); target: target-domain image batch (training only)."""
+        cfg = input['cfg']
+        image = input['image']
+        dev = image.device
+        gts = input['ground_truth_bboxes']
+        if torch.is_tensor(gts) and gts.device != dev:
+            gts = gts.to(dev)  # the targets are produced on the device the gts live on
+        fn = self._pin_args_to_fn(cfg, gts, input['image_info'], input['ignore_regions'])
+        outputs = {'losses': [], 'predict': [], 'accuracy': []}
+
+        feat = self.feature_extractor(image)
+        rpn_cls, rpn_loc = self.rpn(feat)
+
+        if not self.training:
+            proposals = fn['rpn_proposal_fn'](_objectness(rpn_cls), rpn_loc.detach())
+            rois = proposals[:, :5].to(dev).contiguous()
+            assert rois.shape[1] == 5
+            _, cls, loc = self.rcnn(feat, rois)
+            prob = N.row_softmax(cls.detach().contiguous())
+            outputs['predict'] = [rois, fn['predict_bbox_fn'](rois, prob, loc.detach())]
+            return outputs
+
+        # ---- source image: RPN loss, proposals, sampled RoIs, RCNN, cluster regions
+        rpn_loss_cls, rpn_loss_loc, rpn_acc = self._add_rpn_loss(fn['anchor_target_fn'], rpn_cls, rpn_loc)
+        proposals = fn['rpn_proposal_fn'](_objectness(rpn_cls), rpn_loc.detach())
+        rois, cls_targets, loc_targets, loc_weights = fn['proposal_target_fn'](proposals)
+        assert rois.shape[1] == 5
+        x_fea, rcnn_cls, rcnn_loc = self.rcnn(feat, rois)
+        clu_fea, clu_ctr = compute_cluster_targets(rois, x_fea, N_cluster=input['cluster_num'], threshold=input['threshold'])
+
+        # ---- target image: same backbone / RPN / RCNN, no labels, nothing is differentiated through it
+        with torch.no_grad():
+            feat_t = self.feature_extractor(target)
+            rpn_cls_t, rpn_loc_t = self.rpn(feat_t)
+            proposals_t = fn['rpn_proposal_fn'](_objectness(rpn_cls_t), rpn_loc_t)
+            rois_t = proposals_t[0:512, :5].to(dev).contiguous()
+            assert rois_t.shape[1] == 5
+            x_fea_t, _, _ = self.rcnn(feat_t, rois_t)
+            clu_fea_t, clu_ctr_t = compute_cluster_targets(rois_t, x_fea_t, N_cluster=input['cluster_num'],
+                                                           threshold=input['threshold'])
+        assert feat_t.size() == feat.size(), "gan_features does not match the backbone"
+
+        rcnn_loss_cls, rcnn_loss_loc, rcnn_acc = self._add_rcnn_loss(rcnn_cls, rcnn_loc, cls_targets, loc_targets, loc_weights)
+        outputs['losses'] = [rpn_loss_cls, rpn_loss_loc, rcnn_loss_cls, rcnn_loss_loc]
+        outputs['accuracy'] = [rpn_acc, rcnn_acc]
+        outputs['predict'] = [proposals]
+        if x_fea_t.size(0) != 512:  # target image produced too few proposals: fall back to the source clusters
+            logger.info("Different channels {} at target image".format(x_fea_t.size(0)))
+            outputs['cluster_features'] = [clu_fea, clu_fea]
+            outputs['cluster_centers'] = [clu_ctr, clu_ctr]
+        else:
+            outputs['cluster_features'] = [clu_fea, clu_fea_t]
+            outputs['cluster_centers'] = [clu_ctr, clu_ctr_t]
+        return outputs
+
+
+class GAN_dis_AE(nn.Module):
+    """two image discriminators (A: source crops, B: target crops): n_layer stride-2 LeakyReLU convs + 1x1 -> 1"""
+
+    def __init__(self, params):
+        super().__init__()
+        ch, cin, n_layer = params['ch'], params['input_dim_a'], params['n_layer']
+        self.model_A = self._make_net(ch, cin, n_layer - 1)
+        self.model_A.apply(gaussian_weights_init)
+        self.model_B = self._make_net(ch, cin, n_layer - 1)
+        self.model_B.apply(gaussian_weights_init)
+
+    def _make_net(self, ch, input_dim, n_layer):
+        seq = [LeakyReLUConv2d(input_dim, ch, kernel_size=3, stride=2, padding=1)]
+        for _ in range(n_layer):
+            seq.append(LeakyReLUConv2d(ch, ch * 2, kernel_size=3, stride=2, padding=1))
+            ch *= 2
+        seq.append(L.Conv2d(ch, 1, kernel_size=1, stride=1, padding=0))
+        return nn.Sequential(*seq)
+
+    def forward(self, x_aa, x_bb):
+        a = self.model_A(x_aa)
+        b = self.model_B(x_bb)
+        return a.view(a.size(0), -1), b.view(b.size(0), -1)
+
+
+class GAN_dis_AE_patch(nn.Module):
+    """per-cluster weighting net on RoI-feature clusters: ResDis_cluster trunk -> sigmoid, [cluster_num, 2*n_out]"""
+
+    def __init__(self, params=None):
+        super().__init__()
+        if params:
+            self.n_in, self.n_out, clusters = params['n_in'], params['n_out'], params['cluster_num']
+        else:
+            self.n_in, self.n_out, clusters = 128, 256, 4
+        self.model_A_patch = nn.Sequential(ResDis_cluster(n_in=self.n_in, n_out=self.n_out, kernel_size=3, stride=2,
+                                                          padding=1, w=64, h=64, cluster_num=clusters))
+
+    def forward(self, rois_features):
+        return A.sigmoid(self.model_A_patch(rois_features))
+
+
+class GAN_decoder_AE(nn.Module):
+    """two decoders (A: source, B: target): reshape -> n_gen_res_blk INSResBlocks -> (n_gen_front_blk-1) x2
+    up-sampling blocks -> 1x1 transposed conv -> tanh; cluster features [4, ch, 64*64] -> images [4, 3, S, S]"""
+
+    def __init__(self, params):
+        super().__init__()
+        out_dim, ch = params['input_dim_b'], params['ch']
+        n_res, n_front = params['n_gen_res_blk'], params['n_gen_front_blk']
+        drop = params.get('res_dropout_ratio', 0)
+        neww, newh, clusters = params.get('neww', 64), params.get('newh', 64), params.get('cluster_num', 4)
+
+        def branch():
+            seq = [LinUnsRes_cluster(ch, neww, newh, clusters)]
+            seq += [INSResBlock(ch, ch, dropout=drop) for _ in range(n_res)]
+            c = ch
+            for _ in range(n_front - 1):
+                seq.append(LeakyReLUConvTranspose2d_2(c, c // 2, kernel_size=3, stride=1, padding=1, output_padding=0))
+                c //= 2
+            seq += [L.ConvTranspose1x1(c, out_dim), L.Activation("tanh")]
+            return nn.Sequential(*seq)
+
+        # creation order B then A, init order B then A: the reference's RNG consumption order (:368-392)
+        dec_b, dec_a = branch(), None
+        dec_a = branch()
+        self.decode_B = dec_b
+        self.decode_B.apply(gaussian_weights_init)
+        self.decode_A = dec_a
+        self.decode_A.apply(gaussian_weights_init)
+
+    def forward(self, x_aa, x_bb):
+        return self.decode_A(x_aa), self.decode_B(x_bb)

@@ -1,0 +1,237 @@
+"""The SCDA training iteration (tools/faster_rcnn_train_val.py:507-750) on the MI355X.
+
+One call of ScdaTrainer.step() = one source + one target image through the four optimiser phases of the
+reference's train() loop body:
+    (1) image discriminators   (:567-616)      (3) cluster decoders   (:642-704)
+    (2) patch discriminator    (:623-635)      (4) detector           (:716-750)
+The parameter updates are the reference's.  What is NOT replayed is work whose result the reference throws away
+(SURVEY.md 3.1): gradients deposited into nets whose optimiser is not stepping in that phase are zeroed by the
+owning phase's zero_grad() before use, so here those sub-graphs run under no_grad / on detached inputs.  The
+numpy global RNG is consumed in exactly the reference's order (soft labels AND the "hard" labels, which the
+reference also draws with np.random.uniform).
+
+Each model's parameters and gradients live in one flat fp32 bucket (scda_amd.flat): one fused Adam kernel and
+one RCCL all-reduce per phase.  With world_size > 1 the all-reduces of phases 1-3 are launched asynchronously and
+waited for just before the corresponding optimiser step.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import autograd_ops as A
+from . import native as N
+from .flat import FlatAdam, FlatParams
+from .dropin.models.faster_rcnn.faster_rcnn_adver_expansion_reweight_cluster import (GAN_decoder_AE, GAN_dis_AE,
+                                                                                     GAN_dis_AE_patch)
+from .dropin.models.faster_rcnn.vgg_adver_expansion_cluster import vgg16
+from .dropin.utils.distributed_utils import average_gradients
+
+
+def get_corner_from_center(center, recon_size, new_w, new_h):
+    """recon_size x recon_size crop window around each cluster centre, pushed inside the new_w x new_h image;
+    int() truncation as in tools/faster_rcnn_train_val.py:411-438 -> list of [x1, y1, x2, y2]"""
+    half = recon_size // 2
+    boxes = []
+    for cx, cy in np.asarray(center)[:, :2]:
+        x1 = max(int(cx) - half, 0)
+        y1 = max(int(cy) - half, 0)
+        if x1 == 0:
+            x2 = recon_size
+        else:
+            x2 = min(int(cx) + half, new_w)
+            if x2 == new_w:
+                x1 = new_w - recon_size
+        if y1 == 0:
+            y2 = recon_size
+        else:
+            y2 = min(int(cy) + half, new_h)
+            if y2 == new_h:
+                y1 = new_h - recon_size
+        boxes.append([x1, y1, x2, y2])
+    return boxes
+
+
+def builder_gan(cluster_num=4, threshold=128, recon_size=256, neww=64, newh=64):
+    """hyper-parameters of the GAN part: tools/faster_rcnn_train_val.py:255-274"""
+    size2layers = {256: 3, 512: 4, 128: 2}
+    params_dec = {'ch': threshold, 'input_dim_a': 3, 'input_dim_b': 3, 'n_enc_front_blk': 5, 'n_enc_res_blk': 2,
+                  'n_enc_shared_blk': 2, 'n_gen_shared_blk': 2, 'n_gen_res_blk': 3,
+                  'n_gen_front_blk': size2layers[recon_size], 'res_dropout_ratio': 0.5, 'neww': neww, 'newh': newh,
+                  'cluster_num': cluster_num, 'threshold': threshold}
+    params_dis = {'input_dim_a': 3, 'input_dim_b': 3, 'ch': 32, 'n_gen_res_blk': 3, 'n_layer': size2layers[recon_size]}
+    params_patch = {'n_in': threshold, 'n_out': threshold * 2, 'cluster_num': cluster_num}
+    return GAN_dis_AE(params_dis), GAN_decoder_AE(params_dec), GAN_dis_AE_patch(params_patch)
+
+
+def _soft(flag, shape, device):
+    """generate_soft_label: U(0.8,1) for 1, U(0,0.3) for 0, drawn from numpy's global RNG (:440-448)"""
+    lo, hi = (0.8, 1.0) if flag == 1 else (0.0, 0.3)
+    return torch.from_numpy(np.random.uniform(lo, hi, size=tuple(shape))).float().to(device)
+
+
+def _hard(flag, shape, device):
+    """generate_hard_label: constant, but still one numpy draw per element (:450-458)"""
+    v = 1.0 if flag == 1 else 0.0
+    return torch.from_numpy(np.random.uniform(v, v, size=tuple(shape))).float().to(device)
+
+
+def _crops(img, corners, recon):
+    out = []
+    for x1, y1, x2, y2 in corners:
+        assert x2 - x1 == recon and y2 - y1 == recon, "crop window does not match recon_size"
+        out.append(img[:, :, y1:y2, x1:x2])
+    return torch.cat(out, 0).contiguous()
+
+
+class _Frozen:
+    """context: parameters of `modules` temporarily do not require grad (their wgrad kernels are skipped)"""
+
+    def __init__(self, *modules):
+        self.params = [p for m in modules for p in m.parameters()]
+
+    def __enter__(self):
+        for p in self.params:
+            p.requires_grad_(False)
+
+    def __exit__(self, *a):
+        for p in self.params:
+            p.requires_grad_(True)
+
+
+class ScdaTrainer:
+    def __init__(self, cfg, device, lr=1.25e-5, cluster_num=4, threshold=128, recon_size=256, new_w=1024, new_h=512,
+                 weight_decay=1e-4, world_size=1, models=None):
+        self.cfg, self.device = cfg, device
+        self.cluster_num, self.threshold, self.recon = cluster_num, threshold, recon_size
+        self.new_w, self.new_h, self.world_size = new_w, new_h, world_size
+        if models is None:
+            model = vgg16(pretrained=False, cfg=cfg['shared'])
+            dis, dec, dis_patch = builder_gan(cluster_num, threshold, recon_size)
+        else:
+            model, dec, dis, dis_patch = models
+        self.model, self.dec, self.dis, self.dis_patch = (m.to(device) for m in (model, dec, dis, dis_patch))
+        for m in (self.model, self.dec, self.dis, self.dis_patch):
+            m.train()
+        self.flat = {k: FlatParams(m) for k, m in (("det", self.model), ("dec", self.dec), ("dis", self.dis),
+                                                   ("dis_patch", self.dis_patch))}
+        self.opt = {k: FlatAdam(f, lr, betas=(0.9, 0.999), weight_decay=weight_decay) for k, f in self.flat.items()}
+        self.capture = False   # debugging / parity tests: keep a copy of each phase's gradients in self.trace
+        self.trace = {}
+
+    # ------------------------------------------------------------------
+    def _reduce(self, module, async_op):
+        if self.capture:
+            name = {id(self.model): 'det', id(self.dec): 'dec', id(self.dis): 'dis', id(self.dis_patch): 'dis_patch'}[id(module)]
+            self.trace[name] = {k: p.grad.detach().clone() for k, p in module.named_parameters()}
+        if self.world_size > 1:
+            return average_gradients(module, async_op=async_op)
+        return None
+
+    def step(self, image, gts, image_info, target):
+        """image/target [1,3,H,W] on the device; gts [1,G,5]; image_info [1,3] -> dict of 0-dim loss tensors"""
+        dev, ws, C = self.device, float(self.world_size), self.cluster_num
+        x = {'cfg': self.cfg, 'image': image, 'image_info': image_info, 'ground_truth_bboxes': gts,
+             'ignore_regions': None, 'cluster_num': self.cluster_num, 'threshold': self.threshold}
+        outputs = self.model(x, target)
+        ctr_s, ctr_t = outputs['cluster_centers']
+        x_small = _crops(image, get_corner_from_center(ctr_s, self.recon, self.new_w, self.new_h), self.recon)
+        t_small = _crops(target, get_corner_from_center(ctr_t, self.recon, self.new_w, self.new_h), self.recon)
+        src_patch, tgt_patch = outputs['cluster_features']          # [C, threshold, 4096] leaves
+        src_recon, tgt_recon = self.dec(src_patch, tgt_patch)        # [C, 3, recon, recon]
+
+        bce, sig = A.binary_cross_entropy, A.sigmoid
+
+        # ---------------- (1) image discriminators ----------------
+        self.opt['dis'].zero_grad()
+        d_src_fake, d_tgt_fake = self.dis(src_recon.detach(), tgt_recon.detach())
+        d_src_real, d_tgt_real = self.dis(x_small, t_small)
+        p_src_fake, p_tgt_fake, p_src_real, p_tgt_real = sig(d_src_fake), sig(d_tgt_fake), sig(d_src_real), sig(d_tgt_real)
+        row = (1, p_src_real.shape[1])
+        score1 = _soft(1, row, dev)
+        score0 = _soft(0, row, dev)
+        ad_src = 0.0
+        for c in range(C):
+            ad_src = ad_src + (bce(p_src_fake[c:c + 1], score1) + bce(p_src_real[c:c + 1], score0))
+        tgt_pro = self.dis_patch(tgt_patch)                          # [C, 512] in (0,1); also updates BN statistics
+        w_tgt = N.row_mean(tgt_pro.detach().contiguous())            # per-cluster weight (its gradient is dead here)
+        src_pro = self.dis_patch(src_patch)
+        ad_tgt = 0.0
+        for c in range(C):
+            ad_tgt = ad_tgt + (w_tgt[c] * bce(p_tgt_fake[c:c + 1], score0) + bce(p_tgt_real[c:c + 1], score1))
+        adloss = (ad_src + ad_tgt) / ws
+        adloss.backward()
+        w1 = self._reduce(self.dis, async_op=True)
+
+        # ---------------- (2) patch discriminator ----------------
+        self.opt['dis_patch'].zero_grad()
+        score0p = _soft(0, tgt_pro.shape, dev)
+        score1p = _soft(1, src_pro.shape, dev)
+        dis_patch_loss = (bce(src_pro, score1p) + bce(tgt_pro, score0p)) / ws
+        dis_patch_loss.backward()
+        w2 = self._reduce(self.dis_patch, async_op=True)
+        if w1 is not None:
+            w1.wait()
+        self.opt['dis'].step()
+        if w2 is not None:
+            w2.wait()
+        self.opt['dis_patch'].step()
+
+        # ---------------- (3) decoders ----------------
+        self.opt['dec'].zero_grad()
+        with _Frozen(self.dis):
+            d_src_fake, d_tgt_fake = self.dis(src_recon, tgt_recon)   # gradient flows to the decoders only
+            p_src_fake = sig(d_src_fake)
+            with torch.no_grad():
+                d_src_real, d_tgt_real = self.dis(x_small, t_small)
+                p_src_real, p_tgt_real = sig(d_src_real), sig(d_tgt_real)
+                w_tgt2 = N.row_mean(self.dis_patch(tgt_patch).contiguous())
+            p_tgt_fake = sig(d_tgt_fake)
+            one_t = _hard(1, row, dev)
+            zero_t = _hard(0, row, dev)
+            fake1_tgt = 0.0
+            for c in range(C):
+                fake1_tgt = fake1_tgt + w_tgt2[c] * (bce(p_tgt_fake[c:c + 1], one_t) + bce(p_tgt_real[c:c + 1], zero_t))
+            one_s = _hard(1, row, dev)
+            zero_s = _hard(0, row, dev)
+            fake1_src = 0.0
+            for c in range(C):
+                fake1_src = fake1_src + (bce(p_src_fake[c:c + 1], one_s) + bce(p_src_real[c:c + 1], zero_s))
+            recon_loss = (fake1_src + fake1_tgt) / ws
+            recon_loss.backward()
+        w3 = self._reduce(self.dec, async_op=True)
+
+        # ---------------- (4) detector ----------------
+        # The swapped reconstruction of the reference's phase 4 only feeds the LOGGED loss: the cluster features are
+        # leaves, so the 0.1*(fake_loss_source + fake_loss_target) term carries no gradient into the detector
+        # (SURVEY.md 3.1).  The detector backward therefore starts right away and overlaps the decoder all-reduce;
+        # the logged term is evaluated afterwards, without a graph, with the freshly stepped decoder as in the
+        # reference (dec_optimizer.step() precedes it, :704 vs :716).
+        rpn_cls, rpn_loc, rcnn_cls, rcnn_loc = outputs['losses']
+        det_loss = (rpn_cls + rpn_loc + rcnn_cls + rcnn_loc) / ws
+        self.opt['det'].zero_grad()
+        det_loss.backward()
+        w4 = self._reduce(self.model, async_op=True)
+        if w3 is not None:
+            w3.wait()
+        self.opt['dec'].step()
+        with torch.no_grad():
+            swap_src, swap_tgt = self.dec(tgt_patch, src_patch)
+            q_src, q_tgt = self.dis(swap_src, swap_tgt)
+            q_tgt_p = sig(q_tgt)
+            ones_all = _hard(1, q_tgt_p.shape, dev)
+            fake_loss_source = bce(q_tgt_p, ones_all)
+            q_src_p = sig(q_src)
+            ones_row = torch.ones(row, dtype=torch.float32, device=dev)
+            fake_loss_target = 0.0
+            for c in range(C):
+                fake_loss_target = fake_loss_target + w_tgt2[c] * bce(q_src_p[c:c + 1], ones_row)
+        loss = det_loss.detach() + 0.1 * (fake_loss_source + fake_loss_target) / ws
+        if w4 is not None:
+            w4.wait()
+        self.opt['det'].step()
+
+        return {'loss': loss.detach() * ws, 'rpn_cls': rpn_cls.detach(), 'rpn_loc': rpn_loc.detach(),
+                'rcnn_cls': rcnn_cls.detach(), 'rcnn_loc': rcnn_loc.detach(), 'rpn_acc': outputs['accuracy'][0],
+                'rcnn_acc': outputs['accuracy'][1], 'fake_loss_target': fake_loss_target, 'fake_loss_source': fake_loss_source,
+                'recon_loss': recon_loss.detach(), 'adloss': adloss.detach(), 'dis_patch_loss': dis_patch_loss.detach(),
+                'fake_loss1_source': fake1_src.detach()}

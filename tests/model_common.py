@@ -1,0 +1,52 @@
+"""shared set-up for the model-level tests (oracle on CPU, product on the GPU)"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+from conftest import GOLDEN
+sys.path.insert(0, GOLDEN)
+import seeded_init as si  # noqa: E402
+from test_host_functions import CFG  # noqa: E402
+
+SEEDS = dict(det=11, dec=12, dis=13, dis_patch=14, images=21, gts=22, torch=31, numpy=32)
+
+
+def seeded_models(build):
+    """build() -> (det, dec, dis, dis_patch); weights re-drawn with the golden generator's recipe"""
+    det, dec, dis, dis_patch = build()
+    si.seeded_reinit(det, SEEDS['det'], 'det')
+    si.seeded_reinit(dec, SEEDS['dec'], 'gan')
+    si.seeded_reinit(dis, SEEDS['dis'], 'gan')
+    si.seeded_reinit(dis_patch, SEEDS['dis_patch'], 'gan')
+    return det, dec, dis, dis_patch
+
+
+def seeded_inputs(H, W, G=6):
+    src, tgt = si.synth_images(SEEDS['images'], H, W)
+    gts = si.synth_gts(G, SEEDS['gts'], H, W)
+    info = torch.tensor([[H, W, 1.0]])
+    return src, tgt, gts, info
+
+
+def oracle_iteration(H, W, lr=1e-3, record_masks=False, capture=False):
+    """one RefTrainer step on CPU with the golden seeds; returns (result dict, models, masks)"""
+    from oracle import torch_ref as R
+    R.use_cpu_backend()
+    try:
+        torch.manual_seed(1)
+        models = seeded_models(lambda: R.build_models(CFG))
+        tr = R.RefTrainer(CFG, models, lr=lr, new_w=W, new_h=H)
+        tr.capture = capture
+        src, tgt, gts, info = seeded_inputs(H, W)
+        R.RecordingDropout.tape = [] if record_masks else None
+        torch.manual_seed(SEEDS['torch'])
+        np.random.seed(SEEDS['numpy'])
+        res = tr.step(src, gts, info, tgt)
+        masks = R.RecordingDropout.tape
+        R.RecordingDropout.tape = None
+    finally:
+        R.reset_backend()
+    res['_trace'] = tr.trace
+    return res, models, masks
