@@ -1,0 +1,188 @@
+"""Layer kernels (scda_amd/csrc/nn_ops.hip) vs the plain PyTorch fp32 CPU reference of the same op.
+fp32 tolerance 1e-5 relative-to-max unless stated (reductions differ in summation order only)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def close(a, b, tol=1e-5):
+    a = a.detach().cpu().double(); b = b.detach().cpu().double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = (a - b).abs().max().item() / (b.abs().max().item() + 1e-12)
+    assert err < tol, f"relative-to-max error {err:.3e}"
+
+
+def gen(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def test_maxpool(cuda):
+    from scda_amd import autograd_ops as A
+    x = torch.randn(2, 5, 8, 12, generator=gen(1))
+    x[0, 0, 0, :4] = 1.0  # ties -> first wins
+    xr = x.clone().requires_grad_()
+    y = F.max_pool2d(xr, 2, 2)
+    dy = torch.randn(y.shape, generator=gen(2))
+    y.backward(dy)
+    xg = x.to(cuda).requires_grad_()
+    yg = A.MaxPool2x2Fn.apply(xg)
+    yg.backward(dy.to(cuda))
+    assert torch.equal(yg.cpu(), y.detach())
+    assert torch.equal(xg.grad.cpu(), xr.grad)
+
+
+@pytest.mark.parametrize("mode,fn", [("relu", F.relu), ("leaky", lambda t: F.leaky_relu(t, 0.01)), ("tanh", torch.tanh),
+                                     ("sigmoid", torch.sigmoid)])
+def test_activations(cuda, mode, fn):
+    from scda_amd import autograd_ops as A, native as N
+    x = torch.randn(3, 7, 5, generator=gen(3)) * 2
+    xr = x.clone().requires_grad_()
+    y = fn(xr); dy = torch.randn(y.shape, generator=gen(4)); y.backward(dy)
+    xg = x.to(cuda).requires_grad_()
+    yg = A.ActFn.apply(xg, N.ACT_MODE[mode], 0.01); yg.backward(dy.to(cuda))
+    close(yg, y, 1e-6); close(xg.grad, xr.grad, 1e-5)
+
+
+def test_dropout_and_mask_statistics(cuda):
+    from scda_amd import autograd_ops as A, native as N
+    m = N.dropout_mask((1024, 1024), 0.5, 1234, cuda)
+    frac = m.float().mean().item()
+    assert abs(frac - 0.5) < 0.005
+    m2 = N.dropout_mask((1024, 1024), 0.5, 1235, cuda)
+    assert (m != m2).float().mean().item() > 0.4          # different seed -> different mask
+    assert torch.equal(m, N.dropout_mask((1024, 1024), 0.5, 1234, cuda))  # same seed -> same mask
+    x = torch.randn(64, 64, device=cuda, requires_grad=True)
+    mk = N.dropout_mask((64, 64), 0.5, 7, cuda)
+    y = A.DropoutFn.apply(x, mk, 2.0)
+    y.backward(torch.ones_like(y))
+    assert torch.equal(y.detach(), x.detach() * mk.float() * 2.0) and torch.equal(x.grad, mk.float() * 2.0)
+
+
+@pytest.mark.parametrize("R,C,ignore", [(30720, 2, -1), (512, 9, -100), (77, 5, -1)])
+def test_cross_entropy(cuda, R, C, ignore):
+    from scda_amd import autograd_ops as A
+    x = torch.randn(R, C, generator=gen(5)) * 3
+    t = torch.randint(0, C, (R,), generator=gen(6))
+    if ignore == -1:
+        t[torch.rand(R, generator=gen(7)) < 0.6] = -1
+    xr = x.clone().requires_grad_()
+    l = F.cross_entropy(xr, t, ignore_index=ignore); (l * 0.37).backward()
+    xg = x.to(cuda).requires_grad_()
+    lg = A.cross_entropy(xg, t.to(cuda), ignore); (lg * 0.37).backward()
+    close(lg, l, 1e-5); close(xg.grad, xr.grad, 1e-5)
+
+
+def test_accuracy_and_row_softmax(cuda):
+    from scda_amd import native as N
+    x = torch.randn(5000, 2, generator=gen(8)); t = torch.randint(-1, 2, (5000,), generator=gen(9))
+    keep = t != -1
+    ref = (x[keep].argmax(1) == t[keep]).float().mean() * 100
+    close(N.accuracy(x.to(cuda), t.to(cuda), -1)[0], ref, 1e-6)
+    close(N.row_softmax(x.to(cuda)), F.softmax(x, 1), 1e-6)
+
+
+@pytest.mark.parametrize("with_mask", [True, False])
+def test_smooth_l1(cuda, with_mask):
+    from scda_amd import autograd_ops as A
+    p = torch.randn(1, 60, 32, 64, generator=gen(10)); t = torch.randn(1, 60, 32, 64, generator=gen(11)) * 0.5
+    m = (torch.rand(1, 60, 32, 64, generator=gen(12)) < 0.1).float() if with_mask else None
+    pr = p.clone().requires_grad_()
+    d = (pr * m if with_mask else pr) - t
+    a = d.abs(); near = (a < 1 / 9.).float()
+    l = (d.pow(2) * 9 / 2. * near + (a - 0.5 / 9.) * (1 - near)).sum() / 256.
+    l.backward()
+    pg = p.to(cuda).requires_grad_()
+    lg = A.smooth_l1_sum(pg, m.to(cuda) if with_mask else None, t.to(cuda), 3.0, 1 / 256.)
+    lg.backward()
+    close(lg, l, 1e-5); close(pg.grad, pr.grad, 1e-5)
+
+
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_instance_norm(cuda, act):
+    from scda_amd import autograd_ops as A
+    x = torch.randn(4, 6, 16, 16, generator=gen(13)) * 2 + 0.5
+    xr = x.clone().requires_grad_()
+    y = F.instance_norm(xr, eps=1e-5)
+    y = [lambda v: v, F.relu, lambda v: F.leaky_relu(v, 0.01)][act](y)
+    dy = torch.randn(y.shape, generator=gen(14)); y.backward(dy)
+    xg = x.to(cuda).requires_grad_()
+    yg = A.InstanceNormFn.apply(xg, 1e-5, act, 0.01); yg.backward(dy.to(cuda))
+    close(yg, y, 1e-5); close(xg.grad, xr.grad, 1e-4)
+
+
+@pytest.mark.parametrize("act", [0, 2])
+def test_batch_norm_train(cuda, act):
+    from scda_amd import autograd_ops as A
+    B, C, H, W = 4, 10, 8, 8
+    x = torch.randn(B, C, H, W, generator=gen(15)) * 1.5 + 0.3
+    ga = 1 + 0.1 * torch.randn(C, generator=gen(16)); be = 0.1 * torch.randn(C, generator=gen(17))
+    rm = 0.1 * torch.randn(C, generator=gen(18)); rv = 1 + 0.1 * torch.rand(C, generator=gen(19))
+    xr, gr, br = x.clone().requires_grad_(), ga.clone().requires_grad_(), be.clone().requires_grad_()
+    rm_r, rv_r = rm.clone(), rv.clone()
+    y = F.batch_norm(xr, rm_r, rv_r, gr, br, True, 0.1, 1e-5)
+    if act == 2:
+        y = F.leaky_relu(y, 0.01)
+    dy = torch.randn(y.shape, generator=gen(20)); y.backward(dy)
+    xg, gg, bg = x.to(cuda).requires_grad_(), ga.to(cuda).requires_grad_(), be.to(cuda).requires_grad_()
+    rm_g, rv_g = rm.to(cuda), rv.to(cuda)
+    yg = A.BatchNormTrainFn.apply(xg, gg, bg, rm_g, rv_g, 1e-5, 0.1, act, 0.01); yg.backward(dy.to(cuda))
+    close(yg, y, 1e-5); close(xg.grad, xr.grad, 1e-4); close(gg.grad, gr.grad, 1e-4); close(bg.grad, br.grad, 1e-4)
+    close(rm_g, rm_r, 1e-5); close(rv_g, rv_r, 1e-5)
+
+
+@pytest.mark.parametrize("shape", [(4, 3, 64, 64), (1, 2, 5, 7), (4, 8, 128, 128)])
+def test_upsample2x(cuda, shape):
+    from scda_amd import autograd_ops as A
+    x = torch.randn(*shape, generator=gen(21))
+    xr = x.clone().requires_grad_()
+    y = F.interpolate(xr, scale_factor=2, mode='bilinear', align_corners=True)
+    dy = torch.randn(y.shape, generator=gen(22)); y.backward(dy)
+    xg = x.to(cuda).requires_grad_()
+    yg = A.Upsample2xFn.apply(xg); yg.backward(dy.to(cuda))
+    close(yg, y, 1e-5); close(xg.grad, xr.grad, 1e-5)
+
+
+def test_bce_gap_rowmean_add(cuda):
+    from scda_amd import autograd_ops as A, native as N
+    p = torch.rand(1, 1024, generator=gen(23)).clamp(1e-6, 1 - 1e-6); p[0, 0] = 0.0; p[0, 1] = 1.0
+    t = torch.rand(1, 1024, generator=gen(24))
+    pr = p.clone().requires_grad_()
+    l = F.binary_cross_entropy(pr, t); (l * 1.7).backward()
+    pg = p.to(cuda).requires_grad_()
+    lg = A.binary_cross_entropy(pg, t.to(cuda)); (lg * 1.7).backward()
+    close(lg, l, 1e-5); close(pg.grad[:, 2:], pr.grad[:, 2:], 1e-5)
+    x = torch.randn(4, 512, 8, 8, generator=gen(25)); xr = x.clone().requires_grad_()
+    y = F.adaptive_avg_pool2d(xr, 1).flatten(1); dy = torch.randn(y.shape, generator=gen(26)); y.backward(dy)
+    xg = x.to(cuda).requires_grad_(); yg = A.GlobalAvgPoolFn.apply(xg); yg.backward(dy.to(cuda))
+    close(yg, y, 1e-5); close(xg.grad, xr.grad, 1e-5)
+    close(N.row_mean(y.detach().to(cuda).contiguous()), y.detach().mean(1), 1e-5)
+    a = torch.randn(3, 4, 5, generator=gen(27)); b = torch.randn(3, 4, 5, generator=gen(28))
+    close(A.AddFn.apply(a.to(cuda), b.to(cuda)), a + b, 1e-7)
+
+
+@pytest.mark.parametrize("n", [1, 5, 1027, 4096 * 257])
+def test_adam_matches_torch(cuda, n):
+    from scda_amd import native as N
+    p = torch.randn(n, generator=gen(29)); gs = [torch.randn(n, generator=gen(30 + i)) * 0.1 for i in range(3)]
+    pr = p.clone().requires_grad_()
+    opt = torch.optim.Adam([pr], lr=1e-3, betas=(0.9, 0.999), weight_decay=1e-4)
+    pg = torch.zeros((n + 3) // 4 * 4, device=cuda)[:n]; pg.copy_(p)
+    m = torch.zeros_like(pg); v = torch.zeros_like(pg)
+    for i, g in enumerate(gs):
+        pr.grad = g.clone(); opt.step()
+        N.adam_step(pg, g.to(cuda), m, v, 1e-3, 0.9, 0.999, 1e-8, 1e-4, i + 1)
+    close(pg, pr, 1e-6)
+
+
+def test_conv_transpose_1x1_and_layers(cuda):
+    from scda_amd import layers as L
+    ref = torch.nn.ConvTranspose2d(32, 3, 1, 1, 0)
+    mine = L.ConvTranspose1x1(32, 3).to(cuda)
+    mine.load_state_dict(ref.state_dict())
+    x = torch.randn(4, 32, 16, 16, generator=gen(40)); xr = x.clone().requires_grad_()
+    y = ref(xr); dy = torch.randn(y.shape, generator=gen(41)); y.backward(dy)
+    xg = x.to(cuda).requires_grad_(); yg = mine(xg); yg.backward(dy.to(cuda))
+    close(yg, y, 1e-4); close(xg.grad, xr.grad, 1e-4); close(mine.weight.grad, ref.weight.grad, 1e-4); close(mine.bias.grad, ref.bias.grad, 1e-4)
