@@ -1,0 +1,177 @@
+#!/usr/bin/env python
+"""bench.py -- the SCDA hot path on MI355X: VGG16 Faster-R-CNN + 4-cluster SCDA training iteration
+(forward + backward + gradient all-reduce + Adam, all four optimiser phases), synthetic 512x1024 input, batch 1/GPU.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`, one rank per GPU)
+
+One "step" = one iteration = 1 source + 1 target 512x1024 image per GPU; images/s = 2 * N * steps / time.
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline      dominant kernel (fp32-MFMA implicit-GEMM conv, 3x3 stride 1, 128x128 tile): algorithmic FLOPs of its
+                launches inside the timed region / their summed duration (HIP events recorded on the launch stream by the
+                library's profiler), against the 157.3 TFLOP/s fp32-MFMA peak
+  cpu_baseline  the CPU oracle of the same iteration (oracle/torch_ref.py, a faithful PyTorch-CPU restatement of the
+                reference's train() body, pinned against the reference) timed on this box's host cores: rank 0, N=1 only
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CFG = {
+    "shared": {"gan_model_flag": 2, "scales": [512], "max_size": 1024, "anchor_scales": [2, 4, 8, 16, 32],
+               "anchor_ratios": [0.5, 1, 2], "anchor_stride": 16, "bbox_normalize_stats_precomputed": True,
+               "bbox_normalize_stds": [0.1, 0.1, 0.2, 0.2], "bbox_normalize_means": [0, 0, 0, 0], "num_classes": 9},
+    "train_anchor_target_cfg": {"rpn_batch_size": 256, "nms_iou_thresh": 0.7, "positive_iou_thresh": 0.7,
+                                "negative_iou_thresh": 0.3, "positive_percent": 0.5, "ignore_iou_thresh": 0.5},
+    "train_rpn_proposal_cfg": {"nms_iou_thresh": 0.7, "pre_nms_top_n": 12000, "post_nms_top_n": 2000, "roi_min_size": 2},
+    "train_proposal_target_cfg": {"batch_size": 512, "positive_iou_thresh": 0.5, "negative_iou_thresh_hi": 0.5,
+                                  "negative_iou_thresh_lo": 0.0, "ignore_iou_thresh": 0.5, "positive_percent": 0.25,
+                                  "append_gts": True},
+    "test_rpn_proposal_cfg": {"nms_iou_thresh": 0.7, "pre_nms_top_n": 6000, "post_nms_top_n": 300, "roi_min_size": 2},
+    "test_predict_bbox_cfg": {"nms_iou_thresh": 0.5, "score_thresh": 0.0, "top_n": 100},
+}
+for _k in CFG:
+    if _k != "shared":
+        CFG[_k].update(CFG["shared"])
+
+H, W, G = 512, 1024, 12
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+DOMINANT = "conv_igemm_kernel<128,128,3,3,1,0>"
+
+
+def synth_batch(rank):
+    """N(0,1) images clamped to [-1,1]; G integer-cornered gt boxes, log-uniform sizes, classes 1..8"""
+    g = torch.Generator().manual_seed(1000 + rank)
+    src = torch.randn(1, 3, H, W, generator=g).clamp_(-1, 1)
+    tgt = torch.randn(1, 3, H, W, generator=g).clamp_(-1, 1)
+    r = np.random.RandomState(2000 + rank)
+    w = np.exp(r.uniform(np.log(16), np.log(400), G)); h = np.exp(r.uniform(np.log(16), np.log(300), G))
+    x1 = r.uniform(0, W - 1 - w); y1 = r.uniform(0, H - 1 - h)
+    box = np.stack([np.floor(x1), np.floor(y1), np.minimum(np.ceil(x1 + w), W - 1), np.minimum(np.ceil(y1 + h), H - 1)], 1)
+    gts = torch.from_numpy(np.concatenate([box, r.randint(1, 9, (G, 1))], 1).astype(np.float32)[None])
+    return src, tgt, gts, torch.tensor([[H, W, 1.0]])
+
+
+def cpu_baseline():
+    """one full-size iteration of the CPU oracle on this box's host cores (bounded sample of the same workload)"""
+    from oracle import torch_ref as R
+    try:
+        import psutil
+        cores = psutil.cpu_count(logical=False) or os.cpu_count() or 1
+    except Exception:
+        cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)   # physical cores: SMT siblings only slow the fp32 conv/GEMM loops down
+    R.use_cpu_backend()
+    try:
+        torch.manual_seed(0)
+        np.random.seed(0)
+        models = R.build_models(CFG)
+        tr = R.RefTrainer(CFG, models, lr=1.25e-5, new_w=W, new_h=H)
+        src, tgt, gts, info = synth_batch(0)
+        t0 = time.time()
+        tr.step(src, gts, info, tgt)
+        dt = time.time() - t0
+    finally:
+        R.reset_backend()
+    return {"value": round(2.0 / dt, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "1 full iteration (1 source + 1 target 512x1024 image, all 4 phases incl. Adam) of oracle/torch_ref.py "
+                      "RefTrainer, %.1f s, no warm-up" % dt,
+            "s_per_iter": round(dt, 3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (a.gpus, a.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+
+    from scda_amd import native
+    from scda_amd.train_step import ScdaTrainer
+    from scda_amd.dropin.utils.distributed_utils import broadcast_params
+
+    torch.manual_seed(0)          # identical initial weights on every rank (then broadcast, as the reference does)
+    np.random.seed(100 + rank)    # per-rank sampling / soft-label stream
+    tr = ScdaTrainer(CFG, dev, lr=1.25e-5, new_w=W, new_h=H, world_size=world)
+    if world > 1:
+        for m in (tr.model, tr.dis, tr.dec, tr.dis_patch):
+            broadcast_params(m)
+    src, tgt, gts, info = synth_batch(rank)
+    src, tgt = src.to(dev), tgt.to(dev)
+
+    for _ in range(a.warmup):
+        tr.step(src, gts, info, tgt)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    native.prof_enable(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = tr.step(src, gts, info, tgt)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    native.prof_enable(False)
+    prof = native.prof_collect()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        ms = dt / a.steps * 1e3
+        value = 2.0 * world * a.steps / dt
+        roof = None
+        if DOMINANT in prof:
+            n, tms, fl = prof[DOMINANT]
+            ach = fl / (tms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": DOMINANT, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "launches": n, "avg_launch_ms": round(tms / n, 4),
+                    "gemm_class_ms_per_step": {k: round(v[1] / a.steps, 3) for k, v in sorted(prof.items())}}
+        res = {
+            "metric": "images/sec (fwd+bwd) VGG16 Faster-RCNN+SCDA 512x1024", "value": round(value, 3), "unit": "images/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "vgg16_FasterRCNN + 4-cluster SCDA, synthetic Cityscapes->Foggy 512x1024, batch=1/GPU "
+                                   "(BASELINE.json configs[1]); 1 step = 1 source + 1 target image, 4 optimiser phases",
+                       "image": [H, W], "gt_boxes": G, "rois": 512, "clusters": 4, "recon": 256, "parallelism": "dp%d" % world,
+                       "iters_per_s": round(world * a.steps / dt, 3), "final_loss": round(float(out["loss"]), 4)},
+            "roofline": roof,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

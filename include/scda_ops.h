@@ -40,6 +40,14 @@ int scda_version(void);
 int scda_device_count(void);
 const char *scda_last_error(void);
 
+/* launch profiler for the GEMM-class kernels: when enabled, a hipEvent pair is recorded on the launch stream
+ * around each conv / GEMM main kernel; after a device synchronisation scda_prof_collect() fills, per kernel class
+ * k in [0, scda_prof_num_kernels()), the number of launches, their summed duration (ms) and algorithmic FLOPs. */
+void scda_prof_enable(int on);
+int scda_prof_num_kernels(void);
+const char *scda_prof_kernel_name(int k);
+int scda_prof_collect(long long *launches, double *ms, double *flops);
+
 /* ---------------------------------------------------------------- NMS ---- */
 /* replaces  int gpu_nms(THLongTensor* keep, THLongTensor* num_out, THCudaTensor* boxes, float thresh)
  *           extensions/_nms/src/nms_cuda.h:1, nms_cuda.c:17-67, cuda/nms_kernel.cu:26-83
@@ -156,7 +164,8 @@ int scda_axpby_hip(const float *a, const float *b, float *y, long long n, float 
 /* nn.Dropout(p): mask[i] = keep ? 1 : 0 from a counter-based generator; y = mask ? x*scale : 0 */
 int scda_dropout_mask_hip(uint8_t *mask, long long n, float p, uint64_t seed, void *stream);
 int scda_dropout_apply_hip(const float *x, const uint8_t *mask, float *y, long long n, float scale, void *stream);
-int scda_bias_grad_nchw_hip(const float *dy, float *db, int B, int C, int HW, int accumulate, void *stream);
+size_t scda_bias_grad_workspace_bytes(int C);
+int scda_bias_grad_nchw_hip(const float *dy, float *db, int B, int C, int HW, int accumulate, float *ws, void *stream);
 int scda_colsum_hip(const float *dy, float *db, int M, int N, int accumulate, void *stream);
 /* F.cross_entropy(ignore_index), mean over valid rows (faster_rcnn_adver_expansion_reweight_cluster.py:49,63)
  * out2[0] = loss, out2[1] = number of valid rows; probs [R,C] is kept for the backward */

@@ -88,6 +88,15 @@ def roi_pool_bwd(top, arg, rois, feat_shape, ph, pw, scale):
     return g
 
 
+def roi_pool_bwd_scatter(top, arg, feat_shape, ph, pw):
+    top = _f32(top)
+    arg = np.ascontiguousarray(arg, dtype=np.int32)
+    B, C, H, W = feat_shape
+    g = np.zeros((B, C, H, W), dtype=np.float32)
+    lib().orc_roi_pool_bwd_scatter(_p(top), _p(arg), I(top.shape[0]), I(B), I(C), I(H), I(W), I(ph), I(pw), _p(g))
+    return g
+
+
 def roi_align_fwd(feat, rois, ah, aw, scale):
     feat = _f32(feat); rois = _f32(rois)
     B, C, H, W = feat.shape

@@ -199,6 +199,19 @@ ORC_API int orc_roi_pool_bwd(const float *top_diff, const int32_t *argmax, const
     return 1;
 }
 
+/* Scatter form of the same backward: walking the outputs in (roi, c, ph, pw) order and adding top_diff into
+ * bottom_diff[argmax] visits, for every input element, its contributors in (roi, ph, pw) order -- the gather
+ * kernel's order -- so the fp32 sums are bit-identical (asserted in tests/test_oracle_golden.py) at 1/1000 of the
+ * cost.  Used by the model-level oracle / CPU baseline.                                                        */
+ORC_API int orc_roi_pool_bwd_scatter(const float *top_diff, const int32_t *argmax, int R, int B, int C, int H, int W,
+                                     int PH, int PW, float *bottom_diff) {
+    memset(bottom_diff, 0, (size_t)B * C * H * W * sizeof(float));
+    const size_t total = (size_t)R * C * PH * PW;
+    for (size_t i = 0; i < total; ++i)
+        if (argmax[i] >= 0) bottom_diff[argmax[i]] += top_diff[i];
+    return 1;
+}
+
 /* ------------------------------------------------------------------ */
 /* RoIAlign, old single-sample variant (extensions/_roi_align/src/roi_align_kernel.cu) */
 /* The CUDA text mixes float and double literals (1., 0.); the double ones  */

@@ -50,7 +50,7 @@ class _RoIPoolFn(torch.autograd.Function):
     def backward(ctx, g):
         (rois,) = ctx.saved_tensors
         shape, ph, pw, scale = ctx.cfg
-        gi = orc.roi_pool_bwd(g.contiguous().numpy(), ctx.arg, rois.numpy(), shape, ph, pw, scale)
+        gi = orc.roi_pool_bwd_scatter(g.contiguous().numpy(), ctx.arg, shape, ph, pw)  # == gather form, bit for bit
         return torch.from_numpy(gi), None, None, None, None
 
 

@@ -431,10 +431,12 @@ static int launch_conv(const float *Wm, const float *X, const ConvGeom &g0, Epi 
     e.splits = splits;
     e.ws = ws;
     dim3 grid(cdiv(g.N, BNv), cdiv(g.M, BMv), splits);
+    prof_begin(PK_CONV + ((DGRAD ? 2 : 0) + (small_m ? 1 : 0)) * 3 + prof_shape(KH, S), 2.0 * g.M * (double)g.N * g.K, st);
     if (small_m)
         hipLaunchKernelGGL((conv_igemm_kernel<64, 128, KH, KW, S, DGRAD>), grid, dim3(256), 0, st, Wm, X, g, e);
     else
         hipLaunchKernelGGL((conv_igemm_kernel<128, 128, KH, KW, S, DGRAD>), grid, dim3(256), 0, st, Wm, X, g, e);
+    prof_end(st);
     int rc = launch_status("conv_igemm_kernel");
     if (rc || splits == 1) return rc;
     hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(ew_grid((long long)g.M * g.N)), dim3(256), 0, st, ws, splits, g.M,
@@ -454,6 +456,7 @@ static int launch_wgrad(const float *dY, const float *X, WgradGeom g, float *dW,
     g.k_per_split = round_k_per_split(g.K, splits);
     splits = cdiv(g.K, g.k_per_split);
     dim3 grid(cdiv(g.N, BNv), cdiv(g.M, BMv), splits);
+    prof_begin(PK_CONV_WGRAD + prof_shape(KH, S), 2.0 * g.M * (double)g.N * g.K, st);
     if (small && BNv == 64)
         hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, KH, KW, S>), grid, dim3(256), 0, st, dY, X, g, ws);
     else if (small)
@@ -462,6 +465,7 @@ static int launch_wgrad(const float *dY, const float *X, WgradGeom g, float *dW,
         hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, KH, KW, S>), grid, dim3(256), 0, st, dY, X, g, ws);
     else
         hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, KH, KW, S>), grid, dim3(256), 0, st, dY, X, g, ws);
+    prof_end(st);
     int rc = launch_status("conv_wgrad_kernel");
     if (rc) return rc;
     const long long total = (long long)g.M * g.N;
@@ -573,10 +577,12 @@ SCDA_API int scda_gemm_hip(const float *A, const float *B, float *C, int M, int 
         else if (trans_a && !trans_b) hipLaunchKernelGGL((gemm_kernel<BM_, BN_, true, false>), grid, dim3(256), 0, st, A, B, g, e); \
         else hipLaunchKernelGGL((gemm_kernel<BM_, BN_, true, true>), grid, dim3(256), 0, st, A, B, g, e);  \
     } while (0)
+    prof_begin(PK_GEMM, 2.0 * M * (double)N * K, st);
     if (BMv == 64 && BNv == 64) GEMM_LAUNCH(64, 64);
     else if (BMv == 64) GEMM_LAUNCH(64, 128);
     else if (BNv == 64) GEMM_LAUNCH(128, 64);
     else GEMM_LAUNCH(128, 128);
+    prof_end(st);
     int rc = launch_status("gemm_kernel");
     if (rc || splits == 1) return rc;
     const long long total = (long long)M * N;

@@ -8,6 +8,8 @@
 #include <float.h>
 #include <stdarg.h>
 
+#include <vector>
+
 #include "common.h"
 
 #pragma clang fp contract(off)
@@ -20,6 +22,28 @@ void set_error(const char *fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+// ---- launch profiler (see common.h) ----------------------------------------
+struct ProfRec { int kernel; double flops; hipEvent_t a, b; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+static std::vector<hipEvent_t> g_prof_pool;
+static hipEvent_t prof_event() {
+    hipEvent_t e;
+    if (!g_prof_pool.empty()) { e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+    (void)hipEventCreate(&e);
+    return e;
+}
+void prof_begin(int kernel, double flops, hipStream_t st) {
+    if (!g_prof_on) return;
+    ProfRec r{kernel, flops, prof_event(), prof_event()};
+    (void)hipEventRecord(r.a, st);
+    g_prof.push_back(r);
+}
+void prof_end(hipStream_t st) {
+    if (!g_prof_on || g_prof.empty()) return;
+    (void)hipEventRecord(g_prof.back().b, st);
 }
 
 // ---------------------------------------------------------------------------
@@ -505,6 +529,35 @@ SCDA_API int scda_device_count(void) {
 }
 
 SCDA_API const char *scda_last_error(void) { return g_err; }
+
+SCDA_API void scda_prof_enable(int on) { g_prof_on = on != 0; }
+
+// after a device synchronisation: per kernel class k (see scda_prof_kernel_name): launches, total milliseconds,
+// total algorithmic FLOPs.  Arrays hold scda_prof_num_kernels() entries.  Clears the recorded events.
+SCDA_API int scda_prof_num_kernels(void) { return PK_COUNT; }
+SCDA_API const char *scda_prof_kernel_name(int k) {
+    static const char *names[PK_COUNT] = {
+        "conv_igemm_kernel<128,128,3,3,1,0>", "conv_igemm_kernel<128,128,3,3,2,0>", "conv_igemm_kernel<128,128,1,1,1,0>",
+        "conv_igemm_kernel<64,128,3,3,1,0>", "conv_igemm_kernel<64,128,3,3,2,0>", "conv_igemm_kernel<64,128,1,1,1,0>",
+        "conv_igemm_kernel<128,128,3,3,1,1>", "conv_igemm_kernel<128,128,3,3,2,1>", "conv_igemm_kernel<128,128,1,1,1,1>",
+        "conv_igemm_kernel<64,128,3,3,1,1>", "conv_igemm_kernel<64,128,3,3,2,1>", "conv_igemm_kernel<64,128,1,1,1,1>",
+        "conv_wgrad_kernel<*,*,3,3,1>", "conv_wgrad_kernel<*,*,3,3,2>", "conv_wgrad_kernel<*,*,1,1,1>", "gemm_kernel<*>"};
+    return (k >= 0 && k < PK_COUNT) ? names[k] : "";
+}
+SCDA_API int scda_prof_collect(long long *launches, double *ms, double *flops) {
+    for (int k = 0; k < PK_COUNT; ++k) { launches[k] = 0; ms[k] = 0; flops[k] = 0; }
+    for (auto &r : g_prof) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) {
+            launches[r.kernel] += 1; ms[r.kernel] += t; flops[r.kernel] += r.flops;
+        } else {
+            (void)hipGetLastError();
+        }
+        g_prof_pool.push_back(r.a); g_prof_pool.push_back(r.b);
+    }
+    g_prof.clear();
+    return SCDA_OK;
+}
 
 SCDA_API size_t scda_nms_workspace_bytes(int n) {
     if (n <= 0) return 0;

@@ -130,19 +130,37 @@ __global__ __launch_bounds__(256) void dropout_apply_kernel(const float *__restr
 }
 
 // ------------------------------------------------------- bias gradients -----
-// db[c] (+)= sum_{b,p} dy[b][c][p]     one workgroup per channel
-__global__ __launch_bounds__(256) void bias_grad_nchw_kernel(const float *__restrict__ dy, float *__restrict__ db,
-                                                             const int B, const int C, const int HW,
-                                                             const int accumulate) {
+// db[c] (+)= sum_{b,p} dy[b][c][p].  Stage 1: grid (C, nsplit) -- each workgroup reduces one contiguous slice of a
+// channel's pixels (float4 loads), partial[c][s]; stage 2: one wave per channel adds the slices in fixed order.
+__global__ __launch_bounds__(256) void bias_grad_partial_kernel(const float *__restrict__ dy, float *__restrict__ partial,
+                                                                const int B, const int C, const int HW,
+                                                                const int slice) {
     __shared__ float red[16];
-    const int c = blockIdx.x;
+    const int c = blockIdx.x, s0 = blockIdx.y * slice;
+    const int s1 = min(HW, s0 + slice);
     float s = 0.f;
     for (int b = 0; b < B; ++b) {
         const float *p = dy + ((size_t)b * C + c) * HW;
-        for (int i = threadIdx.x; i < HW; i += blockDim.x) s += p[i];
+        if (((HW | s0) & 3) == 0) {
+            const float4 *p4 = reinterpret_cast<const float4 *>(p + s0);
+            const int n4 = (s1 - s0) >> 2;
+            for (int i = threadIdx.x; i < n4; i += blockDim.x) { const float4 v = p4[i]; s += (v.x + v.y) + (v.z + v.w); }
+            for (int i = s0 + (n4 << 2) + threadIdx.x; i < s1; i += blockDim.x) s += p[i];
+        } else {
+            for (int i = s0 + threadIdx.x; i < s1; i += blockDim.x) s += p[i];
+        }
     }
     s = block_sum(s, red);
-    if (threadIdx.x == 0) db[c] = accumulate ? db[c] + s : s;
+    if (threadIdx.x == 0) partial[(size_t)c * gridDim.y + blockIdx.y] = s;
+}
+
+__global__ __launch_bounds__(256) void bias_grad_finish_kernel(const float *__restrict__ partial, float *__restrict__ db,
+                                                               const int C, const int nsplit, const int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int i = 0; i < nsplit; ++i) s += partial[(size_t)c * nsplit + i];
+    db[c] = accumulate ? db[c] + s : s;
 }
 
 // db[n] (+)= sum_m dy[m][n]    (linear bias): one thread per column, rows in order
@@ -619,10 +637,25 @@ SCDA_API int scda_dropout_apply_hip(const float *x, const uint8_t *mask, float *
     return launch_status("dropout_apply_kernel");
 }
 
-SCDA_API int scda_bias_grad_nchw_hip(const float *dy, float *db, int B, int C, int HW, int accumulate, void *stream) {
-    NN_CHECK(dy && db && B > 0 && C > 0 && HW > 0, "scda_bias_grad_nchw_hip")
-    hipLaunchKernelGGL(bias_grad_nchw_kernel, dim3(C), dim3(256), 0, as_stream(stream), dy, db, B, C, HW, accumulate);
-    return launch_status("bias_grad_nchw_kernel");
+#define BIAS_GRAD_MAX_SPLIT 128
+SCDA_API size_t scda_bias_grad_workspace_bytes(int C) { return (size_t)C * BIAS_GRAD_MAX_SPLIT * sizeof(float); }
+
+SCDA_API int scda_bias_grad_nchw_hip(const float *dy, float *db, int B, int C, int HW, int accumulate, float *ws,
+                                     void *stream) {
+    NN_CHECK(dy && db && ws && B > 0 && C > 0 && HW > 0, "scda_bias_grad_nchw_hip")
+    // ~2048 workgroups in total, at least 2048 pixels per slice
+    int nsplit = 2048 / C;
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > BIAS_GRAD_MAX_SPLIT) nsplit = BIAS_GRAD_MAX_SPLIT;
+    int slice = (HW + nsplit - 1) / nsplit;
+    if (slice < 2048) slice = 2048;
+    slice = (slice + 3) & ~3;
+    nsplit = (HW + slice - 1) / slice;
+    hipLaunchKernelGGL(bias_grad_partial_kernel, dim3(C, nsplit), dim3(256), 0, as_stream(stream), dy, ws, B, C, HW, slice);
+    int rc = launch_status("bias_grad_partial_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(bias_grad_finish_kernel, dim3(cdiv(C, 256)), dim3(256), 0, as_stream(stream), (const float *)ws, db, C, nsplit, accumulate);
+    return launch_status("bias_grad_finish_kernel");
 }
 
 SCDA_API int scda_colsum_hip(const float *dy, float *db, int M, int N, int accumulate, void *stream) {

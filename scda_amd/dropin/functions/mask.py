@@ -24,7 +24,12 @@ def proposals_to_centers(proposals):
 def cluster_indices(proposals_np, N_cluster=4, threshold=128):
     """-> (index int64 [N_cluster, threshold] into the RoI list, centres float64 [N_cluster, 2])"""
     from sklearn.cluster import KMeans
-    km = KMeans(n_clusters=N_cluster, random_state=0).fit(proposals_to_centers(proposals_np))
+    from threadpoolctl import threadpool_limits
+    # 512 two-dimensional points: one thread.  (On a 256-thread host the OpenMP fork/join of sklearn's Lloyd loop costs
+    # ~15 ms per call; the arithmetic is microseconds.  Cluster labels do not depend on the thread count; the float32
+    # centres move in the last bits (per-thread partial sums), far below the int() truncation of the crop corners.)
+    with threadpool_limits(limits=1):
+        km = KMeans(n_clusters=N_cluster, random_state=0).fit(proposals_to_centers(proposals_np))
     rows = []
     for c in range(N_cluster):
         member = np.where(km.labels_[:] == c)[0]

@@ -116,6 +116,14 @@ class FasterRCNN_AdEx(nn.Module):
             outputs['predict'] = [rois, fn['predict_bbox_fn'](rois, prob, loc.detach())]
             return outputs
 
+        # The target image's backbone + RPN are enqueued NOW, before any host-side box logic: the MI355X works through
+        # them while the host labels anchors / sorts proposals for the source image.  Results are unaffected (no RNG in
+        # these layers); every RNG-consuming call below keeps the reference's order.
+        with torch.no_grad():
+            feat_t = self.feature_extractor(target)
+            rpn_cls_t, rpn_loc_t = self.rpn(feat_t)
+            obj_t = _objectness(rpn_cls_t)
+
         # ---- source image: RPN loss, proposals, sampled RoIs, RCNN, cluster regions
         rpn_loss_cls, rpn_loss_loc, rpn_acc = self._add_rpn_loss(fn['anchor_target_fn'], rpn_cls, rpn_loc)
         proposals = fn['rpn_proposal_fn'](_objectness(rpn_cls), rpn_loc.detach())
@@ -126,9 +134,7 @@ class FasterRCNN_AdEx(nn.Module):
 
         # ---- target image: same backbone / RPN / RCNN, no labels, nothing is differentiated through it
         with torch.no_grad():
-            feat_t = self.feature_extractor(target)
-            rpn_cls_t, rpn_loc_t = self.rpn(feat_t)
-            proposals_t = fn['rpn_proposal_fn'](_objectness(rpn_cls_t), rpn_loc_t)
+            proposals_t = fn['rpn_proposal_fn'](obj_t, rpn_loc_t)
             rois_t = proposals_t[0:512, :5].to(dev).contiguous()
             assert rois_t.shape[1] == 5
             x_fea_t, _, _ = self.rcnn(feat_t, rois_t)

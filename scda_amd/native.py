@@ -384,7 +384,10 @@ def bias_grad_nchw(dy):
     B, C = dy.shape[0], dy.shape[1]
     HW = dy.numel() // (B * C)
     db = torch.empty(C, dtype=torch.float32, device=dy.device)
-    _check(lib().scda_bias_grad_nchw_hip(_p(dy), _p(db), i32(B), i32(C), i32(HW), i32(0), _stream()), "scda_bias_grad_nchw_hip")
+    L = lib()
+    L.scda_bias_grad_workspace_bytes.restype = ctypes.c_size_t
+    ws = torch.empty(L.scda_bias_grad_workspace_bytes(i32(C)) // 4, dtype=torch.float32, device=dy.device)
+    _check(L.scda_bias_grad_nchw_hip(_p(dy), _p(db), i32(B), i32(C), i32(HW), i32(0), _p(ws), _stream()), "scda_bias_grad_nchw_hip")
     return db
 
 
@@ -552,3 +555,21 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_de
     _req(param, "param"); _req(grad, "grad"); _req(exp_avg, "exp_avg"); _req(exp_avg_sq, "exp_avg_sq")
     _check(lib().scda_adam_hip(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), i64(param.numel()), f32(lr), f32(beta1), f32(beta2),
                                f32(eps), f32(weight_decay), i32(step), _stream()), "scda_adam_hip")
+
+
+# ------------------------------------------------------------ profiler ------
+def prof_enable(on):
+    lib().scda_prof_enable(i32(1 if on else 0))
+
+
+def prof_collect():
+    """after torch.cuda.synchronize(): {kernel name: (launches, total_ms, total_flops)} for kernels that ran"""
+    L = lib()
+    L.scda_prof_kernel_name.restype = ctypes.c_char_p
+    n = L.scda_prof_num_kernels()
+    launches = (ctypes.c_longlong * n)()
+    ms = (ctypes.c_double * n)()
+    fl = (ctypes.c_double * n)()
+    _check(L.scda_prof_collect(launches, ms, fl), "scda_prof_collect")
+    return {L.scda_prof_kernel_name(i32(k)).decode(): (int(launches[k]), float(ms[k]), float(fl[k]))
+            for k in range(n) if launches[k] > 0}
