@@ -1,0 +1,100 @@
+"""Data-parallel plumbing (scda_amd/dropin/utils/distributed_utils.py + scda_amd/flat.py) with world_size 2 on the
+gloo backend, CPU tensors: flat-bucket gradient SUM all-reduce (sync and async), fallback for un-flattened modules,
+initial broadcast including buffers, env:// rendezvous fallback of dist_init."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class Tiny(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a = nn.Linear(5, 3)
+        self.bn = nn.BatchNorm1d(3)
+        self.b = nn.Linear(3, 2, bias=False)
+
+
+def _worker(rank, world, port, results):
+    for k in ("SLURM_PROCID", "SLURM_NTASKS", "SLURM_NODELIST"):
+        os.environ.pop(k, None)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1")
+    from scda_amd.dropin.utils.distributed_utils import average_gradients, broadcast_params, dist_init
+    from scda_amd.flat import FlatParams
+    r, w = dist_init(str(port), backend="gloo")
+    assert (r, w) == (rank, world)
+    torch.manual_seed(100 + rank)           # different weights per rank before the broadcast
+    m = Tiny()
+    flat = FlatParams(m)
+    m.bn.running_mean.fill_(float(rank + 1))
+    broadcast_params(m)
+    ok_bcast = all(float((p - q).abs().max()) == 0 for p, q in zip(m.state_dict().values(), _rank0_state().values()))
+    ok_bn = float(m.bn.running_mean[0]) == 1.0
+    # flat-bucket all-reduce: every gradient element = rank+1  -> 1+2 = 3
+    for p in m.parameters():
+        p.grad.fill_(float(rank + 1))
+    average_gradients(m)
+    ok_sum = all(bool((p.grad == 3).all()) for p in m.parameters())
+    assert all(p.grad.data_ptr() >= flat.grad.data_ptr() for p in m.parameters())   # still views of the bucket
+    for p in m.parameters():
+        p.grad.fill_(float(10 * (rank + 1)))
+    work = average_gradients(m, async_op=True)
+    work.wait()
+    ok_async = all(bool((p.grad == 30).all()) for p in m.parameters())
+    # un-flattened module: coalesced on the fly
+    m2 = Tiny()
+    for p in m2.parameters():
+        p.grad = torch.full_like(p, float(rank + 1))
+    average_gradients(m2)
+    ok_plain = all(bool((p.grad == 3).all()) for p in m2.parameters())
+    results[rank] = (ok_bcast, ok_bn, ok_sum, ok_async, ok_plain)
+    dist.destroy_process_group()
+
+
+def _rank0_state():
+    torch.manual_seed(100)
+    m = Tiny()
+    m.bn.running_mean.fill_(1.0)
+    return m.state_dict()
+
+
+def test_world_size_2_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        results = mgr.dict()
+        procs = [ctx.Process(target=_worker, args=(r, world, port, results)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(120)
+            assert p.exitcode == 0
+        assert dict(results) == {0: (True,) * 5, 1: (True,) * 5}
+
+
+def test_flat_params_views_and_adam_bucket_alignment():
+    from scda_amd.flat import FlatParams
+    m = Tiny()
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    flat = FlatParams(m)
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, before[k])                      # values preserved
+    for p in m.parameters():
+        assert p.data_ptr() % 16 == flat.data.data_ptr() % 16  # 16-byte aligned segments
+        assert p.grad is not None and p.grad.shape == p.shape
+    flat.grad.fill_(2.0)
+    assert all(bool((p.grad == 2).all()) for p in m.parameters())
+    flat.zero_grad()
+    assert float(flat.grad.abs().sum()) == 0
