@@ -199,8 +199,9 @@ _WS = {}
 
 
 def workspace(nbytes, device):
-    """Grow-only per-device scratch buffer (split-K slabs); never freed during a run."""
-    key = (device.type, device.index)
+    """Grow-only scratch buffer (split-K slabs), one per (device, stream): kernels on different HIP streams may run
+    concurrently and must not share slabs.  Never freed during a run."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)

@@ -117,6 +117,9 @@ class ScdaTrainer:
         self.opt = {k: FlatAdam(f, lr, betas=(0.9, 0.999), weight_decay=weight_decay) for k, f in self.flat.items()}
         self.capture = False   # debugging / parity tests: keep a copy of each phase's gradients in self.trace
         self.trace = {}
+        # scheduling: detector backward enqueued as soon as its losses exist; target branch on a high-priority side stream
+        self.early_backward = True
+        self.side = torch.cuda.Stream(device=device, priority=-1) if device.type == "cuda" else None
 
     # ------------------------------------------------------------------
     def _reduce(self, module, async_op):
@@ -132,6 +135,21 @@ class ScdaTrainer:
         dev, ws, C = self.device, float(self.world_size), self.cluster_num
         x = {'cfg': self.cfg, 'image': image, 'image_info': image_info, 'ground_truth_bboxes': gts,
              'ignore_regions': None, 'cluster_num': self.cluster_num, 'threshold': self.threshold}
+        pending = {}
+
+        def detector_backward(losses):
+            # Phase (4)'s gradient depends only on the four detector losses (the adversarial term of the reference's
+            # detector loss carries no gradient into the detector), so its backward -- and, multi-GPU,
+            # the 547 MB all-reduce -- starts here and runs underneath the rest of the iteration.
+            det_loss = (losses[0] + losses[1] + losses[2] + losses[3]) / ws
+            self.opt['det'].zero_grad()
+            det_loss.backward()
+            pending['det_loss'] = det_loss.detach()
+            pending['w4'] = self._reduce(self.model, async_op=True)
+
+        if self.early_backward:
+            x['_after_source_losses'] = detector_backward
+            x['_side_stream'] = self.side
         outputs = self.model(x, target)
         ctr_s, ctr_t = outputs['cluster_centers']
         x_small = _crops(image, get_corner_from_center(ctr_s, self.recon, self.new_w, self.new_h), self.recon)
@@ -207,10 +225,9 @@ class ScdaTrainer:
         # the logged term is evaluated afterwards, without a graph, with the freshly stepped decoder as in the
         # reference (dec_optimizer.step() precedes it, :704 vs :716).
         rpn_cls, rpn_loc, rcnn_cls, rcnn_loc = outputs['losses']
-        det_loss = (rpn_cls + rpn_loc + rcnn_cls + rcnn_loc) / ws
-        self.opt['det'].zero_grad()
-        det_loss.backward()
-        w4 = self._reduce(self.model, async_op=True)
+        if not self.early_backward:
+            detector_backward(outputs['losses'])
+        det_loss, w4 = pending['det_loss'], pending['w4']
         if w3 is not None:
             w3.wait()
         self.opt['dec'].step()
@@ -225,7 +242,7 @@ class ScdaTrainer:
             fake_loss_target = 0.0
             for c in range(C):
                 fake_loss_target = fake_loss_target + w_tgt2[c] * bce(q_src_p[c:c + 1], ones_row)
-        loss = det_loss.detach() + 0.1 * (fake_loss_source + fake_loss_target) / ws
+        loss = det_loss + 0.1 * (fake_loss_source + fake_loss_target) / ws
         if w4 is not None:
             w4.wait()
         self.opt['det'].step()
