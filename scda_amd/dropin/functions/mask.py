@@ -21,14 +21,26 @@ def proposals_to_centers(proposals):
     return np.stack([(proposals[:, 3] + proposals[:, 1]) / 2.0, (proposals[:, 4] + proposals[:, 2]) / 2.0], axis=1)
 
 
+_TPC = None
+
+
+def _one_thread():
+    """threadpoolctl context limiting OpenMP/BLAS pools to one thread; the controller (a scan of the loaded shared
+    libraries) is built once, not per call"""
+    global _TPC
+    if _TPC is None:
+        from threadpoolctl import ThreadpoolController
+        _TPC = ThreadpoolController()
+    return _TPC.limit(limits=1)
+
+
 def cluster_indices(proposals_np, N_cluster=4, threshold=128):
     """-> (index int64 [N_cluster, threshold] into the RoI list, centres float64 [N_cluster, 2])"""
     from sklearn.cluster import KMeans
-    from threadpoolctl import threadpool_limits
     # 512 two-dimensional points: one thread.  (On a 256-thread host the OpenMP fork/join of sklearn's Lloyd loop costs
     # ~15 ms per call; the arithmetic is microseconds.  Cluster labels do not depend on the thread count; the float32
     # centres move in the last bits (per-thread partial sums), far below the int() truncation of the crop corners.)
-    with threadpool_limits(limits=1):
+    with _one_thread():
         km = KMeans(n_clusters=N_cluster, random_state=0).fit(proposals_to_centers(proposals_np))
     rows = []
     for c in range(N_cluster):

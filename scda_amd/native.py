@@ -40,7 +40,13 @@ def _check(status, what):
         raise ScdaNativeError(f"{what} failed with status {status}: {msg}")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """current HIP stream of the current device as void* (one C call; this runs once per kernel launch)"""
+    if _raw_stream is not None:
+        return ctypes.c_void_p(_raw_stream(torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -201,7 +207,7 @@ _WS = {}
 def workspace(nbytes, device):
     """Grow-only scratch buffer (split-K slabs), one per (device, stream): kernels on different HIP streams may run
     concurrently and must not share slabs.  Never freed during a run."""
-    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    key = (device.index, _stream().value)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)

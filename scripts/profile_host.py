@@ -16,4 +16,4 @@ pr = cProfile.Profile(); pr.enable()
 for _ in range(5): tr.step(src, gts, info, tgt)
 torch.cuda.synchronize()
 pr.disable()
-s = io.StringIO(); ps = pstats.Stats(pr, stream=s).sort_stats("cumulative"); ps.print_stats(60); print(s.getvalue()[:9000])
+s = io.StringIO(); ps = pstats.Stats(pr, stream=s).sort_stats("tottime"); ps.print_stats(45); print(s.getvalue()[:9000])
