@@ -40,10 +40,11 @@ int scda_version(void);
 int scda_device_count(void);
 const char *scda_last_error(void);
 
-/* launch profiler for the GEMM-class kernels: when enabled, a hipEvent pair is recorded on the launch stream
- * around each conv / GEMM main kernel; after a device synchronisation scda_prof_collect() fills, per kernel class
- * k in [0, scda_prof_num_kernels()), the number of launches, their summed duration (ms) and algorithmic FLOPs. */
-void scda_prof_enable(int on);
+/* launch profiler for the GEMM-class kernels: for every kernel class k whose bit is set in kernel_mask a hipEvent
+ * pair is recorded on the launch stream around each launch of that kernel; after a device synchronisation
+ * scda_prof_collect() fills, per class k in [0, scda_prof_num_kernels()), the number of launches, their summed
+ * duration (ms) and algorithmic FLOPs.  (Event records are queue markers: keep the mask narrow inside timed regions.) */
+void scda_prof_enable(unsigned kernel_mask);
 int scda_prof_num_kernels(void);
 const char *scda_prof_kernel_name(int k);
 int scda_prof_collect(long long *launches, double *ms, double *flops);

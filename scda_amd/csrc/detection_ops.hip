@@ -26,7 +26,7 @@ void set_error(const char *fmt, ...) {
 
 // ---- launch profiler (see common.h) ----------------------------------------
 struct ProfRec { int kernel; double flops; hipEvent_t a, b; };
-static bool g_prof_on = false;
+static unsigned g_prof_mask = 0;  // bit k set: time launches of kernel class k
 static std::vector<ProfRec> g_prof;
 static std::vector<hipEvent_t> g_prof_pool;
 static hipEvent_t prof_event() {
@@ -35,14 +35,17 @@ static hipEvent_t prof_event() {
     (void)hipEventCreate(&e);
     return e;
 }
+static bool g_prof_open = false;
 void prof_begin(int kernel, double flops, hipStream_t st) {
-    if (!g_prof_on) return;
+    g_prof_open = (g_prof_mask >> kernel) & 1u;
+    if (!g_prof_open) return;
     ProfRec r{kernel, flops, prof_event(), prof_event()};
     (void)hipEventRecord(r.a, st);
     g_prof.push_back(r);
 }
 void prof_end(hipStream_t st) {
-    if (!g_prof_on || g_prof.empty()) return;
+    if (!g_prof_open || g_prof.empty()) return;
+    g_prof_open = false;
     (void)hipEventRecord(g_prof.back().b, st);
 }
 
@@ -530,7 +533,7 @@ SCDA_API int scda_device_count(void) {
 
 SCDA_API const char *scda_last_error(void) { return g_err; }
 
-SCDA_API void scda_prof_enable(int on) { g_prof_on = on != 0; }
+SCDA_API void scda_prof_enable(unsigned kernel_mask) { g_prof_mask = kernel_mask; }
 
 // after a device synchronisation: per kernel class k (see scda_prof_kernel_name): launches, total milliseconds,
 // total algorithmic FLOPs.  Arrays hold scda_prof_num_kernels() entries.  Clears the recorded events.

@@ -565,8 +565,24 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_de
 
 
 # ------------------------------------------------------------ profiler ------
-def prof_enable(on):
-    lib().scda_prof_enable(i32(1 if on else 0))
+def prof_kernel_names():
+    L = lib()
+    L.scda_prof_kernel_name.restype = ctypes.c_char_p
+    return [L.scda_prof_kernel_name(i32(k)).decode() for k in range(L.scda_prof_num_kernels())]
+
+
+def prof_enable(kernels):
+    """kernels: False/None = off, True = all GEMM-class kernels, or an iterable of kernel names to time"""
+    names = prof_kernel_names()
+    if not kernels:
+        mask = 0
+    elif kernels is True:
+        mask = (1 << len(names)) - 1
+    else:
+        mask = 0
+        for k in kernels:
+            mask |= 1 << names.index(k)
+    lib().scda_prof_enable(ctypes.c_uint(mask))
 
 
 def prof_collect():
