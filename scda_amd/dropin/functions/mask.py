@@ -21,27 +21,33 @@ def proposals_to_centers(proposals):
     return np.stack([(proposals[:, 3] + proposals[:, 1]) / 2.0, (proposals[:, 4] + proposals[:, 2]) / 2.0], axis=1)
 
 
-_TPC = None
+_POOLS_LIMITED = []
 
 
-def _one_thread():
-    """threadpoolctl context limiting OpenMP/BLAS pools to one thread; the controller (a scan of the loaded shared
-    libraries) is built once, not per call"""
-    global _TPC
-    if _TPC is None:
+def _limit_host_pools_once():
+    """Pin the BLAS / OpenMP pools that numpy, scipy and sklearn bring along to ONE thread, once, for the life of the
+    process (torch's own pool is left alone).  The host-side work of the SCDA step is 512-point k-means, 12 000-element
+    sorts and a few small reductions: on a 256-thread host the default pools only hurt -- waking or re-spawning 255
+    worker threads costs 30-60 ms per parallel region (measured with scripts/stall_sampler.py: stalls inside
+    sklearn's Lloyd loop, np.einsum, np.var and threadpoolctl's own set_num_threads), and their spin-waiting preempts the
+    thread that feeds the GPU.  Results do not depend on the thread count except for the last bits of the float32
+    k-means centres (see tests/test_host_functions.py)."""
+    if _POOLS_LIMITED:
+        return
+    try:
         from threadpoolctl import ThreadpoolController
-        _TPC = ThreadpoolController()
-    return _TPC.limit(limits=1)
+        ctl = ThreadpoolController()
+        ctl.lib_controllers = [c for c in ctl.lib_controllers if "torch" not in (c.filepath or "")]
+        _POOLS_LIMITED.append(ctl.limit(limits=1))   # kept alive, never restored
+    except Exception:  # threadpoolctl missing: correctness is unaffected
+        _POOLS_LIMITED.append(None)
 
 
 def cluster_indices(proposals_np, N_cluster=4, threshold=128):
     """-> (index int64 [N_cluster, threshold] into the RoI list, centres float64 [N_cluster, 2])"""
     from sklearn.cluster import KMeans
-    # 512 two-dimensional points: one thread.  (On a 256-thread host the OpenMP fork/join of sklearn's Lloyd loop costs
-    # ~15 ms per call; the arithmetic is microseconds.  Cluster labels do not depend on the thread count; the float32
-    # centres move in the last bits (per-thread partial sums), far below the int() truncation of the crop corners.)
-    with _one_thread():
-        km = KMeans(n_clusters=N_cluster, random_state=0).fit(proposals_to_centers(proposals_np))
+    _limit_host_pools_once()   # 512 two-dimensional points: one thread
+    km = KMeans(n_clusters=N_cluster, random_state=0).fit(proposals_to_centers(proposals_np))
     rows = []
     for c in range(N_cluster):
         member = np.where(km.labels_[:] == c)[0]

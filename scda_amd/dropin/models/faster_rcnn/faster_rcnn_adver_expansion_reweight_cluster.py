@@ -15,6 +15,7 @@ import torch.nn as nn
 from scda_amd import autograd_ops as A
 from scda_amd import layers as L
 from scda_amd import native as N
+from scda_amd._timing import mark
 from scda_amd.dropin.functions.anchor_target import compute_anchor_targets
 from scda_amd.dropin.functions.mask import compute_cluster_targets
 from scda_amd.dropin.functions.predict_bbox import compute_predicted_bboxes
@@ -125,16 +126,22 @@ class FasterRCNN_AdEx(nn.Module):
             obj_t = _objectness(rpn_cls_t)
         ev_backbones = torch.cuda.Event()
         ev_backbones.record()
+        mark('backbones_enqueued')
 
         # ---- source image: RPN loss, proposals, sampled RoIs, RCNN, cluster regions
         rpn_loss_cls, rpn_loss_loc, rpn_acc = self._add_rpn_loss(fn['anchor_target_fn'], rpn_cls, rpn_loc)
+        mark('anchor_targets+rpn_loss')
         proposals = fn['rpn_proposal_fn'](_objectness(rpn_cls), rpn_loc.detach())
+        mark('src_proposals')
         rois, cls_targets, loc_targets, loc_weights = fn['proposal_target_fn'](proposals)
+        mark('src_proposal_targets')
         assert rois.shape[1] == 5
         x_fea, rcnn_cls, rcnn_loc = self.rcnn(feat, rois)
+        mark('src_rcnn_enqueued')
         clu_fea, clu_ctr = compute_cluster_targets(rois, x_fea, N_cluster=input['cluster_num'], threshold=input['threshold'])
         rcnn_loss_cls, rcnn_loss_loc, rcnn_acc = self._add_rcnn_loss(rcnn_cls, rcnn_loc, cls_targets, loc_targets, loc_weights)
         losses = [rpn_loss_cls, rpn_loss_loc, rcnn_loss_cls, rcnn_loss_loc]
+        mark('src_cluster+rcnn_loss')
 
         # Optional scheduling hooks of this repository's own training step (absent when the reference's driver calls us):
         #  '_after_source_losses': called as soon as the four detector losses exist -- the step uses it to enqueue the
@@ -144,6 +151,7 @@ class FasterRCNN_AdEx(nn.Module):
         hook = input.get('_after_source_losses')
         if hook is not None:
             hook(losses)
+            mark('det_backward_enqueued')
         side = input.get('_side_stream')
         main = torch.cuda.current_stream(dev) if side is not None else None
 
@@ -167,6 +175,7 @@ class FasterRCNN_AdEx(nn.Module):
             for t in (x_fea_t, clu_fea_t):
                 t.record_stream(main)
         assert feat_t.size() == feat.size(), "gan_features does not match the backbone"
+        mark('target_branch')
 
         outputs['losses'] = losses
         outputs['accuracy'] = [rpn_acc, rcnn_acc]

@@ -21,6 +21,7 @@ import torch.distributed as dist
 from . import autograd_ops as A
 from . import native as N
 from .flat import FlatAdam, FlatParams
+from ._timing import mark
 from .dropin.models.faster_rcnn.faster_rcnn_adver_expansion_reweight_cluster import (GAN_decoder_AE, GAN_dis_AE,
                                                                                      GAN_dis_AE_patch)
 from .dropin.models.faster_rcnn.vgg_adver_expansion_cluster import vgg16
@@ -102,6 +103,8 @@ class ScdaTrainer:
     def __init__(self, cfg, device, lr=1.25e-5, cluster_num=4, threshold=128, recon_size=256, new_w=1024, new_h=512,
                  weight_decay=1e-4, world_size=1, models=None):
         self.cfg, self.device = cfg, device
+        from .dropin.functions.mask import _limit_host_pools_once
+        _limit_host_pools_once()
         self.cluster_num, self.threshold, self.recon = cluster_num, threshold, recon_size
         self.new_w, self.new_h, self.world_size = new_w, new_h, world_size
         if models is None:
@@ -150,6 +153,7 @@ class ScdaTrainer:
         if self.early_backward:
             x['_after_source_losses'] = detector_backward
             x['_side_stream'] = self.side
+        mark('step_begin')
         outputs = self.model(x, target)
         ctr_s, ctr_t = outputs['cluster_centers']
         x_small = _crops(image, get_corner_from_center(ctr_s, self.recon, self.new_w, self.new_h), self.recon)
@@ -158,6 +162,7 @@ class ScdaTrainer:
         src_recon, tgt_recon = self.dec(src_patch, tgt_patch)        # [C, 3, recon, recon]
 
         bce, sig = A.binary_cross_entropy, A.sigmoid
+        mark('crops+dec_fwd_enqueued')
 
         # ---------------- (1) image discriminators ----------------
         self.opt['dis'].zero_grad()
@@ -179,6 +184,7 @@ class ScdaTrainer:
         adloss = (ad_src + ad_tgt) / ws
         adloss.backward()
         w1 = self._reduce(self.dis, async_op=True)
+        mark('phase1')
 
         # ---------------- (2) patch discriminator ----------------
         self.opt['dis_patch'].zero_grad()
@@ -193,6 +199,7 @@ class ScdaTrainer:
         if w2 is not None:
             w2.wait()
         self.opt['dis_patch'].step()
+        mark('phase2')
 
         # ---------------- (3) decoders ----------------
         self.opt['dec'].zero_grad()
@@ -217,6 +224,7 @@ class ScdaTrainer:
             recon_loss = (fake1_src + fake1_tgt) / ws
             recon_loss.backward()
         w3 = self._reduce(self.dec, async_op=True)
+        mark('phase3')
 
         # ---------------- (4) detector ----------------
         # The swapped reconstruction of the reference's phase 4 only feeds the LOGGED loss: the cluster features are
@@ -246,6 +254,7 @@ class ScdaTrainer:
         if w4 is not None:
             w4.wait()
         self.opt['det'].step()
+        mark('phase4+det_step')
 
         return {'loss': loss.detach() * ws, 'rpn_cls': rpn_cls.detach(), 'rpn_loc': rpn_loc.detach(),
                 'rcnn_cls': rcnn_cls.detach(), 'rcnn_loc': rcnn_loc.detach(), 'rpn_acc': outputs['accuracy'][0],
