@@ -64,12 +64,16 @@ def synth_batch(rank):
 def cpu_baseline():
     """one full-size iteration of the CPU oracle on this box's host cores (bounded sample of the same workload)"""
     from oracle import torch_ref as R
+    from scda_amd.hostenv import cpu_quota
     try:
         import psutil
         cores = psutil.cpu_count(logical=False) or os.cpu_count() or 1
     except Exception:
         cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)   # physical cores: SMT siblings only slow the fp32 conv/GEMM loops down
+    quota = cpu_quota()           # the container's CFS quota is what the host actually grants (16 CPUs on the bench boxes)
+    if quota:
+        cores = min(cores, quota)
+    torch.set_num_threads(cores)
     R.use_cpu_backend()
     try:
         torch.manual_seed(0)

@@ -34,6 +34,10 @@ def _limit_host_pools_once():
     k-means centres (see tests/test_host_functions.py)."""
     if _POOLS_LIMITED:
         return
+    import os
+    if os.environ.get('SCDA_NO_POOL_LIMIT'):
+        _POOLS_LIMITED.append(None)
+        return
     try:
         from threadpoolctl import ThreadpoolController
         ctl = ThreadpoolController()

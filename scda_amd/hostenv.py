@@ -1,0 +1,43 @@
+"""Host-thread hygiene for the process that feeds the GPU.
+
+The SCDA iteration's host side is a single Python thread issuing ~1500 small launches plus a few ms of numpy; it needs
+one core.  Left alone, torch's intra-op pool (one thread per logical CPU, 256 on the MI355X hosts) and the BLAS/OpenMP
+pools of numpy/scipy/sklearn wake up for tiny parallel regions and spin; inside a container with a CFS quota
+(`cpu.max`, 16 CPUs on the benchmark boxes) that burns the quota within the first milliseconds of every 100 ms period
+and the kernel then freezes *all* threads -- including the one launching kernels -- until the period ends.  Measured
+(scripts/cpu_burn.py): 128 torch threads -> 16.0 cores busy, 35 of 36 periods throttled, 108 ms/iteration with the GPU
+idle a third of the time; 1-4 threads -> 1.2 cores busy, no throttling, 54.6 ms/iteration.
+"""
+import os
+
+_done = []
+
+
+def cpu_quota():
+    """CPUs this cgroup may use per period (cgroup v2 cpu.max / v1 cfs quota), or None if unlimited/unknown"""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if q == "max" else max(1, int(q) // int(p))
+    except Exception:
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else max(1, q // p)
+    except Exception:
+        return None
+
+
+def configure_host_threads(torch_threads=None):
+    """idempotent; torch intra-op threads -> min(4, quota) unless SCDA_TORCH_THREADS overrides; numpy/scipy/sklearn pools -> 1"""
+    if _done:
+        return
+    _done.append(True)
+    if os.environ.get("SCDA_KEEP_HOST_THREADS"):
+        return
+    import torch
+    n = torch_threads or int(os.environ.get("SCDA_TORCH_THREADS", "0")) or min(4, cpu_quota() or 4)
+    if torch.get_num_threads() > n:
+        torch.set_num_threads(n)
+    from .dropin.functions.mask import _limit_host_pools_once
+    _limit_host_pools_once()

@@ -103,8 +103,8 @@ class ScdaTrainer:
     def __init__(self, cfg, device, lr=1.25e-5, cluster_num=4, threshold=128, recon_size=256, new_w=1024, new_h=512,
                  weight_decay=1e-4, world_size=1, models=None):
         self.cfg, self.device = cfg, device
-        from .dropin.functions.mask import _limit_host_pools_once
-        _limit_host_pools_once()
+        from .hostenv import configure_host_threads
+        configure_host_threads()
         self.cluster_num, self.threshold, self.recon = cluster_num, threshold, recon_size
         self.new_w, self.new_h, self.world_size = new_w, new_h, world_size
         if models is None:
