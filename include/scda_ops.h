@@ -129,12 +129,15 @@ int scda_bbox_overlaps_hip(const float *boxes, int N, const float *query, int K,
  * act: 0 none, 1 ReLU, 2 LeakyReLU(slope) fused into the epilogue.
  * ws: workspace of scda_conv2d_workspace_bytes(...) bytes (split-K slabs).      */
 size_t scda_conv2d_workspace_bytes(int batch, int Cin, int IH, int IW, int Cout, int KH, int KW, int S, int P);
-int scda_conv2d_fwd_hip(const float *x, const float *w, const float *bias /*[Cout] or NULL*/, float *y, int batch,
+/* GEMM-ready weight: [Cout,Cin,KH,KW] -> [Cout,KH*KW,Cin] (for_dgrad = 0) or [Cin,KH*KW,Cout] (for_dgrad = 1).
+ * K runs tap-major so that a 16-deep K-slab is 16 consecutive channels at one filter tap. */
+int scda_conv2d_pack_weight_hip(const float *w, float *out, int Cout, int Cin, int KH, int KW, int for_dgrad,
+                                void *stream);
+/* wp = pack(w, 0) */
+int scda_conv2d_fwd_hip(const float *x, const float *wp, const float *bias /*[Cout] or NULL*/, float *y, int batch,
                         int Cin, int IH, int IW, int Cout, int KH, int KW, int S, int P, int act, float slope,
                         void *ws, size_t ws_bytes, void *stream);
-/* wt = w with dims 0 and 1 swapped ([Cin,Cout,KH,KW]); operand of the data-gradient GEMM */
-int scda_conv2d_swap01_hip(const float *w, float *wt, int Cout, int Cin, int KH, int KW, void *stream);
-/* dx [batch,Cin,IH,IW] = conv-transpose of dy [batch,Cout,OH,OW] (fully overwritten) */
+/* dx [batch,Cin,IH,IW] = conv-transpose of dy [batch,Cout,OH,OW] (fully overwritten); wt = pack(w, 1) */
 int scda_conv2d_dgrad_hip(const float *dy, const float *wt, float *dx, int batch, int Cin, int IH, int IW, int Cout,
                           int KH, int KW, int S, int P, void *ws, size_t ws_bytes, void *stream);
 /* dw [Cout,Cin,KH,KW] (+)= sum over batch and pixels; deterministic split-K (no atomics) */

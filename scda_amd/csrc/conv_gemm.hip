@@ -12,6 +12,12 @@
 // The im2col matrix is never materialised: each thread gathers its B elements
 // straight from the activation tensor into registers (prefetch for the next
 // K-step), then stages them in LDS in the k-major layout mfma_tile.h reads.
+//
+// K is ordered TAP-MAJOR for forward / dgrad:  k = (kh*KW + kw) * C + c.  A 16-deep K-slab is then 16 consecutive
+// channels at ONE filter tap, so the (kh,kw) decode, the bounds test and the pixel offset are computed once per
+// slab (scalar / one VALU op each) and the 8 gathers of a thread are `base + j*2*plane` -- the ablation in
+// scripts/ablate/ showed the per-element index math of the channel-major order cost 35 % of the kernel.  The weight
+// operand is pre-permuted to [M][KH*KW][C] by scda_conv2d_pack_weight_hip (cached per optimiser step by the caller).
 #include "mfma_tile.h"
 
 namespace scda {
@@ -24,7 +30,9 @@ struct ConvGeom {
     int pad;
     int M, N, K;
     int k_per_split;  // multiple of BK
-    Div dPHW, dPW;
+    int slab_aligned; // CB % BK == 0: a K-slab never straddles two filter taps
+    int a_vec4;       // K % 4 == 0 and 16-byte aligned weights: float4 loads of the A operand
+    Div dPHW, dPW, dCB;
 };
 
 struct Epi {
@@ -54,8 +62,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float *__restrict
     const int k_begin = blockIdx.z * g.k_per_split;
     const int k_end = min(g.K, k_begin + g.k_per_split);
 
-    // A staging: lanes along K (weights are K-contiguous): k = tid%16, rows tid/16 + 16*j
+    // A staging (weights, K-contiguous rows of the packed matrix):
+    //   vec4 path : lane -> (row = tid/4 [+64], 4 consecutive k) one global_load_dwordx4 per 64 rows
+    //   scalar path: k = tid%16, rows tid/16 + 16*j
     const int ka = tid & 15, ra = tid >> 4;
+    const int qa = tid & 3, rva = tid >> 2;
     // B staging: lanes along N (pixels are contiguous): n = tid%BN, k = tid/BN + KS*j (wave-uniform)
     constexpr int KS = 256 / BN;
     const int nb = tid % BN, kb = tid / BN;
@@ -71,39 +82,66 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float *__restrict
 
     float ar[T::A_ELEMS], br[T::B_ELEMS];
 
-    auto gload = [&](int k0) {
-#pragma unroll
-        for (int j = 0; j < T::A_ELEMS; ++j) {
-            const int m = m0 + ra + 16 * j, k = k0 + ka;
-            ar[j] = (m < g.M && k < k_end) ? Wm[(size_t)m * g.K + k] : 0.f;
+    // offset of tap (kh,kw) for this thread's pixel inside one channel plane, or -1 if it falls outside
+    auto tap_offset = [&](int kh, int kw) -> int {
+        if (!n_ok) return -1;
+        if (!DGRAD) {
+            const int iy = py * S + kh - g.pad, ix = px * S + kw - g.pad;
+            return ((unsigned)iy < (unsigned)g.HB && (unsigned)ix < (unsigned)g.WB) ? iy * g.WB + ix : -1;
+        } else {
+            const int ty = py + g.pad - kh, tx = px + g.pad - kw;
+            if (ty < 0 || tx < 0) return -1;
+            const int oy = ty / S, ox = tx / S;
+            return (oy * S == ty && ox * S == tx && oy < g.HB && ox < g.WB) ? oy * g.WB + ox : -1;
         }
+    };
+
+    auto gload = [&](int k0) {
+        if (g.a_vec4) {
 #pragma unroll
-        for (int j = 0; j < T::B_ELEMS; ++j) {
-            const int k = k0 + kb + KS * j;  // wave-uniform: the decode below is scalar work
-            const int c = k / (KH * KW);
-            const int rem = k - c * (KH * KW);
-            const int kh = rem / KW, kw = rem - kh * KW;
-            float v = 0.f;
-            if (n_ok && k < k_end) {
-                if (!DGRAD) {
-                    const int iy = py * S + kh - g.pad, ix = px * S + kw - g.pad;
-                    if ((unsigned)iy < (unsigned)g.HB && (unsigned)ix < (unsigned)g.WB)
-                        v = xb[(size_t)c * plane + iy * g.WB + ix];
-                } else {
-                    const int ty = py + g.pad - kh, tx = px + g.pad - kw;
-                    if (ty >= 0 && tx >= 0) {
-                        const int oy = ty / S, ox = tx / S;
-                        if (oy * S == ty && ox * S == tx && oy < g.HB && ox < g.WB)
-                            v = xb[(size_t)c * plane + oy * g.WB + ox];
-                    }
-                }
+            for (int j = 0; j < T::A_ELEMS / 4; ++j) {
+                const int m = m0 + rva + 64 * j, k = k0 + 4 * qa;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (m < g.M && k < k_end) v = *reinterpret_cast<const float4 *>(Wm + (size_t)m * g.K + k);
+                ar[4 * j + 0] = v.x; ar[4 * j + 1] = v.y; ar[4 * j + 2] = v.z; ar[4 * j + 3] = v.w;
             }
-            br[j] = v;
+        } else {
+#pragma unroll
+            for (int j = 0; j < T::A_ELEMS; ++j) {
+                const int m = m0 + ra + 16 * j, k = k0 + ka;
+                ar[j] = (m < g.M && k < k_end) ? Wm[(size_t)m * g.K + k] : 0.f;
+            }
+        }
+        if (g.slab_aligned) {
+            // whole slab = channels c0 .. c0+15 of one tap: decode once (k0 is wave-uniform -> scalar unit)
+            const int r = g.dCB.div(k0), c0 = k0 - r * g.CB;
+            const int kh = r / KW, kw = r - kh * KW;
+            const int off = tap_offset(kh, kw);
+            const float *src = xb + (size_t)(c0 + kb) * plane + (off < 0 ? 0 : off);
+            const bool ok = off >= 0 && k0 < k_end;
+#pragma unroll
+            for (int j = 0; j < T::B_ELEMS; ++j) br[j] = ok ? src[(size_t)(KS * j) * plane] : 0.f;
+        } else {
+#pragma unroll
+            for (int j = 0; j < T::B_ELEMS; ++j) {
+                const int k = k0 + kb + KS * j;  // wave-uniform
+                const int r = g.dCB.div(k), c = k - r * g.CB;
+                const int kh = r / KW, kw = r - kh * KW;
+                const int off = (k < k_end) ? tap_offset(kh, kw) : -1;
+                br[j] = off >= 0 ? xb[(size_t)c * plane + off] : 0.f;
+            }
         }
     };
     auto sstore = [&](int buf) {
+        if (g.a_vec4) {
 #pragma unroll
-        for (int j = 0; j < T::A_ELEMS; ++j) As(buf)[ka * T::LDA + ra + 16 * j] = ar[j];
+            for (int j = 0; j < T::A_ELEMS / 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) As(buf)[(4 * qa + i) * T::LDA + rva + 64 * j] = ar[4 * j + i];
+        } else {
+#pragma unroll
+            for (int j = 0; j < T::A_ELEMS; ++j) As(buf)[ka * T::LDA + ra + 16 * j] = ar[j];
+        }
 #pragma unroll
         for (int j = 0; j < T::B_ELEMS; ++j) Bs(buf)[(kb + KS * j) * T::LDB + nb] = br[j];
     };
@@ -387,16 +425,28 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float *__restrict__ A, 
     }
 }
 
-// W[d0][d1][khw] -> Wt[d1][d0][khw]   (weights for the dgrad-as-gather GEMM)
-__global__ __launch_bounds__(256) void swap01_kernel(const float *__restrict__ w, float *__restrict__ wt, const int d0,
-                                                     const int d1, const int khw) {
-    const long long total = (long long)d0 * d1 * khw;
+// weight packing for the tap-major GEMM:  w[Cout][Cin][R]  ->
+//   forward : out[Cout][R][Cin]      (M = Cout, k = r*Cin  + ci)
+//   dgrad   : out[Cin][R][Cout]      (M = Cin,  k = r*Cout + co)
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float *__restrict__ w, float *__restrict__ out,
+                                                          const int Cout, const int Cin, const int R,
+                                                          const int for_dgrad) {
+    const long long total = (long long)Cout * Cin * R;
     for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
          idx += (long long)blockDim.x * gridDim.x) {
-        const int t = (int)(idx % khw);
-        const long long r = idx / khw;
-        const int b = (int)(r % d0), a = (int)(r / d0);  // output index (a in d1, b in d0)
-        wt[idx] = w[((size_t)b * d1 + a) * khw + t];
+        int co, ci, r;
+        if (!for_dgrad) {  // idx enumerates out[co][r][ci]
+            ci = (int)(idx % Cin);
+            const long long t = idx / Cin;
+            r = (int)(t % R);
+            co = (int)(t / R);
+        } else {           // idx enumerates out[ci][r][co]
+            co = (int)(idx % Cout);
+            const long long t = idx / Cout;
+            r = (int)(t % R);
+            ci = (int)(t / R);
+        }
+        out[idx] = w[((size_t)co * Cin + ci) * R + r];
     }
 }
 
@@ -511,12 +561,14 @@ SCDA_API int scda_conv2d_fwd_hip(const float *x, const float *w, const float *bi
     ConvGeom g;
     g.batch = batch; g.CB = Cin; g.HB = IH; g.WB = IW; g.PH = OH; g.PW = OW; g.pad = P;
     g.M = Cout; g.N = batch * OH * OW; g.K = Cin * KH * KW; g.k_per_split = 0;
-    g.dPHW = Div(OH * OW); g.dPW = Div(OW);
+    g.dPHW = Div(OH * OW); g.dPW = Div(OW); g.dCB = Div(Cin);
+    g.slab_aligned = (Cin % BK) == 0;
+    g.a_vec4 = (g.K % 4) == 0 && (((uintptr_t)w) & 15) == 0;
     Epi e{y, nullptr, bias, 0, act, slope, 1};
     CONV_DISPATCH(launch_conv, , false > (w, x, g, e, (float *)ws, ws_bytes, as_stream(stream)))
 }
 
-// dx = dgrad(dy, wt) where wt = swap01(w) is [Cin][Cout][KH][KW] (scda_conv2d_swap01_hip)
+// dx = dgrad(dy, wt) where wt = pack(w, for_dgrad=1) is [Cin][KH*KW][Cout] (scda_conv2d_pack_weight_hip)
 SCDA_API int scda_conv2d_dgrad_hip(const float *dy, const float *wt, float *dx, int batch, int Cin, int IH, int IW,
                                    int Cout, int KH, int KW, int S, int P, void *ws, size_t ws_bytes, void *stream) {
     if (!dy || !wt || !dx || batch <= 0) { set_error("scda_conv2d_dgrad_hip: bad arguments"); return SCDA_EINVAL; }
@@ -524,16 +576,20 @@ SCDA_API int scda_conv2d_dgrad_hip(const float *dy, const float *wt, float *dx, 
     ConvGeom g;
     g.batch = batch; g.CB = Cout; g.HB = OH; g.WB = OW; g.PH = IH; g.PW = IW; g.pad = P;
     g.M = Cin; g.N = batch * IH * IW; g.K = Cout * KH * KW; g.k_per_split = 0;
-    g.dPHW = Div(IH * IW); g.dPW = Div(IW);
+    g.dPHW = Div(IH * IW); g.dPW = Div(IW); g.dCB = Div(Cout);
+    g.slab_aligned = (Cout % BK) == 0;
+    g.a_vec4 = (g.K % 4) == 0 && (((uintptr_t)wt) & 15) == 0;
     Epi e{dx, nullptr, nullptr, 0, (int)ACT_NONE, 0.f, 1};
     CONV_DISPATCH(launch_conv, , true > (wt, dy, g, e, (float *)ws, ws_bytes, as_stream(stream)))
 }
 
-SCDA_API int scda_conv2d_swap01_hip(const float *w, float *wt, int Cout, int Cin, int KH, int KW, void *stream) {
-    if (!w || !wt) { set_error("scda_conv2d_swap01_hip: null pointer"); return SCDA_EINVAL; }
+SCDA_API int scda_conv2d_pack_weight_hip(const float *w, float *out, int Cout, int Cin, int KH, int KW, int for_dgrad,
+                                         void *stream) {
+    if (!w || !out || Cout <= 0 || Cin <= 0) { set_error("scda_conv2d_pack_weight_hip: bad arguments"); return SCDA_EINVAL; }
     const long long total = (long long)Cout * Cin * KH * KW;
-    hipLaunchKernelGGL(swap01_kernel, dim3(ew_grid(total)), dim3(256), 0, as_stream(stream), w, wt, Cout, Cin, KH * KW);
-    return launch_status("swap01_kernel");
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(ew_grid(total)), dim3(256), 0, as_stream(stream), w, out, Cout, Cin, KH * KW,
+                       for_dgrad);
+    return launch_status("pack_weight_kernel");
 }
 
 SCDA_API int scda_conv2d_wgrad_hip(const float *dy, const float *x, float *dw, int batch, int Cin, int IH, int IW,

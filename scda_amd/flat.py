@@ -63,3 +63,4 @@ class FlatAdam:
         lr = self.param_groups[0]["lr"]
         N.adam_step(self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, lr, self.betas[0], self.betas[1],
                     self.eps, self.weight_decay, self.step_count)
+        N.WEIGHT_EPOCH[0] += 1   # the kernel wrote through raw pointers: packed-weight caches are stale now

@@ -7,6 +7,7 @@ device is missing.
 """
 import ctypes
 import os
+import weakref
 
 import torch
 
@@ -226,6 +227,32 @@ def _conv_ws(batch, cin, ih, iw, cout, kh, kw, s, p, device):
     return workspace(n, device), n
 
 
+WEIGHT_EPOCH = [0]   # bumped by the optimisers of this package after every step: invalidates packed-weight caches
+_PACK_CACHE = {}
+
+
+def conv2d_pack_weight(w, for_dgrad=False, cache=True):
+    """[Cout,Cin,KH,KW] -> GEMM-ready [Cout,KH*KW,Cin] (forward) or [Cin,KH*KW,Cout] (dgrad); 1x1 forward is the
+    identity.  Cached per (storage, direction) until the weight changes (tensor version or optimiser epoch)."""
+    _req(w, "w")
+    Cout, Cin, KH, KW = w.shape
+    if KH * KW == 1 and not for_dgrad:
+        return w
+    key = (w.data_ptr(), for_dgrad)
+    tag = (w._version, WEIGHT_EPOCH[0], tuple(w.shape))
+    if cache:
+        hit = _PACK_CACHE.get(key)
+        # valid only for the very same tensor object (a freed temporary's address may be reused by another weight)
+        if hit is not None and hit[0] == tag and hit[2]() is w:
+            return hit[1]
+    out = torch.empty(w.numel(), dtype=torch.float32, device=w.device)
+    _check(lib().scda_conv2d_pack_weight_hip(_p(w), _p(out), i32(Cout), i32(Cin), i32(KH), i32(KW), i32(int(for_dgrad)),
+                                             _stream()), "scda_conv2d_pack_weight_hip")
+    if cache:
+        _PACK_CACHE[key] = (tag, out, weakref.ref(w))
+    return out
+
+
 def conv2d_fwd(x, w, bias, stride, pad, act=ACT_NONE, slope=0.01):
     _req(x, "x"); _req(w, "w")
     if bias is not None:
@@ -236,29 +263,20 @@ def conv2d_fwd(x, w, bias, stride, pad, act=ACT_NONE, slope=0.01):
         raise ValueError(f"conv2d: input has {Cin} channels, weight expects {Cin2}")
     OH = (IH + 2 * pad - KH) // stride + 1
     OW = (IW + 2 * pad - KW) // stride + 1
+    wp = conv2d_pack_weight(w, False)
     y = torch.empty(B, Cout, OH, OW, dtype=torch.float32, device=x.device)
     ws, n = _conv_ws(B, Cin, IH, IW, Cout, KH, KW, stride, pad, x.device)
-    _check(lib().scda_conv2d_fwd_hip(_p(x), _p(w), _p(bias), _p(y), i32(B), i32(Cin), i32(IH), i32(IW), i32(Cout), i32(KH),
+    _check(lib().scda_conv2d_fwd_hip(_p(x), _p(wp), _p(bias), _p(y), i32(B), i32(Cin), i32(IH), i32(IW), i32(Cout), i32(KH),
                                      i32(KW), i32(stride), i32(pad), i32(act), f32(slope), _p(ws), _sz(n), _stream()),
            "scda_conv2d_fwd_hip")
     return y
 
 
-def conv2d_swap01(w):
-    _req(w, "w")
-    Cout, Cin, KH, KW = w.shape
-    wt = torch.empty(Cin, Cout, KH, KW, dtype=torch.float32, device=w.device)
-    _check(lib().scda_conv2d_swap01_hip(_p(w), _p(wt), i32(Cout), i32(Cin), i32(KH), i32(KW), _stream()),
-           "scda_conv2d_swap01_hip")
-    return wt
-
-
-def conv2d_dgrad(dy, w, x_shape, stride, pad, wt=None):
+def conv2d_dgrad(dy, w, x_shape, stride, pad):
     _req(dy, "dy"); _req(w, "w")
     B, Cin, IH, IW = x_shape
     Cout, _, KH, KW = w.shape
-    if wt is None:
-        wt = conv2d_swap01(w)
+    wt = conv2d_pack_weight(w, True)
     dx = torch.empty(B, Cin, IH, IW, dtype=torch.float32, device=dy.device)
     ws, n = _conv_ws(B, Cin, IH, IW, Cout, KH, KW, stride, pad, dy.device)
     _check(lib().scda_conv2d_dgrad_hip(_p(dy), _p(wt), _p(dx), i32(B), i32(Cin), i32(IH), i32(IW), i32(Cout), i32(KH),

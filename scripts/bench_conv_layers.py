@@ -28,10 +28,9 @@ for name, B, Cin, H, W, Cout, k, s, p in LAYERS:
     b = torch.randn(Cout, device=dev)
     y = native.conv2d_fwd(x, w, b, s, p, 1)
     dy = torch.randn_like(y)
-    wt = native.conv2d_swap01(w)
     flop = 2.0 * y.numel() * Cin * k * k
     tf = timeit(lambda: native.conv2d_fwd(x, w, b, s, p, 1))
-    td = timeit(lambda: native.conv2d_dgrad(dy, w, x.shape, s, p, wt=wt))
+    td = timeit(lambda: native.conv2d_dgrad(dy, w, x.shape, s, p))
     tw = timeit(lambda: native.conv2d_wgrad(dy, x, w.shape, s, p))
     rows.append((name, flop / 1e9, tf, flop / tf / 1e9, td, flop / td / 1e9, tw, flop / tw / 1e9))
     print("%-8s %7.2f GFLOP  fwd %7.3f ms %6.1f TF | dgrad %7.3f ms %6.1f TF | wgrad %7.3f ms %6.1f TF" % rows[-1], flush=True)
