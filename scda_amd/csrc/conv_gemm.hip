@@ -215,6 +215,7 @@ struct WgradGeom {
     int batch, Cin, IH, IW, Cout, OH, OW, pad;
     int M, N, K;  // Cout, Cin*KH*KW, batch*OH*OW
     int k_per_split;
+    int a_vec4;   // OH*OW % 4 == 0 and dY 16-byte aligned: float4 loads of dY
     Div dOHW, dOW;
 };
 
@@ -233,47 +234,77 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
     const int k_end = min(g.K, k_begin + g.k_per_split);
 
     // both operands are contiguous along K (= output pixels): lanes along K
+    //   A (dY rows = co): vec4 path lane -> (row = tid/4 [+64], 4 consecutive pixels); scalar path k = tid%16, rows tid/16+16j
+    //   B (X gather, rows n = (ci,kh,kw)): k = tid%16, rows tid/16 + 16*j
     const int kl = tid & 15, rl = tid >> 4;
+    const int qa = tid & 3, rva = tid >> 2;
     const int ohw = g.dOHW.d, ihw = g.IH * g.IW;
 
-    // per-row constants of the B gather: n -> (ci,kh,kw)
-    int b_coff[T::B_ELEMS], b_dy[T::B_ELEMS], b_dx[T::B_ELEMS];
+    // per-row constants of the B gather: n -> (ci,kh,kw):  signed offset of the tap inside the input plane, and the
+    // tap's index into the 9-bit validity mask that is rebuilt once per K-step from 3 row + 3 column tests
+    int b_base[T::B_ELEMS], b_tap[T::B_ELEMS];
 #pragma unroll
     for (int j = 0; j < T::B_ELEMS; ++j) {
         const int n = n0 + rl + 16 * j;
         const int c = n / (KH * KW), rem = n - c * (KH * KW);
         const int kh = rem / KW, kw = rem - kh * KW;
-        b_coff[j] = (n < g.N) ? c * ihw : -1;
-        b_dy[j] = kh - g.pad;
-        b_dx[j] = kw - g.pad;
+        b_base[j] = c * ihw + (kh - g.pad) * g.IW + (kw - g.pad);
+        b_tap[j] = (n < g.N) ? kh * KW + kw : 31;   // bit 31 of the mask is never set
     }
 
     float ar[T::A_ELEMS], br[T::B_ELEMS];
     auto gload = [&](int k0) {
+        if (g.a_vec4) {
+            const int k = k0 + 4 * qa;
+            int img, pix;
+            g.dOHW.divmod(k < k_end ? k : 0, img, pix);
+            const float *dyb = dY + (size_t)img * g.Cout * ohw + pix;
+#pragma unroll
+            for (int j = 0; j < T::A_ELEMS / 4; ++j) {
+                const int m = m0 + rva + 64 * j;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k < k_end && m < g.M) v = *reinterpret_cast<const float4 *>(dyb + (size_t)m * ohw);
+                ar[4 * j + 0] = v.x; ar[4 * j + 1] = v.y; ar[4 * j + 2] = v.z; ar[4 * j + 3] = v.w;
+            }
+        }
         const int k = k0 + kl;
         const bool k_ok = k < k_end;
         int img, pix, oy, ox;
         g.dOHW.divmod(k_ok ? k : 0, img, pix);
         g.dOW.divmod(pix, oy, ox);
-        const float *dyb = dY + (size_t)img * g.Cout * ohw + pix;
-        const float *xb = X + (size_t)img * g.Cin * ihw;
+        if (!g.a_vec4) {
+            const float *dyb = dY + (size_t)img * g.Cout * ohw + pix;
 #pragma unroll
-        for (int j = 0; j < T::A_ELEMS; ++j) {
-            const int m = m0 + rl + 16 * j;
-            ar[j] = (k_ok && m < g.M) ? dyb[(size_t)m * ohw] : 0.f;
+            for (int j = 0; j < T::A_ELEMS; ++j) {
+                const int m = m0 + rl + 16 * j;
+                ar[j] = (k_ok && m < g.M) ? dyb[(size_t)m * ohw] : 0.f;
+            }
         }
+        // validity of each of the KH*KW taps for this output pixel
+        unsigned mask = 0;
+        if (k_ok) {
 #pragma unroll
-        for (int j = 0; j < T::B_ELEMS; ++j) {
-            const int iy = oy * S + b_dy[j], ix = ox * S + b_dx[j];
-            float v = 0.f;
-            if (k_ok && b_coff[j] >= 0 && (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW)
-                v = xb[b_coff[j] + iy * g.IW + ix];
-            br[j] = v;
+            for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < KW; ++kw) {
+                    const int iy = oy * S + kh - g.pad, ix = ox * S + kw - g.pad;
+                    if ((unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW) mask |= 1u << (kh * KW + kw);
+                }
         }
+        const float *xb = X + (size_t)img * g.Cin * ihw + (oy * S) * g.IW + ox * S;
+#pragma unroll
+        for (int j = 0; j < T::B_ELEMS; ++j) br[j] = ((mask >> b_tap[j]) & 1u) ? xb[b_base[j]] : 0.f;
     };
     auto sstore = [&](int buf) {
+        if (g.a_vec4) {
 #pragma unroll
-        for (int j = 0; j < T::A_ELEMS; ++j) As(buf)[kl * T::LDA + rl + 16 * j] = ar[j];
+            for (int j = 0; j < T::A_ELEMS / 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) As(buf)[(4 * qa + i) * T::LDA + rva + 64 * j] = ar[4 * j + i];
+        } else {
+#pragma unroll
+            for (int j = 0; j < T::A_ELEMS; ++j) As(buf)[kl * T::LDA + rl + 16 * j] = ar[j];
+        }
 #pragma unroll
         for (int j = 0; j < T::B_ELEMS; ++j) Bs(buf)[kl * T::LDB + rl + 16 * j] = br[j];
     };
@@ -601,6 +632,7 @@ SCDA_API int scda_conv2d_wgrad_hip(const float *dy, const float *x, float *dw, i
     g.batch = batch; g.Cin = Cin; g.IH = IH; g.IW = IW; g.Cout = Cout; g.OH = OH; g.OW = OW; g.pad = P;
     g.M = Cout; g.N = Cin * KH * KW; g.K = batch * OH * OW; g.k_per_split = 0;
     g.dOHW = Div(OH * OW); g.dOW = Div(OW);
+    g.a_vec4 = ((OH * OW) % 4) == 0 && (((uintptr_t)dy) & 15) == 0;
     CONV_DISPATCH(launch_wgrad, > (dy, x, g, dw, accumulate, (float *)ws, ws_bytes, as_stream(stream)))
 }
 
