@@ -33,6 +33,9 @@ class FlatParams:
             p.grad = self.grad[off:off + n].view_as(p.data)
             off += sz
         self.numel = total
+        self.epoch = 0   # bumped by the optimiser after each step: invalidates packed-weight caches of THESE parameters only
+        for p in params:
+            p._scda_flat = self
         module._scda_flat = self
 
     def zero_grad(self):
@@ -63,4 +66,4 @@ class FlatAdam:
         lr = self.param_groups[0]["lr"]
         N.adam_step(self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, lr, self.betas[0], self.betas[1],
                     self.eps, self.weight_decay, self.step_count)
-        N.WEIGHT_EPOCH[0] += 1   # the kernel wrote through raw pointers: packed-weight caches are stale now
+        self.flat.epoch += 1   # the kernel wrote through raw pointers: packed-weight caches of this bucket are stale

@@ -227,7 +227,7 @@ def _conv_ws(batch, cin, ih, iw, cout, kh, kw, s, p, device):
     return workspace(n, device), n
 
 
-WEIGHT_EPOCH = [0]   # bumped by the optimisers of this package after every step: invalidates packed-weight caches
+WEIGHT_EPOCH = [0]   # fallback epoch for weights that are not part of a FlatParams bucket (bump after raw-pointer updates)
 _PACK_CACHE = {}
 
 
@@ -239,7 +239,8 @@ def conv2d_pack_weight(w, for_dgrad=False, cache=True):
     if KH * KW == 1 and not for_dgrad:
         return w
     key = (w.data_ptr(), for_dgrad)
-    tag = (w._version, WEIGHT_EPOCH[0], tuple(w.shape))
+    flat = getattr(w, "_scda_flat", None)
+    tag = (w._version, flat.epoch if flat is not None else WEIGHT_EPOCH[0], tuple(w.shape))
     if cache:
         hit = _PACK_CACHE.get(key)
         # valid only for the very same tensor object (a freed temporary's address may be reused by another weight)
@@ -404,23 +405,25 @@ def dropout_apply(x, mask, scale):
     return y
 
 
-def bias_grad_nchw(dy):
+def bias_grad_nchw(dy, out=None):
+    """db[c] = sum over batch and pixels; with `out` given, accumulates into it"""
     _req(dy, "dy")
     B, C = dy.shape[0], dy.shape[1]
     HW = dy.numel() // (B * C)
-    db = torch.empty(C, dtype=torch.float32, device=dy.device)
+    db = out if out is not None else torch.empty(C, dtype=torch.float32, device=dy.device)
     L = lib()
     L.scda_bias_grad_workspace_bytes.restype = ctypes.c_size_t
     ws = torch.empty(L.scda_bias_grad_workspace_bytes(i32(C)) // 4, dtype=torch.float32, device=dy.device)
-    _check(L.scda_bias_grad_nchw_hip(_p(dy), _p(db), i32(B), i32(C), i32(HW), i32(0), _p(ws), _stream()), "scda_bias_grad_nchw_hip")
+    _check(L.scda_bias_grad_nchw_hip(_p(dy), _p(db), i32(B), i32(C), i32(HW), i32(0 if out is None else 1), _p(ws), _stream()),
+           "scda_bias_grad_nchw_hip")
     return db
 
 
-def colsum(dy):
+def colsum(dy, out=None):
     _req(dy, "dy")
     M, N = dy.shape
-    db = torch.empty(N, dtype=torch.float32, device=dy.device)
-    _check(lib().scda_colsum_hip(_p(dy), _p(db), i32(M), i32(N), i32(0), _stream()), "scda_colsum_hip")
+    db = out if out is not None else torch.empty(N, dtype=torch.float32, device=dy.device)
+    _check(lib().scda_colsum_hip(_p(dy), _p(db), i32(M), i32(N), i32(0 if out is None else 1), _stream()), "scda_colsum_hip")
     return db
 
 
@@ -510,14 +513,16 @@ def batchnorm_fwd(x, gamma, beta, run_mean, run_var, eps, momentum, act, slope):
     return y, mean, rstd
 
 
-def batchnorm_bwd(dy, x, gamma, beta, mean, rstd, act, slope, need_dx=True):
+def batchnorm_bwd(dy, x, gamma, beta, mean, rstd, act, slope, need_dx=True, out=None):
+    """out = (dgamma, dbeta) buffers to accumulate into, or None to allocate"""
     _req(dy, "dy"); _req(x, "x")
     B, C, H, W = x.shape
     dx = torch.empty_like(x) if need_dx else None
-    dg = torch.empty(C, dtype=torch.float32, device=x.device)
-    db = torch.empty(C, dtype=torch.float32, device=x.device)
+    dg, db = out if out is not None else (torch.empty(C, dtype=torch.float32, device=x.device),
+                                          torch.empty(C, dtype=torch.float32, device=x.device))
     _check(lib().scda_batchnorm_bwd_hip(_p(dy), _p(x), _p(gamma), _p(beta), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db), i32(B), i32(C),
-                                        i32(H * W), i32(act), f32(slope), i32(0), _stream()), "scda_batchnorm_bwd_hip")
+                                        i32(H * W), i32(act), f32(slope), i32(0 if out is None else 1), _stream()),
+           "scda_batchnorm_bwd_hip")
     return dx, dg, db
 
 
