@@ -502,8 +502,10 @@ template <int KH, int KW, int S, bool DGRAD>
 static int launch_conv(const float *Wm, const float *X, const ConvGeom &g0, Epi e, float *ws, size_t ws_bytes,
                        hipStream_t st) {
     ConvGeom g = g0;
+    // 64-pixel N tiles: measured 10-12 % faster than 128 on every VGG layer (scripts/ablate/conv_ablate2: more
+    // resident workgroups per CU hide the gather latency better; accumulators drop to 32 registers per lane)
     const bool small_m = g.M <= 64;
-    const int BMv = small_m ? 64 : 128, BNv = 128;
+    const int BMv = small_m ? 64 : 128, BNv = 64;
     const long long tiles = (long long)cdiv(g.M, BMv) * cdiv(g.N, BNv);
     int splits = pick_splits(tiles, g.K);
     while (splits > 1 && (size_t)splits * g.M * g.N * sizeof(float) > ws_bytes) --splits;
@@ -514,9 +516,9 @@ static int launch_conv(const float *Wm, const float *X, const ConvGeom &g0, Epi 
     dim3 grid(cdiv(g.N, BNv), cdiv(g.M, BMv), splits);
     prof_begin(PK_CONV + ((DGRAD ? 2 : 0) + (small_m ? 1 : 0)) * 3 + prof_shape(KH, S), 2.0 * g.M * (double)g.N * g.K, st);
     if (small_m)
-        hipLaunchKernelGGL((conv_igemm_kernel<64, 128, KH, KW, S, DGRAD>), grid, dim3(256), 0, st, Wm, X, g, e);
+        hipLaunchKernelGGL((conv_igemm_kernel<64, 64, KH, KW, S, DGRAD>), grid, dim3(256), 0, st, Wm, X, g, e);
     else
-        hipLaunchKernelGGL((conv_igemm_kernel<128, 128, KH, KW, S, DGRAD>), grid, dim3(256), 0, st, Wm, X, g, e);
+        hipLaunchKernelGGL((conv_igemm_kernel<128, 64, KH, KW, S, DGRAD>), grid, dim3(256), 0, st, Wm, X, g, e);
     prof_end(st);
     int rc = launch_status("conv_igemm_kernel");
     if (rc || splits == 1) return rc;
