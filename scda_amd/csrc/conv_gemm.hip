@@ -18,6 +18,8 @@
 // slab (scalar / one VALU op each) and the 8 gathers of a thread are `base + j*2*plane` -- the ablation in
 // scripts/ablate/ showed the per-element index math of the channel-major order cost 35 % of the kernel.  The weight
 // operand is pre-permuted to [M][KH*KW][C] by scda_conv2d_pack_weight_hip (cached per optimiser step by the caller).
+#include <stdlib.h>
+
 #include "mfma_tile.h"
 
 namespace scda {
@@ -498,14 +500,25 @@ static int round_k_per_split(int K, int splits) {
     return kps;
 }
 
+// N-tile width.  Measured per VGG layer (gpurun_out/conv_layers_v4.log, SCDA_CONV_BN=64|128 A/B): 64-pixel tiles win
+// ~9 % when the 128-wide grid has about one workgroup per CU (conv4_x: 256 tiles) -- twice the workgroups, no split-K;
+// with fewer tiles split-K on 128-wide tiles is better, with more (>= 2 per CU) the wider tile's reuse wins.
+static int pick_bn(int M, int N, int K) {
+    (void)K;
+    const int BMv = M <= 64 ? 64 : 128;
+    const long long t128 = (long long)cdiv(M, BMv) * cdiv(N, 128);
+    return (t128 >= 192 && t128 < 512) ? 64 : 128;
+}
+
 template <int KH, int KW, int S, bool DGRAD>
 static int launch_conv(const float *Wm, const float *X, const ConvGeom &g0, Epi e, float *ws, size_t ws_bytes,
                        hipStream_t st) {
     ConvGeom g = g0;
-    // 64-pixel N tiles: measured 10-12 % faster than 128 on every VGG layer (scripts/ablate/conv_ablate2: more
-    // resident workgroups per CU hide the gather latency better; accumulators drop to 32 registers per lane)
     const bool small_m = g.M <= 64;
-    const int BMv = small_m ? 64 : 128, BNv = 64;
+    const int BMv = small_m ? 64 : 128;
+    int BNv = pick_bn(g.M, g.N, g.K);
+    static const char *force = getenv("SCDA_CONV_BN");   // experiment knob: 64 | 128
+    if (force) BNv = atoi(force) == 64 ? 64 : 128;
     const long long tiles = (long long)cdiv(g.M, BMv) * cdiv(g.N, BNv);
     int splits = pick_splits(tiles, g.K);
     while (splits > 1 && (size_t)splits * g.M * g.N * sizeof(float) > ws_bytes) --splits;
@@ -515,10 +528,14 @@ static int launch_conv(const float *Wm, const float *X, const ConvGeom &g0, Epi 
     e.ws = ws;
     dim3 grid(cdiv(g.N, BNv), cdiv(g.M, BMv), splits);
     prof_begin(PK_CONV + ((DGRAD ? 2 : 0) + (small_m ? 1 : 0)) * 3 + prof_shape(KH, S), 2.0 * g.M * (double)g.N * g.K, st);
-    if (small_m)
+    if (small_m && BNv == 64)
         hipLaunchKernelGGL((conv_igemm_kernel<64, 64, KH, KW, S, DGRAD>), grid, dim3(256), 0, st, Wm, X, g, e);
-    else
+    else if (small_m)
+        hipLaunchKernelGGL((conv_igemm_kernel<64, 128, KH, KW, S, DGRAD>), grid, dim3(256), 0, st, Wm, X, g, e);
+    else if (BNv == 64)
         hipLaunchKernelGGL((conv_igemm_kernel<128, 64, KH, KW, S, DGRAD>), grid, dim3(256), 0, st, Wm, X, g, e);
+    else
+        hipLaunchKernelGGL((conv_igemm_kernel<128, 128, KH, KW, S, DGRAD>), grid, dim3(256), 0, st, Wm, X, g, e);
     prof_end(st);
     int rc = launch_status("conv_igemm_kernel");
     if (rc || splits == 1) return rc;
