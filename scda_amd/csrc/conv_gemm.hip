@@ -24,6 +24,9 @@
 
 namespace scda {
 
+// float4 that only promises 4-byte alignment (global_load_dwordx4 needs dword, not 16-byte, alignment on gfx9+)
+struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };
+
 struct ConvGeom {
     // tensor the B operand gathers from: [batch, CB, HB, WB]
     int batch, CB, HB, WB;
@@ -34,6 +37,7 @@ struct ConvGeom {
     int k_per_split;  // multiple of BK
     int slab_aligned; // CB % BK == 0: a K-slab never straddles two filter taps
     int a_vec4;       // K % 4 == 0 and 16-byte aligned weights: float4 loads of the A operand
+    int b_vec4;       // stride 1, slab_aligned, pixel-row length % 4 == 0: 4 consecutive pixels per gather (dwordx4)
     Div dPHW, dPW, dCB;
 };
 
@@ -82,6 +86,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float *__restrict
     const float *xb = X + (size_t)img * g.CB * g.HB * g.WB;
     const int plane = g.HB * g.WB;
 
+    // vec4 B staging (stride-1 convs): lane -> 4 consecutive pixels of one k-row; BN/4 lanes per row
+    constexpr int NQ = BN / 4, KV = 256 / NQ;          // rows covered per pass
+    const int nq = tid % NQ, kq = tid / NQ;
+    int vimg = 0, vpy = 0, vpx = 0;
+    bool vn_ok = false;
+    if (S == 1 && g.b_vec4) {
+        const int n4 = n0 + 4 * nq;
+        vn_ok = n4 < g.N;
+        int vpix;
+        g.dPHW.divmod(vn_ok ? n4 : 0, vimg, vpix);
+        g.dPW.divmod(vpix, vpy, vpx);
+    }
+    const float *xbv = X + (size_t)vimg * g.CB * g.HB * g.WB;
+
     float ar[T::A_ELEMS], br[T::B_ELEMS];
 
     // offset of tap (kh,kw) for this thread's pixel inside one channel plane, or -1 if it falls outside
@@ -114,7 +132,33 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float *__restrict
                 ar[j] = (m < g.M && k < k_end) ? Wm[(size_t)m * g.K + k] : 0.f;
             }
         }
-        if (g.slab_aligned) {
+        if (S == 1 && g.b_vec4) {
+            // 4 consecutive pixels of the same image row per lane: one (possibly 4-byte-aligned) dwordx4 gather
+            const int r = g.dCB.div(k0), c0 = k0 - r * g.CB;
+            const int kh = r / KW, kw = r - kh * KW;
+            const int iy = DGRAD ? vpy + g.pad - kh : vpy + kh - g.pad;
+            const int ix0 = DGRAD ? vpx + g.pad - kw : vpx + kw - g.pad;
+            const bool row_ok = vn_ok && k0 < k_end && (unsigned)iy < (unsigned)g.HB;
+            const bool all_in = ix0 >= 0 && ix0 + 3 < g.WB;
+            const float *src = xbv + (size_t)(c0 + kq) * plane + iy * g.WB + ix0;
+#pragma unroll
+            for (int j = 0; j < T::B_ELEMS / 4; ++j) {
+                const float *p = src + (size_t)(KV * j) * plane;
+                float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+                if (row_ok) {
+                    if (all_in) {
+                        const f4u v = *reinterpret_cast<const f4u *>(p);
+                        v0 = v.x; v1 = v.y; v2 = v.z; v3 = v.w;
+                    } else {   // image border: per-element bounds (two lanes per pixel row at most)
+                        if ((unsigned)(ix0 + 0) < (unsigned)g.WB) v0 = p[0];
+                        if ((unsigned)(ix0 + 1) < (unsigned)g.WB) v1 = p[1];
+                        if ((unsigned)(ix0 + 2) < (unsigned)g.WB) v2 = p[2];
+                        if ((unsigned)(ix0 + 3) < (unsigned)g.WB) v3 = p[3];
+                    }
+                }
+                br[4 * j + 0] = v0; br[4 * j + 1] = v1; br[4 * j + 2] = v2; br[4 * j + 3] = v3;
+            }
+        } else if (g.slab_aligned) {
             // whole slab = channels c0 .. c0+15 of one tap: decode once (k0 is wave-uniform -> scalar unit)
             const int r = g.dCB.div(k0), c0 = k0 - r * g.CB;
             const int kh = r / KW, kw = r - kh * KW;
@@ -144,8 +188,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float *__restrict
 #pragma unroll
             for (int j = 0; j < T::A_ELEMS; ++j) As(buf)[ka * T::LDA + ra + 16 * j] = ar[j];
         }
+        if (S == 1 && g.b_vec4) {
 #pragma unroll
-        for (int j = 0; j < T::B_ELEMS; ++j) Bs(buf)[(kb + KS * j) * T::LDB + nb] = br[j];
+            for (int j = 0; j < T::B_ELEMS / 4; ++j)
+                *reinterpret_cast<float4 *>(Bs(buf) + (kq + KV * j) * T::LDB + 4 * nq) =
+                    make_float4(br[4 * j], br[4 * j + 1], br[4 * j + 2], br[4 * j + 3]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < T::B_ELEMS; ++j) Bs(buf)[(kb + KS * j) * T::LDB + nb] = br[j];
+        }
     };
 
     f32x16 acc[T::TM][T::TN];
@@ -614,6 +665,7 @@ SCDA_API int scda_conv2d_fwd_hip(const float *x, const float *w, const float *bi
     g.dPHW = Div(OH * OW); g.dPW = Div(OW); g.dCB = Div(Cin);
     g.slab_aligned = (Cin % BK) == 0;
     g.a_vec4 = (g.K % 4) == 0 && (((uintptr_t)w) & 15) == 0;
+    g.b_vec4 = S == 1 && g.slab_aligned && (OW % 4) == 0 && (g.N % 4) == 0 && !getenv("SCDA_CONV_NO_BVEC");
     Epi e{y, nullptr, bias, 0, act, slope, 1};
     CONV_DISPATCH(launch_conv, , false > (w, x, g, e, (float *)ws, ws_bytes, as_stream(stream)))
 }
@@ -629,6 +681,7 @@ SCDA_API int scda_conv2d_dgrad_hip(const float *dy, const float *wt, float *dx, 
     g.dPHW = Div(IH * IW); g.dPW = Div(IW); g.dCB = Div(Cout);
     g.slab_aligned = (Cout % BK) == 0;
     g.a_vec4 = (g.K % 4) == 0 && (((uintptr_t)wt) & 15) == 0;
+    g.b_vec4 = S == 1 && g.slab_aligned && (IW % 4) == 0 && (g.N % 4) == 0 && !getenv("SCDA_CONV_NO_BVEC");
     Epi e{dx, nullptr, nullptr, 0, (int)ACT_NONE, 0.f, 1};
     CONV_DISPATCH(launch_conv, , true > (wt, dy, g, e, (float *)ws, ws_bytes, as_stream(stream)))
 }
