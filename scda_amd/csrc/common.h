@@ -37,6 +37,11 @@ static inline int ew_grid(long long n, int block = 256) {
 
 constexpr int kWave = 64;  // gfx950 wavefront
 
+// 4 KB of device zeros (per device, allocated on first use, never freed).  Gathers whose lane falls outside the
+// tensor read from here instead of being predicated: with no select after the load there is nothing that needs the
+// loaded value before the LDS store, so the s_waitcnt lands AFTER the MFMAs of the current K-slab.
+const float *zero_page();
+
 // ---- optional per-launch timing of the GEMM-class kernels (scda_prof_* in the C ABI) ----
 // When enabled, a hipEvent pair is recorded on the launch stream around the tagged kernel;
 // scda_prof_collect() (after a device sync) turns them into per-kernel count / time / flops.

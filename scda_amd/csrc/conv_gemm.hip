@@ -38,6 +38,7 @@ struct ConvGeom {
     int slab_aligned; // CB % BK == 0: a K-slab never straddles two filter taps
     int a_vec4;       // K % 4 == 0 and 16-byte aligned weights: float4 loads of the A operand
     int b_vec4;       // stride 1, slab_aligned, pixel-row length % 4 == 0: 4 consecutive pixels per gather (dwordx4)
+    const float *zp;  // zero page: source of every out-of-range gather lane
     Div dPHW, dPW, dCB;
 };
 
@@ -54,7 +55,11 @@ struct Epi {
 // ---------------------------------------------------------------------------
 // conv forward / dgrad
 // ---------------------------------------------------------------------------
-template <int BM, int BN, int KH, int KW, int S, bool DGRAD>
+// FAST = weights 16-byte aligned with K % 4 == 0 (float4 A loads) AND channel count % 16 == 0 (a K-slab never straddles
+// two filter taps).  Every VGG / RPN / decoder / discriminator layer except the 3-channel stems qualifies.  All gathers
+// are issued UNCONDITIONALLY from a clamped in-bounds address and zeroed with a select afterwards: a predicated
+// `cond ? *p : 0` made hipcc wrap every single load in its own exec-mask branch (one s_cbranch per load).
+template <int BM, int BN, int KH, int KW, int S, bool DGRAD, bool FAST>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const float *__restrict__ Wm, const float *__restrict__ X,
                                                          const ConvGeom g, const Epi e) {
     using T = TileCfg<BM, BN>;
@@ -117,69 +122,43 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float *__restrict
     };
 
     auto gload = [&](int k0) {
-        if (g.a_vec4) {
+        if (FAST) {
 #pragma unroll
             for (int j = 0; j < T::A_ELEMS / 4; ++j) {
                 const int m = m0 + rva + 64 * j, k = k0 + 4 * qa;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (m < g.M && k < k_end) v = *reinterpret_cast<const float4 *>(Wm + (size_t)m * g.K + k);
+                const float *pa = (m < g.M && k < k_end) ? Wm + (size_t)m * g.K + k : g.zp;
+                const float4 v = *reinterpret_cast<const float4 *>(pa);
                 ar[4 * j + 0] = v.x; ar[4 * j + 1] = v.y; ar[4 * j + 2] = v.z; ar[4 * j + 3] = v.w;
             }
-        } else {
-#pragma unroll
-            for (int j = 0; j < T::A_ELEMS; ++j) {
-                const int m = m0 + ra + 16 * j, k = k0 + ka;
-                ar[j] = (m < g.M && k < k_end) ? Wm[(size_t)m * g.K + k] : 0.f;
-            }
-        }
-        if (S == 1 && g.b_vec4) {
-            // 4 consecutive pixels of the same image row per lane: one (possibly 4-byte-aligned) dwordx4 gather
-            const int r = g.dCB.div(k0), c0 = k0 - r * g.CB;
-            const int kh = r / KW, kw = r - kh * KW;
-            const int iy = DGRAD ? vpy + g.pad - kh : vpy + kh - g.pad;
-            const int ix0 = DGRAD ? vpx + g.pad - kw : vpx + kw - g.pad;
-            const bool row_ok = vn_ok && k0 < k_end && (unsigned)iy < (unsigned)g.HB;
-            const bool all_in = ix0 >= 0 && ix0 + 3 < g.WB;
-            const float *src = xbv + (size_t)(c0 + kq) * plane + iy * g.WB + ix0;
-#pragma unroll
-            for (int j = 0; j < T::B_ELEMS / 4; ++j) {
-                const float *p = src + (size_t)(KV * j) * plane;
-                float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
-                if (row_ok) {
-                    if (all_in) {
-                        const f4u v = *reinterpret_cast<const f4u *>(p);
-                        v0 = v.x; v1 = v.y; v2 = v.z; v3 = v.w;
-                    } else {   // image border: per-element bounds (two lanes per pixel row at most)
-                        if ((unsigned)(ix0 + 0) < (unsigned)g.WB) v0 = p[0];
-                        if ((unsigned)(ix0 + 1) < (unsigned)g.WB) v1 = p[1];
-                        if ((unsigned)(ix0 + 2) < (unsigned)g.WB) v2 = p[2];
-                        if ((unsigned)(ix0 + 3) < (unsigned)g.WB) v3 = p[3];
-                    }
-                }
-                br[4 * j + 0] = v0; br[4 * j + 1] = v1; br[4 * j + 2] = v2; br[4 * j + 3] = v3;
-            }
-        } else if (g.slab_aligned) {
             // whole slab = channels c0 .. c0+15 of one tap: decode once (k0 is wave-uniform -> scalar unit)
             const int r = g.dCB.div(k0), c0 = k0 - r * g.CB;
             const int kh = r / KW, kw = r - kh * KW;
             const int off = tap_offset(kh, kw);
-            const float *src = xb + (size_t)(c0 + kb) * plane + (off < 0 ? 0 : off);
-            const bool ok = off >= 0 && k0 < k_end;
+            const float *src = off >= 0 ? xb + (size_t)(c0 + kb) * plane + off : g.zp;
+            const size_t stride = off >= 0 ? (size_t)KS * plane : 0;
 #pragma unroll
-            for (int j = 0; j < T::B_ELEMS; ++j) br[j] = ok ? src[(size_t)(KS * j) * plane] : 0.f;
+            for (int j = 0; j < T::B_ELEMS; ++j) br[j] = src[j * stride];
         } else {
+#pragma unroll
+            for (int j = 0; j < T::A_ELEMS; ++j) {
+                const int m = m0 + ra + 16 * j, k = k0 + ka;
+                const float *pa = (m < g.M && k < k_end) ? Wm + (size_t)m * g.K + k : g.zp;
+                ar[j] = *pa;
+            }
 #pragma unroll
             for (int j = 0; j < T::B_ELEMS; ++j) {
                 const int k = k0 + kb + KS * j;  // wave-uniform
-                const int r = g.dCB.div(k), c = k - r * g.CB;
+                const bool k_ok = k < k_end;
+                const int r = g.dCB.div(k_ok ? k : 0), c = (k_ok ? k : 0) - r * g.CB;
                 const int kh = r / KW, kw = r - kh * KW;
-                const int off = (k < k_end) ? tap_offset(kh, kw) : -1;
-                br[j] = off >= 0 ? xb[(size_t)c * plane + off] : 0.f;
+                const int off = k_ok ? tap_offset(kh, kw) : -1;
+                const float *pb = off >= 0 ? xb + (size_t)c * plane + off : g.zp;
+                br[j] = *pb;
             }
         }
     };
     auto sstore = [&](int buf) {
-        if (g.a_vec4) {
+        if (FAST) {
 #pragma unroll
             for (int j = 0; j < T::A_ELEMS / 4; ++j)
 #pragma unroll
@@ -188,15 +167,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float *__restrict
 #pragma unroll
             for (int j = 0; j < T::A_ELEMS; ++j) As(buf)[ka * T::LDA + ra + 16 * j] = ar[j];
         }
-        if (S == 1 && g.b_vec4) {
 #pragma unroll
-            for (int j = 0; j < T::B_ELEMS / 4; ++j)
-                *reinterpret_cast<float4 *>(Bs(buf) + (kq + KV * j) * T::LDB + 4 * nq) =
-                    make_float4(br[4 * j], br[4 * j + 1], br[4 * j + 2], br[4 * j + 3]);
-        } else {
-#pragma unroll
-            for (int j = 0; j < T::B_ELEMS; ++j) Bs(buf)[(kb + KS * j) * T::LDB + nb] = br[j];
-        }
+        for (int j = 0; j < T::B_ELEMS; ++j) Bs(buf)[(kb + KS * j) * T::LDB + nb] = br[j];
     };
 
     f32x16 acc[T::TM][T::TN];
@@ -579,14 +551,17 @@ static int launch_conv(const float *Wm, const float *X, const ConvGeom &g0, Epi 
     e.ws = ws;
     dim3 grid(cdiv(g.N, BNv), cdiv(g.M, BMv), splits);
     prof_begin(PK_CONV + ((DGRAD ? 2 : 0) + (small_m ? 1 : 0)) * 3 + prof_shape(KH, S), 2.0 * g.M * (double)g.N * g.K, st);
-    if (small_m && BNv == 64)
-        hipLaunchKernelGGL((conv_igemm_kernel<64, 64, KH, KW, S, DGRAD>), grid, dim3(256), 0, st, Wm, X, g, e);
-    else if (small_m)
-        hipLaunchKernelGGL((conv_igemm_kernel<64, 128, KH, KW, S, DGRAD>), grid, dim3(256), 0, st, Wm, X, g, e);
-    else if (BNv == 64)
-        hipLaunchKernelGGL((conv_igemm_kernel<128, 64, KH, KW, S, DGRAD>), grid, dim3(256), 0, st, Wm, X, g, e);
-    else
-        hipLaunchKernelGGL((conv_igemm_kernel<128, 128, KH, KW, S, DGRAD>), grid, dim3(256), 0, st, Wm, X, g, e);
+    const bool fast = g.a_vec4 && g.slab_aligned;
+#define CONV_LAUNCH(BM_, BN_)                                                                                       \
+    do {                                                                                                            \
+        if (fast) hipLaunchKernelGGL((conv_igemm_kernel<BM_, BN_, KH, KW, S, DGRAD, true>), grid, dim3(256), 0, st, Wm, X, g, e);  \
+        else hipLaunchKernelGGL((conv_igemm_kernel<BM_, BN_, KH, KW, S, DGRAD, false>), grid, dim3(256), 0, st, Wm, X, g, e);      \
+    } while (0)
+    if (small_m && BNv == 64) CONV_LAUNCH(64, 64);
+    else if (small_m) CONV_LAUNCH(64, 128);
+    else if (BNv == 64) CONV_LAUNCH(128, 64);
+    else CONV_LAUNCH(128, 128);
+#undef CONV_LAUNCH
     prof_end(st);
     int rc = launch_status("conv_igemm_kernel");
     if (rc || splits == 1) return rc;
@@ -657,6 +632,7 @@ SCDA_API int scda_conv2d_fwd_hip(const float *x, const float *w, const float *bi
                                  int IW, int Cout, int KH, int KW, int S, int P, int act, float slope, void *ws,
                                  size_t ws_bytes, void *stream) {
     if (!x || !w || !y || batch <= 0 || Cin <= 0 || Cout <= 0) { set_error("scda_conv2d_fwd_hip: bad arguments"); return SCDA_EINVAL; }
+    if (!zero_page()) { set_error("scda_conv2d_fwd_hip: could not allocate the zero page"); return SCDA_ELAUNCH; }
     const int OH = conv_out_dim(IH, KH, S, P), OW = conv_out_dim(IW, KW, S, P);
     if (OH <= 0 || OW <= 0) { set_error("scda_conv2d_fwd_hip: empty output"); return SCDA_EINVAL; }
     ConvGeom g;
@@ -665,6 +641,7 @@ SCDA_API int scda_conv2d_fwd_hip(const float *x, const float *w, const float *bi
     g.dPHW = Div(OH * OW); g.dPW = Div(OW); g.dCB = Div(Cin);
     g.slab_aligned = (Cin % BK) == 0;
     g.a_vec4 = (g.K % 4) == 0 && (((uintptr_t)w) & 15) == 0;
+    g.zp = zero_page();
     g.b_vec4 = S == 1 && g.slab_aligned && (OW % 4) == 0 && (g.N % 4) == 0 && !getenv("SCDA_CONV_NO_BVEC");
     Epi e{y, nullptr, bias, 0, act, slope, 1};
     CONV_DISPATCH(launch_conv, , false > (w, x, g, e, (float *)ws, ws_bytes, as_stream(stream)))
@@ -681,6 +658,7 @@ SCDA_API int scda_conv2d_dgrad_hip(const float *dy, const float *wt, float *dx, 
     g.dPHW = Div(IH * IW); g.dPW = Div(IW); g.dCB = Div(Cout);
     g.slab_aligned = (Cout % BK) == 0;
     g.a_vec4 = (g.K % 4) == 0 && (((uintptr_t)wt) & 15) == 0;
+    g.zp = zero_page();
     g.b_vec4 = S == 1 && g.slab_aligned && (IW % 4) == 0 && (g.N % 4) == 0 && !getenv("SCDA_CONV_NO_BVEC");
     Epi e{dx, nullptr, nullptr, 0, (int)ACT_NONE, 0.f, 1};
     CONV_DISPATCH(launch_conv, , true > (wt, dy, g, e, (float *)ws, ws_bytes, as_stream(stream)))

@@ -24,6 +24,18 @@ void set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
+const float *zero_page() {
+    static const float *pages[64] = {nullptr};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64) dev = 0;
+    if (!pages[dev]) {
+        void *p = nullptr;
+        if (hipMalloc(&p, 4096) == hipSuccess && hipMemset(p, 0, 4096) == hipSuccess) pages[dev] = (const float *)p;
+    }
+    return pages[dev];
+}
+
 // ---- launch profiler (see common.h) ----------------------------------------
 struct ProfRec { int kernel; double flops; hipEvent_t a, b; };
 static unsigned g_prof_mask = 0;  // bit k set: time launches of kernel class k
