@@ -241,6 +241,7 @@ struct WgradGeom {
     int M, N, K;  // Cout, Cin*KH*KW, batch*OH*OW
     int k_per_split;
     int a_vec4;   // OH*OW % 4 == 0 and dY 16-byte aligned: float4 loads of dY
+    const float *zp;
     Div dOHW, dOW;
 };
 
@@ -287,8 +288,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
 #pragma unroll
             for (int j = 0; j < T::A_ELEMS / 4; ++j) {
                 const int m = m0 + rva + 64 * j;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (k < k_end && m < g.M) v = *reinterpret_cast<const float4 *>(dyb + (size_t)m * ohw);
+                const float *pa = (k < k_end && m < g.M) ? dyb + (size_t)m * ohw : g.zp;
+                const float4 v = *reinterpret_cast<const float4 *>(pa);
                 ar[4 * j + 0] = v.x; ar[4 * j + 1] = v.y; ar[4 * j + 2] = v.z; ar[4 * j + 3] = v.w;
             }
         }
@@ -302,7 +303,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
 #pragma unroll
             for (int j = 0; j < T::A_ELEMS; ++j) {
                 const int m = m0 + rl + 16 * j;
-                ar[j] = (k_ok && m < g.M) ? dyb[(size_t)m * ohw] : 0.f;
+                const float *pa = (k_ok && m < g.M) ? dyb + (size_t)m * ohw : g.zp;
+                ar[j] = *pa;
             }
         }
         // validity of each of the KH*KW taps for this output pixel
@@ -318,7 +320,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
         }
         const float *xb = X + (size_t)img * g.Cin * ihw + (oy * S) * g.IW + ox * S;
 #pragma unroll
-        for (int j = 0; j < T::B_ELEMS; ++j) br[j] = ((mask >> b_tap[j]) & 1u) ? xb[b_base[j]] : 0.f;
+        for (int j = 0; j < T::B_ELEMS; ++j) {
+            const float *pb = ((mask >> b_tap[j]) & 1u) ? xb + b_base[j] : g.zp;
+            br[j] = *pb;
+        }
     };
     auto sstore = [&](int buf) {
         if (g.a_vec4) {
@@ -387,6 +392,7 @@ __global__ __launch_bounds__(256) void dense_splitk_reduce_kernel(const float *_
 struct GemmGeom {
     int M, N, K, lda, ldb, ldc;
     int k_per_split;
+    const float *zp;
 };
 
 template <int BM, int BN, bool TA, bool TB>
@@ -414,20 +420,24 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float *__restrict__ A, 
         for (int j = 0; j < T::A_ELEMS; ++j) {
             if (!TA) {
                 const int m = m0 + rl + 16 * j, k = k0 + kl;
-                ar[j] = (m < g.M && k < k_end) ? A[(size_t)m * g.lda + k] : 0.f;
+                const float *pa = (m < g.M && k < k_end) ? A + (size_t)m * g.lda + k : g.zp;
+                ar[j] = *pa;
             } else {
                 const int m = m0 + ma, k = k0 + kma + KSA * j;
-                ar[j] = (m < g.M && k < k_end) ? A[(size_t)k * g.lda + m] : 0.f;
+                const float *pa = (m < g.M && k < k_end) ? A + (size_t)k * g.lda + m : g.zp;
+                ar[j] = *pa;
             }
         }
 #pragma unroll
         for (int j = 0; j < T::B_ELEMS; ++j) {
             if (!TB) {
                 const int n = n0 + rl + 16 * j, k = k0 + kl;
-                br[j] = (n < g.N && k < k_end) ? B[(size_t)n * g.ldb + k] : 0.f;
+                const float *pb = (n < g.N && k < k_end) ? B + (size_t)n * g.ldb + k : g.zp;
+                br[j] = *pb;
             } else {
                 const int n = n0 + nbb, k = k0 + knb + KSB * j;
-                br[j] = (n < g.N && k < k_end) ? B[(size_t)k * g.ldb + n] : 0.f;
+                const float *pb = (n < g.N && k < k_end) ? B + (size_t)k * g.ldb + n : g.zp;
+                br[j] = *pb;
             }
         }
     };
@@ -683,6 +693,8 @@ SCDA_API int scda_conv2d_wgrad_hip(const float *dy, const float *x, float *dw, i
     g.M = Cout; g.N = Cin * KH * KW; g.K = batch * OH * OW; g.k_per_split = 0;
     g.dOHW = Div(OH * OW); g.dOW = Div(OW);
     g.a_vec4 = ((OH * OW) % 4) == 0 && (((uintptr_t)dy) & 15) == 0;
+    g.zp = zero_page();
+    if (!g.zp) { set_error("scda_conv2d_wgrad_hip: could not allocate the zero page"); return SCDA_ELAUNCH; }
     CONV_DISPATCH(launch_wgrad, > (dy, x, g, dw, accumulate, (float *)ws, ws_bytes, as_stream(stream)))
 }
 
@@ -704,7 +716,8 @@ SCDA_API int scda_gemm_hip(const float *A, const float *B, float *C, int M, int 
     while (splits > 1 && (size_t)splits * M * N * sizeof(float) > ws_bytes) --splits;
     if (accumulate && splits == 1) { set_error("scda_gemm_hip: accumulate needs a workspace"); return SCDA_EINVAL; }
     if (splits > 1 && ldc != N) { set_error("scda_gemm_hip: split-K needs ldc == N"); return SCDA_EINVAL; }
-    GemmGeom g{M, N, K, lda, ldb, ldc, round_k_per_split(K, splits)};
+    GemmGeom g{M, N, K, lda, ldb, ldc, round_k_per_split(K, splits), zero_page()};
+    if (!g.zp) { set_error("scda_gemm_hip: could not allocate the zero page"); return SCDA_ELAUNCH; }
     splits = cdiv(K, g.k_per_split);
     Epi e{C, (float *)ws, bias, bias_on_n, act, slope, splits};
     dim3 grid(cdiv(N, BNv), cdiv(M, BMv), splits);
