@@ -523,7 +523,8 @@ static int pick_splits(long long tiles, int K, int want_blocks = 512) {
     int max_s = K / (BK * 4);  // at least 4 K-steps per split
     if (max_s < 1) max_s = 1;
     if (s > max_s) s = max_s;
-    if (s > 64) s = 64;
+    const int cap = tiles <= 2 ? 256 : 64;   // a single-tile weight gradient (conv1_1: 64x27) still has to fill 256 CUs
+    if (s > cap) s = cap;
     return s < 1 ? 1 : s;
 }
 
@@ -630,7 +631,7 @@ SCDA_API size_t scda_conv2d_workspace_bytes(int batch, int Cin, int IH, int IW, 
     size_t out_elems = (size_t)batch * Cout * OH * OW, in_elems = (size_t)batch * Cin * IH * IW;
     size_t w_elems = (size_t)Cout * Cin * KH * KW;
     size_t a = 8 * (out_elems > in_elems ? out_elems : in_elems);
-    size_t b = 64 * w_elems;
+    size_t b = (w_elems <= 64 * 128 ? 256 : 64) * w_elems;
     size_t cap = (size_t)256 << 20;  // slabs never need to exceed 256 MB: pick_splits shrinks to fit
     size_t need = (a > b ? a : b) * sizeof(float);
     if (need > cap) need = cap;

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const int n, const float t
 
 // Greedy sweep on the device: one 256-thread workgroup walks the 64-box chunks.
 // Per chunk, wave 0 resolves the 64 in-chunk decisions from the diagonal word
-// (a 64-step scalar recurrence over v_readlane), then all waves OR the kept
+// (a scalar recurrence over v_readlane, one step per kept box), then all waves OR the kept
 // boxes' mask rows into the LDS-resident "removed" bit vector.
 __global__ __launch_bounds__(256) void nms_sweep_kernel(const uint64_t *__restrict__ mask, const int n,
                                                         const int col_blocks, int64_t *__restrict__ keep,
@@ -144,12 +144,19 @@ __global__ __launch_bounds__(256) void nms_sweep_kernel(const uint64_t *__restri
             uint64_t removed = remv[b];
             uint64_t kept = 0;
             const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
-            for (int j = 0; j < size; ++j) {  // branch-free 64-step recurrence
+            // recurrence driven by the KEPT boxes only: the lowest undecided candidate is kept, and knocks its diagonal
+            // word out of the candidate set -- one step per kept box (typically ~10 per chunk) instead of 64
+            // `removed` is the same in every lane (one LDS word): make that explicit so the loop runs on the scalar unit
+            const uint64_t removed_u = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(removed >> 32)) << 32) |
+                                       (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)removed);
+            uint64_t cand = ~removed_u;
+            if (size < 64) cand &= (1ULL << size) - 1ULL;
+            while (cand) {
+                const int j = __ffsll((long long)cand) - 1;
                 const uint64_t d = ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)dhi, j) << 32) |
                                    (uint64_t)(unsigned)__builtin_amdgcn_readlane((int)dlo, j);
-                const uint64_t alive = ((removed >> j) & 1ULL) ^ 1ULL;
-                kept |= alive << j;
-                removed |= d & (0ULL - alive);
+                kept |= 1ULL << j;
+                cand &= ~(d | (1ULL << j));
             }
             // truncate to max_keep (indices are emitted in ascending order)
             int nk = __popcll(kept);
@@ -253,53 +260,84 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_kernel(const long long total
     }
 }
 
-// Backward, gather form with the reference's summation order (roi, ph, pw
-// ascending) so the fp32 sums are bit-identical.  The integer RoI rectangles
-// are computed once per workgroup into LDS (R x 5 ints) instead of once per
-// (thread, roi) as the reference does.
-__global__ __launch_bounds__(256) void roi_pool_bwd_kernel(const int total, const float *__restrict__ top,
+// Backward, gather form with the reference's summation order (roi, ph, pw ascending) so the fp32 sums are
+// bit-identical.  One workgroup = one (image, channel, 4-row band) of the feature map: it first compacts, in RoI order,
+// the RoIs of that image whose integer rectangle touches the band (ballot + prefix count, order preserving) into LDS,
+// then every thread walks only that short list.  The reference tests all R RoIs for every one of the B*C*H*W
+// elements; here the band filter removes ~80-90 % of them before the per-element loop.
+constexpr int kBandRows = 4;
+
+__global__ __launch_bounds__(256) void roi_pool_bwd_kernel(const float *__restrict__ top,
                                                            const int32_t *__restrict__ argmax, const int R,
                                                            const float scale, const int C, const int H, const int W,
                                                            const int PH, const int PW, float *__restrict__ bottom,
                                                            const float *__restrict__ rois) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    int *rect = reinterpret_cast<int *>(smem_raw);  // [R][5]
-    for (int r = threadIdx.x; r < R; r += blockDim.x) {
-        RoiRect q = roi_rect(rois + (size_t)r * 5, scale);
-        rect[r * 5 + 0] = q.b; rect[r * 5 + 1] = q.sw; rect[r * 5 + 2] = q.sh; rect[r * 5 + 3] = q.ew; rect[r * 5 + 4] = q.eh;
+    int *rect = reinterpret_cast<int *>(smem_raw);   // [count][5]: roi index, sw, sh, ew, eh (only RoIs touching the band)
+    __shared__ int s_count;
+    __shared__ int s_wave_cnt[4];
+    const int bands = (H + kBandRows - 1) / kBandRows;
+    const int band = blockIdx.x % bands;
+    const int c = (blockIdx.x / bands) % C;
+    const int n = blockIdx.x / bands / C;
+    const int h0 = band * kBandRows, h1 = min(H, h0 + kBandRows) - 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    int count = 0;
+    for (int r0 = 0; r0 < R; r0 += 256) {
+        const int r = r0 + tid;
+        bool hit = false;
+        RoiRect q;
+        q.b = q.sw = q.sh = q.ew = q.eh = 0;
+        if (r < R) {
+            q = roi_rect(rois + (size_t)r * 5, scale);
+            hit = q.b == n && q.sh <= h1 && q.eh >= h0 && q.sw <= W - 1 && q.ew >= 0;
+        }
+        const unsigned long long bal = __ballot(hit);
+        if (lane == 0) s_wave_cnt[wave] = __popcll(bal);
+        __syncthreads();
+        int before = count;
+        for (int w2 = 0; w2 < wave; ++w2) before += s_wave_cnt[w2];
+        if (hit) {
+            const int pos = before + __popcll(bal & ((1ULL << lane) - 1ULL));
+            rect[pos * 5 + 0] = r; rect[pos * 5 + 1] = q.sw; rect[pos * 5 + 2] = q.sh; rect[pos * 5 + 3] = q.ew; rect[pos * 5 + 4] = q.eh;
+        }
+        count += s_wave_cnt[0] + s_wave_cnt[1] + s_wave_cnt[2] + s_wave_cnt[3];
+        __syncthreads();
     }
+    if (tid == 0) s_count = count;
     __syncthreads();
-    const int index = blockIdx.x * blockDim.x + threadIdx.x;
-    if (index >= total) return;
-    const int w = index % W;
-    const int h = (index / W) % H;
-    const int c = (index / W / H) % C;
-    const int n = index / W / H / C;
-    float g = 0.f;
+    count = s_count;
+
     const int bins = PH * PW;
-    for (int r = 0; r < R; ++r) {
-        const int *q = rect + r * 5;  // uniform address: LDS broadcast
-        if (q[0] != n) continue;
-        const int sw = q[1], sh = q[2], ew = q[3], eh = q[4];
-        if (!(w >= sw && w <= ew && h >= sh && h <= eh)) continue;
-        const int roi_w = (int)fmaxf((float)(ew - sw + 1), 1.f);
-        const int roi_h = (int)fmaxf((float)(eh - sh + 1), 1.f);
-        const float bin_h = __fdiv_rn((float)roi_h, (float)PH);
-        const float bin_w = __fdiv_rn((float)roi_w, (float)PW);
-        int phs = (int)floorf(__fdiv_rn((float)(h - sh), bin_h));
-        int phe = (int)ceilf(__fdiv_rn((float)(h - sh + 1), bin_h));
-        int pws = (int)floorf(__fdiv_rn((float)(w - sw), bin_w));
-        int pwe = (int)ceilf(__fdiv_rn((float)(w - sw + 1), bin_w));
-        phs = min(max(phs, 0), PH); phe = min(max(phe, 0), PH);
-        pws = min(max(pws, 0), PW); pwe = min(max(pwe, 0), PW);
-        const size_t off = ((size_t)r * C + c) * bins;
-        for (int ph = phs; ph < phe; ++ph)
-            for (int pw = pws; pw < pwe; ++pw) {
-                const size_t o = off + ph * PW + pw;
-                if (argmax[o] == index) g += top[o];
-            }
+    for (int e = tid; e < kBandRows * W; e += 256) {
+        const int h = h0 + e / W, w = e % W;
+        if (h >= H) continue;
+        const int index = ((n * C + c) * H + h) * W + w;
+        float g = 0.f;
+        for (int i = 0; i < count; ++i) {
+            const int *q = rect + i * 5;  // uniform address: LDS broadcast
+            const int sw = q[1], sh = q[2], ew = q[3], eh = q[4];
+            if (!(w >= sw && w <= ew && h >= sh && h <= eh)) continue;
+            const int roi_w = (int)fmaxf((float)(ew - sw + 1), 1.f);
+            const int roi_h = (int)fmaxf((float)(eh - sh + 1), 1.f);
+            const float bin_h = __fdiv_rn((float)roi_h, (float)PH);
+            const float bin_w = __fdiv_rn((float)roi_w, (float)PW);
+            int phs = (int)floorf(__fdiv_rn((float)(h - sh), bin_h));
+            int phe = (int)ceilf(__fdiv_rn((float)(h - sh + 1), bin_h));
+            int pws = (int)floorf(__fdiv_rn((float)(w - sw), bin_w));
+            int pwe = (int)ceilf(__fdiv_rn((float)(w - sw + 1), bin_w));
+            phs = min(max(phs, 0), PH); phe = min(max(phe, 0), PH);
+            pws = min(max(pws, 0), PW); pwe = min(max(pwe, 0), PW);
+            const size_t off = ((size_t)q[0] * C + c) * bins;
+            for (int ph = phs; ph < phe; ++ph)
+                for (int pw = pws; pw < pwe; ++pw) {
+                    const size_t o = off + ph * PW + pw;
+                    if (argmax[o] == index) g += top[o];
+                }
+        }
+        bottom[index] = g;
     }
-    bottom[index] = g;
 }
 
 // ---------------------------------------------------------------------------
@@ -634,8 +672,9 @@ SCDA_API int scda_roi_pool_bwd_hip(const float *top_grad, const int32_t *argmax,
     if (!top_grad || !argmax || !rois) { set_error("scda_roi_pool_bwd_hip: null pointer"); return SCDA_EINVAL; }
     const size_t lds = (size_t)R * 5 * sizeof(int);
     if (lds > 96 * 1024) { set_error("scda_roi_pool_bwd_hip: R=%d too large", R); return SCDA_EINVAL; }
-    hipLaunchKernelGGL(roi_pool_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), lds, as_stream(stream), (int)total,
-                       top_grad, argmax, R, spatial_scale, C, H, W, PH, PW, bottom_grad, rois);
+    const int bands = (H + kBandRows - 1) / kBandRows;
+    hipLaunchKernelGGL(roi_pool_bwd_kernel, dim3((unsigned)((long long)B * C * bands)), dim3(256), lds, as_stream(stream), top_grad,
+                       argmax, R, spatial_scale, C, H, W, PH, PW, bottom_grad, rois);
     return launch_status("roi_pool_bwd_kernel");
 }
 
