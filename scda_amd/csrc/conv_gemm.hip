@@ -50,6 +50,7 @@ struct Epi {
     int act;
     float slope;
     int splits;
+    int accumulate;      // splits == 1 only: out += result (one writer per element)
 };
 
 // ---------------------------------------------------------------------------
@@ -485,7 +486,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float *__restrict__ A, 
                 } else {
                     if (e.bias) v += e.bias_on_n ? e.bias[n] : e.bias[m];
                     v = apply_act(v, e.act, e.slope);
-                    e.out[(size_t)m * g.ldc + n] = v;
+                    float *dst = e.out + (size_t)m * g.ldc + n;
+                    *dst = e.accumulate ? *dst + v : v;
                 }
             }
     }
@@ -654,7 +656,7 @@ SCDA_API int scda_conv2d_fwd_hip(const float *x, const float *w, const float *bi
     g.a_vec4 = (g.K % 4) == 0 && (((uintptr_t)w) & 15) == 0;
     g.zp = zero_page();
     g.b_vec4 = S == 1 && g.slab_aligned && (OW % 4) == 0 && (g.N % 4) == 0 && !getenv("SCDA_CONV_NO_BVEC");
-    Epi e{y, nullptr, bias, 0, act, slope, 1};
+    Epi e{y, nullptr, bias, 0, act, slope, 1, 0};
     CONV_DISPATCH(launch_conv, , false > (w, x, g, e, (float *)ws, ws_bytes, as_stream(stream)))
 }
 
@@ -671,7 +673,7 @@ SCDA_API int scda_conv2d_dgrad_hip(const float *dy, const float *wt, float *dx, 
     g.a_vec4 = (g.K % 4) == 0 && (((uintptr_t)wt) & 15) == 0;
     g.zp = zero_page();
     g.b_vec4 = S == 1 && g.slab_aligned && (IW % 4) == 0 && (g.N % 4) == 0 && !getenv("SCDA_CONV_NO_BVEC");
-    Epi e{dx, nullptr, nullptr, 0, (int)ACT_NONE, 0.f, 1};
+    Epi e{dx, nullptr, nullptr, 0, (int)ACT_NONE, 0.f, 1, 0};
     CONV_DISPATCH(launch_conv, , true > (wt, dy, g, e, (float *)ws, ws_bytes, as_stream(stream)))
 }
 
@@ -713,14 +715,12 @@ SCDA_API int scda_gemm_hip(const float *A, const float *B, float *C, int M, int 
     const int BMv = (M <= 64) ? 64 : 128, BNv = (N <= 64) ? 64 : 128;
     const long long tiles = (long long)cdiv(M, BMv) * cdiv(N, BNv);
     int splits = pick_splits(tiles, K);
-    if (accumulate && splits == 1 && ws) splits = 2 <= K / BK ? 2 : 1;
     while (splits > 1 && (size_t)splits * M * N * sizeof(float) > ws_bytes) --splits;
-    if (accumulate && splits == 1) { set_error("scda_gemm_hip: accumulate needs a workspace"); return SCDA_EINVAL; }
     if (splits > 1 && ldc != N) { set_error("scda_gemm_hip: split-K needs ldc == N"); return SCDA_EINVAL; }
     GemmGeom g{M, N, K, lda, ldb, ldc, round_k_per_split(K, splits), zero_page()};
     if (!g.zp) { set_error("scda_gemm_hip: could not allocate the zero page"); return SCDA_ELAUNCH; }
     splits = cdiv(K, g.k_per_split);
-    Epi e{C, (float *)ws, bias, bias_on_n, act, slope, splits};
+    Epi e{C, (float *)ws, bias, bias_on_n, act, slope, splits, accumulate};
     dim3 grid(cdiv(N, BNv), cdiv(M, BMv), splits);
 #define GEMM_LAUNCH(BM_, BN_)                                                                            \
     do {                                                                                                 \

@@ -111,11 +111,11 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const int n, const float t
     }
 }
 
-// Greedy sweep on the device: one 256-thread workgroup walks the 64-box chunks.
+// Greedy sweep on the device: one 1024-thread workgroup walks the 64-box chunks.
 // Per chunk, wave 0 resolves the 64 in-chunk decisions from the diagonal word
 // (a scalar recurrence over v_readlane, one step per kept box), then all waves OR the kept
 // boxes' mask rows into the LDS-resident "removed" bit vector.
-__global__ __launch_bounds__(256) void nms_sweep_kernel(const uint64_t *__restrict__ mask, const int n,
+__global__ __launch_bounds__(1024) void nms_sweep_kernel(const uint64_t *__restrict__ mask, const int n,
                                                         const int col_blocks, int64_t *__restrict__ keep,
                                                         int64_t *__restrict__ num_out, const int max_keep) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void nms_sweep_kernel(const uint64_t *__restri
     uint64_t *bcast = remv + col_blocks;                       // [2]: kept mask, stop flag
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    for (int i = tid; i < col_blocks; i += 256) remv[i] = 0;
+    for (int i = tid; i < col_blocks; i += 1024) remv[i] = 0;
     if (tid == 0) { bcast[0] = 0; bcast[1] = 0; }
     __syncthreads();
 
@@ -182,21 +182,31 @@ __global__ __launch_bounds__(256) void nms_sweep_kernel(const uint64_t *__restri
         const bool stop = bcast[1] != 0;
         count += __popcll(kept);
         if (stop) break;
-        // OR the kept rows into remv for the columns still ahead
-        for (int cb = b + 1 + tid; cb < col_blocks; cb += 256) {
-            uint64_t acc = remv[cb];
-            uint64_t k = kept;
-            while (k) {
-                // up to 4 independent row loads in flight per step
-                uint64_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;
-                int j0 = __ffsll((long long)k) - 1; k &= k - 1;
-                v0 = mask[(size_t)(base + j0) * col_blocks + cb];
-                if (k) { int j = __ffsll((long long)k) - 1; k &= k - 1; v1 = mask[(size_t)(base + j) * col_blocks + cb]; }
-                if (k) { int j = __ffsll((long long)k) - 1; k &= k - 1; v2 = mask[(size_t)(base + j) * col_blocks + cb]; }
-                if (k) { int j = __ffsll((long long)k) - 1; k &= k - 1; v3 = mask[(size_t)(base + j) * col_blocks + cb]; }
-                acc |= v0 | v1 | v2 | v3;
+        // OR the kept rows into remv for the columns still ahead.  16 waves: thread group g = tid/256 takes every 4th
+        // kept row, 8 independent row loads in flight per thread, groups merge through LDS atomics (ds_or_b64).
+        {
+            const int grp = tid >> 8, t = tid & 255;
+            for (int cb = b + 1 + t; cb < col_blocks; cb += 256) {
+                uint64_t acc = 0, k = kept;
+                int rank = 0;
+                uint64_t mine = 0;   // the kept bits this group owns
+                while (k) { const uint64_t low = k & (~k + 1); if ((rank & 3) == grp) mine |= low; k ^= low; ++rank; }
+                while (mine) {
+                    uint64_t v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        v[u] = 0;
+                        if (mine) {
+                            const int j = __ffsll((long long)mine) - 1;
+                            mine &= mine - 1;
+                            v[u] = mask[(size_t)(base + j) * col_blocks + cb];
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc |= v[u];
+                }
+                if (acc) atomicOr(reinterpret_cast<unsigned long long *>(&remv[cb]), (unsigned long long)acc);
             }
-            remv[cb] = acc;
         }
         __syncthreads();
     }
@@ -641,7 +651,7 @@ SCDA_API int scda_nms_hip(const float *boxes, int n, float thresh, void *mask_ws
     if (st) return st;
     const size_t lds = (size_t)(cb + 2) * sizeof(uint64_t);
     if (lds > 64 * 1024) { set_error("scda_nms_hip: n=%d too large for the LDS-resident sweep", n); return SCDA_EINVAL; }
-    hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(256), lds, as_stream(stream), (const uint64_t *)mask_ws, n, cb,
+    hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(1024), lds, as_stream(stream), (const uint64_t *)mask_ws, n, cb,
                        keep, num_out, max_keep);
     return launch_status("nms_sweep_kernel");
 }
