@@ -10,21 +10,38 @@ import torch
 from scda_amd import native
 
 _impl = {}
+_aux = {}
+
+
+def _aux_stream(dev):
+    """High-priority stream for the box logic's small host->device->host round trips (IoU matrices, NMS).  Their
+    inputs come from host memory, so they depend on nothing that is queued on the compute stream; issuing them there
+    would make the host wait behind whatever the GPU is still working through (e.g. the two backbone passes)."""
+    s = _aux.get(dev.index)
+    if s is None:
+        s = _aux[dev.index] = torch.cuda.Stream(device=dev, priority=-1)
+    return s
 
 
 def _hip_bbox_overlaps(boxes, query):
     dev = torch.device("cuda", torch.cuda.current_device())
-    b = torch.from_numpy(np.ascontiguousarray(boxes[:, :4], dtype=np.float32)).to(dev)
-    q = torch.from_numpy(np.ascontiguousarray(query[:, :4], dtype=np.float32)).to(dev)
-    return native.bbox_overlaps(b, q).cpu().numpy()
+    with torch.cuda.stream(_aux_stream(dev)):
+        b = torch.from_numpy(np.ascontiguousarray(boxes[:, :4], dtype=np.float32)).to(dev)
+        q = torch.from_numpy(np.ascontiguousarray(query[:, :4], dtype=np.float32)).to(dev)
+        return native.bbox_overlaps(b, q).cpu().numpy()
 
 
 def _hip_nms(dets, thresh, max_keep=0):
     """dets: float tensor [N,5] sorted by score (any device) -> CPU LongTensor of kept indices."""
     dev = torch.device("cuda", torch.cuda.current_device())
-    d = dets.to(dev, torch.float32).contiguous()
-    keep, num = native.nms(d, float(thresh), max_keep)
-    return keep[: int(num.item())].cpu().contiguous()
+    if dets.is_cuda:   # device-resident input: stay on the caller's stream (it may still be producing `dets`)
+        d = dets.to(torch.float32).contiguous()
+        keep, num = native.nms(d, float(thresh), max_keep)
+        return keep[: int(num.item())].cpu().contiguous()
+    with torch.cuda.stream(_aux_stream(dev)):
+        d = dets.to(dev, torch.float32).contiguous()
+        keep, num = native.nms(d, float(thresh), max_keep)
+        return keep[: int(num.item())].cpu().contiguous()
 
 
 def use(bbox_overlaps=None, nms=None):

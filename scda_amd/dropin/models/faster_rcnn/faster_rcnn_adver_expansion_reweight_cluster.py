@@ -39,6 +39,22 @@ def accuracy(output, target, topk=(1,), ignore_index=-1):
     return [N.accuracy(output.detach().contiguous(), target.contiguous(), ignore_index)]
 
 
+class _HostCopy:
+    """asynchronous device->pinned-host copy of the RPN outputs, issued right behind the kernels that produce them so
+    that the host can pick them up as soon as THAT image's RPN is done (not when everything queued later is)"""
+
+    def __init__(self, *tensors):
+        self.host = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in tensors]
+        for h, t in zip(self.host, tensors):
+            h.copy_(t, non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record()
+
+    def get(self):
+        self.event.synchronize()
+        return self.host
+
+
 def _objectness(rpn_pred_cls):
     """soft-max over (bg, fg) per anchor, returned in the conv layout [B, 2A, h, w]"""
     nhwc = rpn_pred_cls.detach().permute(0, 2, 3, 1).contiguous()
@@ -107,6 +123,7 @@ class FasterRCNN_AdEx(nn.Module):
 
         feat = self.feature_extractor(image)
         rpn_cls, rpn_loc = self.rpn(feat)
+        src_host = _HostCopy(_objectness(rpn_cls), rpn_loc.detach()) if self.training else None
 
         if not self.training:
             proposals = fn['rpn_proposal_fn'](_objectness(rpn_cls), rpn_loc.detach())
@@ -123,7 +140,7 @@ class FasterRCNN_AdEx(nn.Module):
         with torch.no_grad():
             feat_t = self.feature_extractor(target)
             rpn_cls_t, rpn_loc_t = self.rpn(feat_t)
-            obj_t = _objectness(rpn_cls_t)
+            tgt_host = _HostCopy(_objectness(rpn_cls_t), rpn_loc_t)
         ev_backbones = torch.cuda.Event()
         ev_backbones.record()
         mark('backbones_enqueued')
@@ -131,7 +148,7 @@ class FasterRCNN_AdEx(nn.Module):
         # ---- source image: RPN loss, proposals, sampled RoIs, RCNN, cluster regions
         rpn_loss_cls, rpn_loss_loc, rpn_acc = self._add_rpn_loss(fn['anchor_target_fn'], rpn_cls, rpn_loc)
         mark('anchor_targets+rpn_loss')
-        proposals = fn['rpn_proposal_fn'](_objectness(rpn_cls), rpn_loc.detach())
+        proposals = fn['rpn_proposal_fn'](*src_host.get())
         mark('src_proposals')
         rois, cls_targets, loc_targets, loc_weights = fn['proposal_target_fn'](proposals)
         mark('src_proposal_targets')
@@ -158,7 +175,7 @@ class FasterRCNN_AdEx(nn.Module):
         # ---- target image: same RPN / RCNN, no labels, nothing is differentiated through it
         def target_branch():
             with torch.no_grad():
-                proposals_t = fn['rpn_proposal_fn'](obj_t, rpn_loc_t)
+                proposals_t = fn['rpn_proposal_fn'](*tgt_host.get())
                 rois_t = proposals_t[0:512, :5].to(dev).contiguous()
                 assert rois_t.shape[1] == 5
                 x_fea_t, _, _ = self.rcnn(feat_t, rois_t)
