@@ -23,12 +23,25 @@ def _aux_stream(dev):
     return s
 
 
+def _pinned(a):
+    t = torch.from_numpy(a)
+    p = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    p.copy_(t)
+    return p
+
+
 def _hip_bbox_overlaps(boxes, query):
     dev = torch.device("cuda", torch.cuda.current_device())
-    with torch.cuda.stream(_aux_stream(dev)):
-        b = torch.from_numpy(np.ascontiguousarray(boxes[:, :4], dtype=np.float32)).to(dev)
-        q = torch.from_numpy(np.ascontiguousarray(query[:, :4], dtype=np.float32)).to(dev)
-        return native.bbox_overlaps(b, q).cpu().numpy()
+    aux = _aux_stream(dev)
+    with torch.cuda.stream(aux):
+        # pinned staging + async copies: a pageable hipMemcpy serialises with the compute stream
+        b = _pinned(np.ascontiguousarray(boxes[:, :4], dtype=np.float32)).to(dev, non_blocking=True)
+        q = _pinned(np.ascontiguousarray(query[:, :4], dtype=np.float32)).to(dev, non_blocking=True)
+        out = native.bbox_overlaps(b, q)
+        host = torch.empty(out.shape, dtype=torch.float32, pin_memory=True)
+        host.copy_(out, non_blocking=True)
+        aux.synchronize()
+    return host.numpy().copy()
 
 
 def _hip_nms(dets, thresh, max_keep=0):
@@ -38,10 +51,16 @@ def _hip_nms(dets, thresh, max_keep=0):
         d = dets.to(torch.float32).contiguous()
         keep, num = native.nms(d, float(thresh), max_keep)
         return keep[: int(num.item())].cpu().contiguous()
-    with torch.cuda.stream(_aux_stream(dev)):
-        d = dets.to(dev, torch.float32).contiguous()
+    aux = _aux_stream(dev)
+    with torch.cuda.stream(aux):
+        d = _pinned(np.ascontiguousarray(dets.numpy(), dtype=np.float32)).to(dev, non_blocking=True)
         keep, num = native.nms(d, float(thresh), max_keep)
-        return keep[: int(num.item())].cpu().contiguous()
+        n = dets.shape[0]
+        host = torch.empty(n + 1, dtype=torch.int64, pin_memory=True)   # [keep..., num] in one transfer
+        host[:n].copy_(keep[:n], non_blocking=True)
+        host[n:].copy_(num, non_blocking=True)
+        aux.synchronize()
+    return host[: int(host[n])].clone()
 
 
 def use(bbox_overlaps=None, nms=None):
