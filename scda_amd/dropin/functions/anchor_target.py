@@ -32,8 +32,8 @@ def compute_anchor_targets(feature_size, cfg, ground_truth_bboxes, image_info, i
 
     iou = np.stack([bbox_helper.bbox_iou_overlaps(anchors, gts[b]) for b in range(B)], axis=0)  # [B,KA,G]
     best_gt = iou.argmax(axis=2)
-    best_iou = iou.max(axis=2)
-    per_gt_best = iou.max(axis=1)  # [B,G]
+    best_iou = np.take_along_axis(iou, best_gt[:, :, None], axis=2)[:, :, 0]   # == iou.max(axis=2), one pass less
+    per_gt_best = np.stack([iou[b].max(axis=0) for b in range(B)], axis=0)      # [B,G] (contiguous column reduce)
     per_gt_best[per_gt_best < 0.1] = -1  # a gt nobody overlaps by >= 0.1 claims no anchor
     gb, gka, gg = np.where(iou == per_gt_best[:, None, :])
     best_gt[gb, gka] = gg

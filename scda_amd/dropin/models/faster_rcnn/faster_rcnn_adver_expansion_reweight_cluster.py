@@ -155,20 +155,21 @@ class FasterRCNN_AdEx(nn.Module):
         assert rois.shape[1] == 5
         x_fea, rcnn_cls, rcnn_loc = self.rcnn(feat, rois)
         mark('src_rcnn_enqueued')
-        clu_fea, clu_ctr = compute_cluster_targets(rois, x_fea, N_cluster=input['cluster_num'], threshold=input['threshold'])
         rcnn_loss_cls, rcnn_loss_loc, rcnn_acc = self._add_rcnn_loss(rcnn_cls, rcnn_loc, cls_targets, loc_targets, loc_weights)
         losses = [rpn_loss_cls, rpn_loss_loc, rcnn_loss_cls, rcnn_loss_loc]
-        mark('src_cluster+rcnn_loss')
 
         # Optional scheduling hooks of this repository's own training step (absent when the reference's driver calls us):
         #  '_after_source_losses': called as soon as the four detector losses exist -- the step uses it to enqueue the
         #      detector backward (≈40 % of the iteration's device time) so that it runs underneath the host-side work below
-        #  '_side_stream': HIP stream for the target branch; its small sync-bound pieces (D2H of RPN outputs, NMS, RoI
-        #      sampling, FC head, k-means gather) then never queue behind that backward.
+        #      (k-means of the source RoIs, the whole target branch)
+        #  '_side_stream': HIP stream for the target branch; its small sync-bound pieces (NMS, RoI sampling, FC head,
+        #      k-means gather) then never queue behind that backward.
         hook = input.get('_after_source_losses')
         if hook is not None:
             hook(losses)
             mark('det_backward_enqueued')
+        clu_fea, clu_ctr = compute_cluster_targets(rois, x_fea, N_cluster=input['cluster_num'], threshold=input['threshold'])
+        mark('src_cluster')
         side = input.get('_side_stream')
         main = torch.cuda.current_stream(dev) if side is not None else None
 

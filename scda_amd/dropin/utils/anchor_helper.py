@@ -34,8 +34,24 @@ def get_anchors_over_grid(ratios, scales, stride):
     return generate_anchors(stride=stride, sizes=np.array(scales) * stride)
 
 
+_PLANE_CACHE = {}
+
+
 def get_anchors_over_plane(featmap_h, featmap_w, anchor_ratios, anchor_scales, anchor_stride):
-    """[K*A, 4] float64; row k*A + a is anchor a shifted to cell k = y*featmap_w + x."""
+    """[K*A, 4] float64; row k*A + a is anchor a shifted to cell k = y*featmap_w + x.
+    (The grid depends only on its arguments; it is built once per shape and handed out as a read-only array --
+    the reference rebuilds it three times per iteration.)"""
+    key = (featmap_h, featmap_w, tuple(anchor_scales), anchor_stride)
+    hit = _PLANE_CACHE.get(key)
+    if hit is not None:
+        return hit
+    out = _anchors_over_plane(featmap_h, featmap_w, anchor_ratios, anchor_scales, anchor_stride)
+    out.setflags(write=False)
+    _PLANE_CACHE[key] = out
+    return out
+
+
+def _anchors_over_plane(featmap_h, featmap_w, anchor_ratios, anchor_scales, anchor_stride):
     cell = get_anchors_over_grid(anchor_ratios, anchor_scales, anchor_stride)
     sx, sy = np.meshgrid(np.arange(featmap_w) * anchor_stride, np.arange(featmap_h) * anchor_stride)
     shifts = np.stack([sx.ravel(), sy.ravel(), sx.ravel(), sy.ravel()], axis=1)
