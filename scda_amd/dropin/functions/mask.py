@@ -13,6 +13,9 @@ import torch
 def _np(x):
     if x is None:
         return None
+    host = getattr(x, "_scda_host", None)   # device tensors built from host data carry their host original along:
+    if host is not None:                    # no device->host copy (which would queue behind everything in flight)
+        return host
     return x.detach().cpu().numpy() if torch.is_tensor(x) else x
 
 

@@ -103,4 +103,7 @@ def compute_proposal_targets(proposals, cfg, ground_truth_bboxes, image_info, ig
         x = torch.from_numpy(a)
         return (x.float() if kind == 'f' else x.long()).to(dev).contiguous()
 
-    return dev_t(np.vstack(acc_rois), 'f'), dev_t(all_labels, 'l'), dev_t(np.vstack(acc_t), 'f'), dev_t(np.vstack(acc_w), 'f')
+    rois_np = np.vstack(acc_rois).astype(np.float32)
+    rois_dev = dev_t(rois_np, 'f')
+    rois_dev._scda_host = rois_np   # lets the cluster-region generator read the RoIs without a device->host copy
+    return rois_dev, dev_t(all_labels, 'l'), dev_t(np.vstack(acc_t), 'f'), dev_t(np.vstack(acc_w), 'f')

@@ -177,7 +177,9 @@ class FasterRCNN_AdEx(nn.Module):
         def target_branch():
             with torch.no_grad():
                 proposals_t = fn['rpn_proposal_fn'](*tgt_host.get())
-                rois_t = proposals_t[0:512, :5].to(dev).contiguous()
+                rois_t_host = proposals_t[0:512, :5].contiguous()
+                rois_t = rois_t_host.to(dev).contiguous()
+                rois_t._scda_host = rois_t_host.numpy()
                 assert rois_t.shape[1] == 5
                 x_fea_t, _, _ = self.rcnn(feat_t, rois_t)
                 return (x_fea_t,) + compute_cluster_targets(rois_t, x_fea_t, N_cluster=input['cluster_num'],
