@@ -17,6 +17,9 @@ def _np(x):
 
 def _to_dev(a, like):
     t = torch.from_numpy(a)
+    if torch.is_tensor(like) and like.is_cuda:
+        from scda_amd import native
+        return native.upload(t, like.device)
     return t.to(like.device) if torch.is_tensor(like) else t
 
 

@@ -69,7 +69,11 @@ def cluster_indices(proposals_np, N_cluster=4, threshold=128):
 def compute_cluster_targets(proposals, features, N_cluster=4, threshold=128):
     """proposals [N,>=5], features [N,F] -> (cluster features [N_cluster, threshold, F] (leaf), centres [N_cluster,2])"""
     idx, centres = cluster_indices(_np(proposals), N_cluster, threshold)
-    flat = torch.from_numpy(idx.reshape(-1)).to(features.device)
+    if features.is_cuda:
+        from scda_amd import native
+        flat = native.upload(idx.reshape(-1), features.device)
+    else:
+        flat = torch.from_numpy(idx.reshape(-1))
     with torch.no_grad():
         gathered = features.detach().index_select(0, flat).view(N_cluster, threshold, features.shape[1]).contiguous()
     return gathered.float(), centres

@@ -101,7 +101,11 @@ def compute_proposal_targets(proposals, cfg, ground_truth_bboxes, image_info, ig
 
     def dev_t(a, kind):
         x = torch.from_numpy(a)
-        return (x.float() if kind == 'f' else x.long()).to(dev).contiguous()
+        x = x.float() if kind == 'f' else x.long()
+        if dev.type == 'cuda':
+            from scda_amd import native
+            return native.upload(x, dev)
+        return x.to(dev).contiguous()
 
     rois_np = np.vstack(acc_rois).astype(np.float32)
     rois_dev = dev_t(rois_np, 'f')

@@ -178,7 +178,7 @@ class FasterRCNN_AdEx(nn.Module):
             with torch.no_grad():
                 proposals_t = fn['rpn_proposal_fn'](*tgt_host.get())
                 rois_t_host = proposals_t[0:512, :5].contiguous()
-                rois_t = rois_t_host.to(dev).contiguous()
+                rois_t = N.upload(rois_t_host, dev)
                 rois_t._scda_host = rois_t_host.numpy()
                 assert rois_t.shape[1] == 5
                 x_fea_t, _, _ = self.rcnn(feat_t, rois_t)

@@ -619,3 +619,16 @@ def prof_collect():
     _check(L.scda_prof_collect(launches, ms, fl), "scda_prof_collect")
     return {L.scda_prof_kernel_name(i32(k)).decode(): (int(launches[k]), float(ms[k]), float(fl[k]))
             for k in range(n) if launches[k] > 0}
+
+
+# ------------------------------------------------------- host -> device ------
+def upload(array_or_tensor, device, dtype=None):
+    """numpy array / CPU tensor -> device tensor through a pinned staging buffer with a non-blocking copy.
+    (`tensor.to(device)` from pageable memory is a synchronous, stream-ordered hipMemcpy: the host would sit behind
+    every kernel already queued on the stream.)"""
+    t = array_or_tensor if isinstance(array_or_tensor, torch.Tensor) else torch.from_numpy(array_or_tensor)
+    if dtype is not None and t.dtype != dtype:
+        t = t.to(dtype)
+    pin = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    pin.copy_(t)
+    return pin.to(device, non_blocking=True)

@@ -67,13 +67,13 @@ def builder_gan(cluster_num=4, threshold=128, recon_size=256, neww=64, newh=64):
 def _soft(flag, shape, device):
     """generate_soft_label: U(0.8,1) for 1, U(0,0.3) for 0, drawn from numpy's global RNG (:440-448)"""
     lo, hi = (0.8, 1.0) if flag == 1 else (0.0, 0.3)
-    return torch.from_numpy(np.random.uniform(lo, hi, size=tuple(shape))).float().to(device)
+    return N.upload(np.random.uniform(lo, hi, size=tuple(shape)), device, torch.float32)
 
 
 def _hard(flag, shape, device):
     """generate_hard_label: constant, but still one numpy draw per element (:450-458)"""
     v = 1.0 if flag == 1 else 0.0
-    return torch.from_numpy(np.random.uniform(v, v, size=tuple(shape))).float().to(device)
+    return N.upload(np.random.uniform(v, v, size=tuple(shape)), device, torch.float32)
 
 
 def _crops(img, corners, recon):
