@@ -246,10 +246,7 @@ struct WgradGeom {
     Div dOHW, dOW;
 };
 
-// ROWAL = output row length % 16 == 0 (every VGG / decoder / discriminator layer): a 16-pixel K-slab then lies inside ONE
-// output row of ONE image, so (image, row, first column) are decoded once per slab from the wave-uniform k0 on the scalar
-// unit and each lane only adds its column; the generic path decodes per lane with two integer divisions per K-step.
-template <int BM, int BN, int KH, int KW, int S, bool ROWAL>
+template <int BM, int BN, int KH, int KW, int S>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict__ dY, const float *__restrict__ X,
                                                          const WgradGeom g, float *__restrict__ ws) {
     using T = TileCfg<BM, BN>;
@@ -284,46 +281,30 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
 
     float ar[T::A_ELEMS], br[T::B_ELEMS];
     auto gload = [&](int k0) {
-        int img, pix, oy, ox;
-        bool k_ok;
-        if (ROWAL) {
-            int pix0, ox0;
-            g.dOHW.divmod(k0, img, pix0);      // k0 is wave-uniform: scalar unit
-            g.dOW.divmod(pix0, oy, ox0);
-            pix = pix0 + kl;
-            ox = ox0 + kl;
-            k_ok = k0 < k_end;                 // k_end is a multiple of 16 here
-        } else {
-            const int k = k0 + kl;
-            k_ok = k < k_end;
-            g.dOHW.divmod(k_ok ? k : 0, img, pix);
-            g.dOW.divmod(pix, oy, ox);
-        }
-        const float *dy_img = dY + (size_t)img * g.Cout * ohw;
         if (g.a_vec4) {
-            int pa_pix;
-            bool a_ok;
-            if (ROWAL) { pa_pix = pix - kl + 4 * qa; a_ok = k_ok; }
-            else {
-                const int k = k0 + 4 * qa;
-                a_ok = k < k_end;
-                int aimg;
-                g.dOHW.divmod(a_ok ? k : 0, aimg, pa_pix);
-                dy_img = dY + (size_t)aimg * g.Cout * ohw;
-            }
+            const int k = k0 + 4 * qa;
+            int img, pix;
+            g.dOHW.divmod(k < k_end ? k : 0, img, pix);
+            const float *dyb = dY + (size_t)img * g.Cout * ohw + pix;
 #pragma unroll
             for (int j = 0; j < T::A_ELEMS / 4; ++j) {
                 const int m = m0 + rva + 64 * j;
-                const float *pa = (a_ok && m < g.M) ? dy_img + (size_t)m * ohw + pa_pix : g.zp;
+                const float *pa = (k < k_end && m < g.M) ? dyb + (size_t)m * ohw : g.zp;
                 const float4 v = *reinterpret_cast<const float4 *>(pa);
                 ar[4 * j + 0] = v.x; ar[4 * j + 1] = v.y; ar[4 * j + 2] = v.z; ar[4 * j + 3] = v.w;
             }
-            if (!ROWAL) dy_img = dY + (size_t)img * g.Cout * ohw;
-        } else {
+        }
+        const int k = k0 + kl;
+        const bool k_ok = k < k_end;
+        int img, pix, oy, ox;
+        g.dOHW.divmod(k_ok ? k : 0, img, pix);
+        g.dOW.divmod(pix, oy, ox);
+        if (!g.a_vec4) {
+            const float *dyb = dY + (size_t)img * g.Cout * ohw + pix;
 #pragma unroll
             for (int j = 0; j < T::A_ELEMS; ++j) {
                 const int m = m0 + rl + 16 * j;
-                const float *pa = (k_ok && m < g.M) ? dy_img + (size_t)m * ohw + pix : g.zp;
+                const float *pa = (k_ok && m < g.M) ? dyb + (size_t)m * ohw : g.zp;
                 ar[j] = *pa;
             }
         }
@@ -615,17 +596,14 @@ static int launch_wgrad(const float *dY, const float *X, WgradGeom g, float *dW,
     splits = cdiv(g.K, g.k_per_split);
     dim3 grid(cdiv(g.N, BNv), cdiv(g.M, BMv), splits);
     prof_begin(PK_CONV_WGRAD + prof_shape(KH, S), 2.0 * g.M * (double)g.N * g.K, st);
-    const bool rowal = (g.OW % BK) == 0 && (g.k_per_split % BK) == 0 && (g.K % BK) == 0;
-#define WGRAD_LAUNCH(BM_, BN_)                                                                                      \
-    do {                                                                                                            \
-        if (rowal) hipLaunchKernelGGL((conv_wgrad_kernel<BM_, BN_, KH, KW, S, true>), grid, dim3(256), 0, st, dY, X, g, ws);   \
-        else hipLaunchKernelGGL((conv_wgrad_kernel<BM_, BN_, KH, KW, S, false>), grid, dim3(256), 0, st, dY, X, g, ws);        \
-    } while (0)
-    if (small && BNv == 64) WGRAD_LAUNCH(64, 64);
-    else if (small) WGRAD_LAUNCH(64, 128);
-    else if (BNv == 64) WGRAD_LAUNCH(128, 64);
-    else WGRAD_LAUNCH(128, 128);
-#undef WGRAD_LAUNCH
+    if (small && BNv == 64)
+        hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, KH, KW, S>), grid, dim3(256), 0, st, dY, X, g, ws);
+    else if (small)
+        hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, KH, KW, S>), grid, dim3(256), 0, st, dY, X, g, ws);
+    else if (BNv == 64)
+        hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, KH, KW, S>), grid, dim3(256), 0, st, dY, X, g, ws);
+    else
+        hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, KH, KW, S>), grid, dim3(256), 0, st, dY, X, g, ws);
     prof_end(st);
     int rc = launch_status("conv_wgrad_kernel");
     if (rc) return rc;
