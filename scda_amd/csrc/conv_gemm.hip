@@ -246,13 +246,16 @@ struct WgradGeom {
     Div dOHW, dOW;
 };
 
-template <int BM, int BN, int KH, int KW, int S>
+// WBK = K-slab depth: 32 pixels = one full 128-byte line per gathered row (the K-contiguous operands of the weight
+// gradient are read as [row][16 px] = 64-byte pieces at WBK = 16, i.e. two L1 requests per line)
+template <int BM, int BN, int KH, int KW, int S, int WBK>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict__ dY, const float *__restrict__ X,
                                                          const WgradGeom g, float *__restrict__ ws) {
-    using T = TileCfg<BM, BN>;
+    using T = TileCfg<BM, BN, WBK>;
+    constexpr int RPP = 256 / WBK;   // rows staged per pass
     __shared__ __attribute__((aligned(16))) float lds[T::LDS_FLOATS];
-    auto As = [&](int b) -> float * { return lds + b * (BK * T::LDA); };
-    auto Bs = [&](int b) -> float * { return lds + 2 * BK * T::LDA + b * (BK * T::LDB); };
+    auto As = [&](int b) -> float * { return lds + b * (WBK * T::LDA); };
+    auto Bs = [&](int b) -> float * { return lds + 2 * WBK * T::LDA + b * (WBK * T::LDB); };
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -263,8 +266,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
     // both operands are contiguous along K (= output pixels): lanes along K
     //   A (dY rows = co): vec4 path lane -> (row = tid/4 [+64], 4 consecutive pixels); scalar path k = tid%16, rows tid/16+16j
     //   B (X gather, rows n = (ci,kh,kw)): k = tid%16, rows tid/16 + 16*j
-    const int kl = tid & 15, rl = tid >> 4;
-    const int qa = tid & 3, rva = tid >> 2;
+    const int kl = tid % WBK, rl = tid / WBK;
+    constexpr int QPR = WBK / 4;      // float4 pieces per row
+    const int qa = tid % QPR, rva = tid / QPR;
+    constexpr int RPV = 256 / QPR;    // rows per vec4 pass
     const int ohw = g.dOHW.d, ihw = g.IH * g.IW;
 
     // per-row constants of the B gather: n -> (ci,kh,kw):  signed offset of the tap inside the input plane, and the
@@ -272,7 +277,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
     int b_base[T::B_ELEMS], b_tap[T::B_ELEMS];
 #pragma unroll
     for (int j = 0; j < T::B_ELEMS; ++j) {
-        const int n = n0 + rl + 16 * j;
+        const int n = n0 + rl + RPP * j;
         const int c = n / (KH * KW), rem = n - c * (KH * KW);
         const int kh = rem / KW, kw = rem - kh * KW;
         b_base[j] = c * ihw + (kh - g.pad) * g.IW + (kw - g.pad);
@@ -288,7 +293,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
             const float *dyb = dY + (size_t)img * g.Cout * ohw + pix;
 #pragma unroll
             for (int j = 0; j < T::A_ELEMS / 4; ++j) {
-                const int m = m0 + rva + 64 * j;
+                const int m = m0 + rva + RPV * j;
                 const float *pa = (k < k_end && m < g.M) ? dyb + (size_t)m * ohw : g.zp;
                 const float4 v = *reinterpret_cast<const float4 *>(pa);
                 ar[4 * j + 0] = v.x; ar[4 * j + 1] = v.y; ar[4 * j + 2] = v.z; ar[4 * j + 3] = v.w;
@@ -303,7 +308,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
             const float *dyb = dY + (size_t)img * g.Cout * ohw + pix;
 #pragma unroll
             for (int j = 0; j < T::A_ELEMS; ++j) {
-                const int m = m0 + rl + 16 * j;
+                const int m = m0 + rl + RPP * j;
                 const float *pa = (k_ok && m < g.M) ? dyb + (size_t)m * ohw : g.zp;
                 ar[j] = *pa;
             }
@@ -331,13 +336,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
 #pragma unroll
             for (int j = 0; j < T::A_ELEMS / 4; ++j)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) As(buf)[(4 * qa + i) * T::LDA + rva + 64 * j] = ar[4 * j + i];
+                for (int i = 0; i < 4; ++i) As(buf)[(4 * qa + i) * T::LDA + rva + RPV * j] = ar[4 * j + i];
         } else {
 #pragma unroll
-            for (int j = 0; j < T::A_ELEMS; ++j) As(buf)[kl * T::LDA + rl + 16 * j] = ar[j];
+            for (int j = 0; j < T::A_ELEMS; ++j) As(buf)[kl * T::LDA + rl + RPP * j] = ar[j];
         }
 #pragma unroll
-        for (int j = 0; j < T::B_ELEMS; ++j) Bs(buf)[kl * T::LDB + rl + 16 * j] = br[j];
+        for (int j = 0; j < T::B_ELEMS; ++j) Bs(buf)[kl * T::LDB + rl + RPP * j] = br[j];
     };
 
     f32x16 acc[T::TM][T::TN];
@@ -346,10 +351,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
     sstore(0);
     __syncthreads();
     int buf = 0;
-    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
-        const bool more = k0 + BK < k_end;
-        if (more) gload(k0 + BK);
-        mma_slab<BM, BN>(As(buf), Bs(buf), acc, wm, wn, lane);
+    for (int k0 = k_begin; k0 < k_end; k0 += WBK) {
+        const bool more = k0 + WBK < k_end;
+        if (more) gload(k0 + WBK);
+        mma_slab<BM, BN, WBK>(As(buf), Bs(buf), acc, wm, wn, lane);
         if (more) sstore(buf ^ 1);
         __syncthreads();
         buf ^= 1;
@@ -592,18 +597,22 @@ static int launch_wgrad(const float *dY, const float *X, WgradGeom g, float *dW,
     int splits = pick_splits(tiles, g.K, 768);
     while (splits > 1 && (size_t)splits * g.M * g.N * sizeof(float) > ws_bytes) --splits;
     if ((size_t)splits * g.M * g.N * sizeof(float) > ws_bytes) { set_error("conv wgrad: workspace too small"); return SCDA_EINVAL; }
-    g.k_per_split = round_k_per_split(g.K, splits);
+    g.k_per_split = (round_k_per_split(g.K, splits) + 31) / 32 * 32;
     splits = cdiv(g.K, g.k_per_split);
     dim3 grid(cdiv(g.N, BNv), cdiv(g.M, BMv), splits);
     prof_begin(PK_CONV_WGRAD + prof_shape(KH, S), 2.0 * g.M * (double)g.N * g.K, st);
-    if (small && BNv == 64)
-        hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, KH, KW, S>), grid, dim3(256), 0, st, dY, X, g, ws);
-    else if (small)
-        hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, KH, KW, S>), grid, dim3(256), 0, st, dY, X, g, ws);
-    else if (BNv == 64)
-        hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, KH, KW, S>), grid, dim3(256), 0, st, dY, X, g, ws);
-    else
-        hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, KH, KW, S>), grid, dim3(256), 0, st, dY, X, g, ws);
+    static const char *wbk_env = getenv("SCDA_WGRAD_BK");
+    const bool bk32 = (wbk_env ? atoi(wbk_env) == 32 : true) && (g.k_per_split % 32) == 0;
+#define WGRAD_LAUNCH(BM_, BN_)                                                                                           \
+    do {                                                                                                                 \
+        if (bk32) hipLaunchKernelGGL((conv_wgrad_kernel<BM_, BN_, KH, KW, S, 32>), grid, dim3(256), 0, st, dY, X, g, ws);   \
+        else hipLaunchKernelGGL((conv_wgrad_kernel<BM_, BN_, KH, KW, S, 16>), grid, dim3(256), 0, st, dY, X, g, ws);        \
+    } while (0)
+    if (small && BNv == 64) WGRAD_LAUNCH(64, 64);
+    else if (small) WGRAD_LAUNCH(64, 128);
+    else if (BNv == 64) WGRAD_LAUNCH(128, 64);
+    else WGRAD_LAUNCH(128, 128);
+#undef WGRAD_LAUNCH
     prof_end(st);
     int rc = launch_status("conv_wgrad_kernel");
     if (rc) return rc;

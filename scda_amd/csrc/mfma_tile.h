@@ -20,15 +20,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BK = 16;
 
-template <int BM, int BN>
+template <int BM, int BN, int BKT = BK>
 struct TileCfg {
     static constexpr int LDA = BM + 4;  // +4 words: keeps rows 16B aligned, skews banks
     static constexpr int LDB = BN + 4;
     static constexpr int WM = BM / 2, WN = BN / 2;
     static constexpr int TM = WM / 32, TN = WN / 32;
-    static constexpr int A_ELEMS = BK * BM / 256;  // elements each thread stages per K-step
-    static constexpr int B_ELEMS = BK * BN / 256;
-    static constexpr int LDS_FLOATS = 2 * BK * (LDA + LDB);
+    static constexpr int A_ELEMS = BKT * BM / 256;  // elements each thread stages per K-step
+    static constexpr int B_ELEMS = BKT * BN / 256;
+    static constexpr int LDS_FLOATS = 2 * BKT * (LDA + LDB);
 };
 
 // integer division by a runtime-constant divisor; power-of-two divisors (every
@@ -61,16 +61,16 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[BM / 64][BN / 64]) {
 }
 
 // one BK-deep slab of MFMAs out of LDS
-template <int BM, int BN>
+template <int BM, int BN, int BKT = BK>
 __device__ __forceinline__ void mma_slab(const float *__restrict__ As, const float *__restrict__ Bs,
                                          f32x16 (&acc)[BM / 64][BN / 64], const int wm,
                                          const int wn, const int lane) {
-    using T = TileCfg<BM, BN>;
+    using T = TileCfg<BM, BN, BKT>;
     const int lr = lane & 31, lk = lane >> 5;
     const float *ap = As + lk * T::LDA + wm * T::WM + lr;
     const float *bp = Bs + lk * T::LDB + wn * T::WN + lr;
 #pragma unroll
-    for (int kp = 0; kp < BK / 2; ++kp) {
+    for (int kp = 0; kp < BKT / 2; ++kp) {
         float a[T::TM], b[T::TN];
 #pragma unroll
         for (int i = 0; i < T::TM; ++i) a[i] = ap[(2 * kp) * T::LDA + i * 32];
