@@ -602,7 +602,9 @@ static int launch_wgrad(const float *dY, const float *X, WgradGeom g, float *dW,
     dim3 grid(cdiv(g.N, BNv), cdiv(g.M, BMv), splits);
     prof_begin(PK_CONV_WGRAD + prof_shape(KH, S), 2.0 * g.M * (double)g.N * g.K, st);
     static const char *wbk_env = getenv("SCDA_WGRAD_BK");
-    const bool bk32 = (wbk_env ? atoi(wbk_env) == 32 : true) && (g.k_per_split % 32) == 0;
+    // measured (SCDA_WGRAD_BK=16|32 A/B): 32-deep slabs gain 10-17 % for the 64-row tiles (conv1_x, decoder heads), lose
+    // up to 8 % for 128-row tiles
+    const bool bk32 = (wbk_env ? atoi(wbk_env) == 32 : small) && (g.k_per_split % 32) == 0;
 #define WGRAD_LAUNCH(BM_, BN_)                                                                                           \
     do {                                                                                                                 \
         if (bk32) hipLaunchKernelGGL((conv_wgrad_kernel<BM_, BN_, KH, KW, S, 32>), grid, dim3(256), 0, st, dY, X, g, ws);   \
