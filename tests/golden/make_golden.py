@@ -173,7 +173,7 @@ if __name__ == "__main__":
     ap.add_argument("--only", nargs="*", default=None)
     a = ap.parse_args()
     want = lambda k: a.only is None or k in a.only  # noqa: E731
-    need_driver = want("corners") or want("train")
+    need_driver = want("corners") or want("train") or want("eval")
     if need_driver:
         ns = rh.import_reference_driver(["--config", CFG_PATH, "--port", "1", "--dataset", "cityscapes", "--datadir", "x",
                                          "--arch", "vgg16_FasterRCNN", "--dist", "0", "--cluster_num", "4",
@@ -191,3 +191,6 @@ if __name__ == "__main__":
     if want("train"):
         import make_golden_model
         make_golden_model.generate(ns, HERE)
+    if want("eval"):
+        import make_golden_eval
+        make_golden_eval.generate(ns, HERE)
