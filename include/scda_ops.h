@@ -129,8 +129,13 @@ int scda_bbox_overlaps_hip(const float *boxes, int N, const float *query, int K,
  * act: 0 none, 1 ReLU, 2 LeakyReLU(slope) fused into the epilogue.
  * ws: workspace of scda_conv2d_workspace_bytes(...) bytes (split-K slabs).      */
 size_t scda_conv2d_workspace_bytes(int batch, int Cin, int IH, int IW, int Cout, int KH, int KW, int S, int P);
-/* GEMM-ready weight: [Cout,Cin,KH,KW] -> [Cout,KH*KW,Cin] (for_dgrad = 0) or [Cin,KH*KW,Cout] (for_dgrad = 1).
- * K runs tap-major so that a 16-deep K-slab is 16 consecutive channels at one filter tap. */
+/* GEMM-ready weight: [Cout,Cin,KH,KW] -> the A operand of the forward (for_dgrad = 0, M = Cout, reduced channels
+ * C = Cin) or data-gradient (for_dgrad = 1, M = Cin, C = Cout) implicit GEMM.  The layout is private to the library:
+ *   C % 16 == 0 : [K][mpad] (M contiguous, padded with zero columns to the 64/128-row tile), K ordered
+ *                 channel-block major so that a 16-deep K-slab is 16 consecutive channels at one filter tap
+ *   otherwise   : [M][K], K tap-major
+ * `out` holds scda_conv2d_packed_elems(...) floats.  Re-pack whenever the weight changes. */
+size_t scda_conv2d_packed_elems(int Cout, int Cin, int KH, int KW, int for_dgrad);
 int scda_conv2d_pack_weight_hip(const float *w, float *out, int Cout, int Cin, int KH, int KW, int for_dgrad,
                                 void *stream);
 /* wp = pack(w, 0) */

@@ -13,19 +13,44 @@
 // straight from the activation tensor into registers (prefetch for the next
 // K-step), then stages them in LDS in the k-major layout mfma_tile.h reads.
 //
-// K is ordered TAP-MAJOR for forward / dgrad:  k = (kh*KW + kw) * C + c.  A 16-deep K-slab is then 16 consecutive
-// channels at ONE filter tap, so the (kh,kw) decode, the bounds test and the pixel offset are computed once per
-// slab (scalar / one VALU op each) and the 8 gathers of a thread are `base + j*2*plane` -- the ablation in
-// scripts/ablate/ showed the per-element index math of the channel-major order cost 35 % of the kernel.  The weight
-// operand is pre-permuted to [M][KH*KW][C] by scda_conv2d_pack_weight_hip (cached per optimiser step by the caller).
+// K order for forward / dgrad.  A 16-deep K-slab is 16 consecutive channels at ONE filter tap, so the (kh,kw) decode,
+// the bounds test and the pixel offset are computed once per slab (scalar / one VALU op each) and the 8 gathers of a
+// thread are `base + j*2*plane` -- the ablation in scripts/ablate/ showed the per-element index math of a plain
+// channel-major order cost 35 % of the kernel.  Slabs are ordered CHANNEL-BLOCK major, tap minor:
+//     k = ((c/16) * KH*KW + tap) * 16 + c%16          (channel count % 16 == 0; otherwise tap-major k = tap*C + c)
+// so the 9 taps of one 16-channel group are consecutive K-steps and re-read the same input lines within a few hundred
+// cycles (L1/L2 hits).  With tap-major slabs the reuse distance was C/16 slabs x all resident workgroups = 3..25 MB per
+// XCD, more than its 4 MB L2: rocprofv3 FETCH_SIZE showed conv1_2 fetching 7x its input (profiles/r01_pmc_traffic.md).
+// The weight operand is pre-permuted to match by scda_conv2d_pack_weight_hip (cached per optimiser step by the caller).
+//
+// Workgroup -> tile mapping (all three kernels): 1-D grid, XCD-aware.  The dispatcher places workgroup b on XCD b % 8;
+// `tile_coords` gives each XCD a CONTIGUOUS run of logical tile ids (bijective for any grid size) ordered M-tile
+// fastest, then N-tile, then K-split, so the workgroups that share an input tile (all M-tiles of one pixel tile, and
+// vertically adjacent pixel tiles) run on the same XCD at about the same time and share its L2.
 #include <stdlib.h>
 
 #include "mfma_tile.h"
 
 namespace scda {
 
-// float4 that only promises 4-byte alignment (global_load_dwordx4 needs dword, not 16-byte, alignment on gfx9+)
-struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };
+static bool xcd_swizzle_enabled() {
+    static const bool on = [] { const char *v = getenv("SCDA_XCD_SWIZZLE"); return !(v && atoi(v) == 0); }();
+    return on;
+}
+
+// logical tile of this workgroup: (tx = N-tile, ty = M-tile, tz = K-split); grid is 1-D with nx*ny*nz workgroups
+__device__ __forceinline__ void tile_coords(const int nx, const int ny, const int swz, int &tx, int &ty, int &tz) {
+    const unsigned nwg = gridDim.x, id = blockIdx.x;
+    unsigned L = id;
+    if (swz) {
+        const unsigned q = nwg >> 3, r = nwg & 7, xcd = id & 7;
+        L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+    }
+    const unsigned t = L / (unsigned)ny;
+    ty = (int)(L - t * ny);
+    tz = (int)(t / (unsigned)nx);
+    tx = (int)(t - (unsigned)tz * nx);
+}
 
 struct ConvGeom {
     // tensor the B operand gathers from: [batch, CB, HB, WB]
@@ -35,9 +60,10 @@ struct ConvGeom {
     int pad;
     int M, N, K;
     int k_per_split;  // multiple of BK
-    int slab_aligned; // CB % BK == 0: a K-slab never straddles two filter taps
-    int a_vec4;       // K % 4 == 0 and 16-byte aligned weights: float4 loads of the A operand
-    int b_vec4;       // stride 1, slab_aligned, pixel-row length % 4 == 0: 4 consecutive pixels per gather (dwordx4)
+    int nx, ny, swz;  // tile grid (N-tiles, M-tiles) and the XCD swizzle switch, see tile_coords
+    int slab_aligned; // CB % BK == 0: a K-slab is one filter tap, K is channel-block major, weights are packed [K][mpad]
+                      // and the direct-to-LDS kernel runs; otherwise tap-major [M][K] weights and the gather kernel
+    int mpad;         // M rounded up to the M-tile (leading dimension of the [K][mpad] packed weights)
     const float *zp;  // zero page: source of every out-of-range gather lane
     Div dPHW, dPW, dCB;
 };
@@ -56,11 +82,59 @@ struct Epi {
 // ---------------------------------------------------------------------------
 // conv forward / dgrad
 // ---------------------------------------------------------------------------
-// FAST = weights 16-byte aligned with K % 4 == 0 (float4 A loads) AND channel count % 16 == 0 (a K-slab never straddles
-// two filter taps).  Every VGG / RPN / decoder / discriminator layer except the 3-channel stems qualifies.  All gathers
-// are issued UNCONDITIONALLY from a clamped in-bounds address and zeroed with a select afterwards: a predicated
-// `cond ? *p : 0` made hipcc wrap every single load in its own exec-mask branch (one s_cbranch per load).
-template <int BM, int BN, int KH, int KW, int S, bool DGRAD, bool FAST>
+// offset of filter tap (kh,kw) for pixel (py,px) inside one channel plane of the gathered tensor, or -1 if the tap falls
+// into the padding / between the strides (dgrad) / the pixel itself is out of range
+template <int S, bool DGRAD>
+__device__ __forceinline__ int conv_tap_offset(const ConvGeom &g, const bool n_ok, const int py, const int px, const int kh,
+                                               const int kw) {
+    if (!n_ok) return -1;
+    if (!DGRAD) {
+        const int iy = py * S + kh - g.pad, ix = px * S + kw - g.pad;
+        return ((unsigned)iy < (unsigned)g.HB && (unsigned)ix < (unsigned)g.WB) ? iy * g.WB + ix : -1;
+    } else {
+        const int ty = py + g.pad - kh, tx = px + g.pad - kw;
+        if (ty < 0 || tx < 0) return -1;
+        const int oy = ty / S, ox = tx / S;
+        return (oy * S == ty && ox * S == tx && oy < g.HB && ox < g.WB) ? oy * g.WB + ox : -1;
+    }
+}
+
+// accumulators -> split-K slab, or (+bias) -> activation -> NCHW output; lanes run along N (pixels): 128-byte row segments
+template <int BM, int BN>
+__device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BM / 64][BN / 64], const ConvGeom &g, const Epi &e, const int m0,
+                                              const int n0, const int tz, const int wm, const int wn, const int lane) {
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    const int lr = lane & 31;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WN + j * 32 + lr;
+        if (n >= g.N) continue;
+        int oimg, opix;
+        g.dPHW.divmod(n, oimg, opix);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * WM + i * 32 + frag_row(r, lane);
+                if (m >= g.M) continue;
+                float v = acc[i][j][r];
+                if (e.splits > 1) {
+                    e.ws[((size_t)tz * g.M + m) * g.N + n] = v;
+                } else {
+                    if (e.bias) v += e.bias[m];
+                    v = apply_act(v, e.act, e.slope);
+                    e.out[((size_t)oimg * g.M + m) * g.dPHW.d + opix] = v;
+                }
+            }
+        }
+    }
+}
+
+// ---- (1) generic gather kernel: any channel count; weights [M][K] tap-major, operands staged through registers ----------
+// Used by the layers whose reduced channel count is not a multiple of 16 (the 3-channel stems and heads).  Gathers are
+// issued UNCONDITIONALLY from a pointer that was selected BEFORE the load (zero page for padding / out-of-range lanes): a
+// predicated `cond ? *p : 0` made hipcc wrap every single load in its own exec-mask branch.
+template <int BM, int BN, int KH, int KW, int S, bool DGRAD>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const float *__restrict__ Wm, const float *__restrict__ X,
                                                          const ConvGeom g, const Epi e) {
     using T = TileCfg<BM, BN>;
@@ -70,20 +144,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float *__restrict
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int k_begin = blockIdx.z * g.k_per_split;
+    int tx, ty, tz;
+    tile_coords(g.nx, g.ny, g.swz, tx, ty, tz);
+    const int m0 = ty * BM, n0 = tx * BN;
+    const int k_begin = tz * g.k_per_split;
     const int k_end = min(g.K, k_begin + g.k_per_split);
 
-    // A staging (weights, K-contiguous rows of the packed matrix):
-    //   vec4 path : lane -> (row = tid/4 [+64], 4 consecutive k) one global_load_dwordx4 per 64 rows
-    //   scalar path: k = tid%16, rows tid/16 + 16*j
-    const int ka = tid & 15, ra = tid >> 4;
-    const int qa = tid & 3, rva = tid >> 2;
-    // B staging: lanes along N (pixels are contiguous): n = tid%BN, k = tid/BN + KS*j (wave-uniform)
-    constexpr int KS = 256 / BN;
+    const int ka = tid & 15, ra = tid >> 4;             // A: lanes along K, rows tid/16 + 16*j
+    constexpr int KS = 256 / BN;                        // B: lanes along N (pixels), k = tid/BN + KS*j (wave-uniform)
     const int nb = tid % BN, kb = tid / BN;
 
-    // pixel owned by this thread for the B gather
     const int n_glob = n0 + nb;
     const bool n_ok = n_glob < g.N;
     int img, pix, py, px;
@@ -92,82 +162,31 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float *__restrict
     const float *xb = X + (size_t)img * g.CB * g.HB * g.WB;
     const int plane = g.HB * g.WB;
 
-    // vec4 B staging (stride-1 convs): lane -> 4 consecutive pixels of one k-row; BN/4 lanes per row
-    constexpr int NQ = BN / 4, KV = 256 / NQ;          // rows covered per pass
-    const int nq = tid % NQ, kq = tid / NQ;
-    int vimg = 0, vpy = 0, vpx = 0;
-    bool vn_ok = false;
-    if (S == 1 && g.b_vec4) {
-        const int n4 = n0 + 4 * nq;
-        vn_ok = n4 < g.N;
-        int vpix;
-        g.dPHW.divmod(vn_ok ? n4 : 0, vimg, vpix);
-        g.dPW.divmod(vpix, vpy, vpx);
-    }
-    const float *xbv = X + (size_t)vimg * g.CB * g.HB * g.WB;
-
     float ar[T::A_ELEMS], br[T::B_ELEMS];
-
-    // offset of tap (kh,kw) for this thread's pixel inside one channel plane, or -1 if it falls outside
-    auto tap_offset = [&](int kh, int kw) -> int {
-        if (!n_ok) return -1;
-        if (!DGRAD) {
-            const int iy = py * S + kh - g.pad, ix = px * S + kw - g.pad;
-            return ((unsigned)iy < (unsigned)g.HB && (unsigned)ix < (unsigned)g.WB) ? iy * g.WB + ix : -1;
-        } else {
-            const int ty = py + g.pad - kh, tx = px + g.pad - kw;
-            if (ty < 0 || tx < 0) return -1;
-            const int oy = ty / S, ox = tx / S;
-            return (oy * S == ty && ox * S == tx && oy < g.HB && ox < g.WB) ? oy * g.WB + ox : -1;
-        }
-    };
+    auto tap_offset = [&](int kh, int kw) -> int { return conv_tap_offset<S, DGRAD>(g, n_ok, py, px, kh, kw); };
 
     auto gload = [&](int k0) {
-        if (FAST) {
 #pragma unroll
-            for (int j = 0; j < T::A_ELEMS / 4; ++j) {
-                const int m = m0 + rva + 64 * j, k = k0 + 4 * qa;
-                const float *pa = (m < g.M && k < k_end) ? Wm + (size_t)m * g.K + k : g.zp;
-                const float4 v = *reinterpret_cast<const float4 *>(pa);
-                ar[4 * j + 0] = v.x; ar[4 * j + 1] = v.y; ar[4 * j + 2] = v.z; ar[4 * j + 3] = v.w;
-            }
-            // whole slab = channels c0 .. c0+15 of one tap: decode once (k0 is wave-uniform -> scalar unit)
-            const int r = g.dCB.div(k0), c0 = k0 - r * g.CB;
+        for (int j = 0; j < T::A_ELEMS; ++j) {
+            const int m = m0 + ra + 16 * j, k = k0 + ka;
+            const float *pa = (m < g.M && k < k_end) ? Wm + (size_t)m * g.K + k : g.zp;
+            ar[j] = *pa;
+        }
+#pragma unroll
+        for (int j = 0; j < T::B_ELEMS; ++j) {
+            const int k = k0 + kb + KS * j;  // wave-uniform
+            const bool k_ok = k < k_end;
+            const int kk = k_ok ? k : 0;
+            const int r = g.dCB.div(kk), c = kk - r * g.CB;
             const int kh = r / KW, kw = r - kh * KW;
-            const int off = tap_offset(kh, kw);
-            const float *src = off >= 0 ? xb + (size_t)(c0 + kb) * plane + off : g.zp;
-            const size_t stride = off >= 0 ? (size_t)KS * plane : 0;
-#pragma unroll
-            for (int j = 0; j < T::B_ELEMS; ++j) br[j] = src[j * stride];
-        } else {
-#pragma unroll
-            for (int j = 0; j < T::A_ELEMS; ++j) {
-                const int m = m0 + ra + 16 * j, k = k0 + ka;
-                const float *pa = (m < g.M && k < k_end) ? Wm + (size_t)m * g.K + k : g.zp;
-                ar[j] = *pa;
-            }
-#pragma unroll
-            for (int j = 0; j < T::B_ELEMS; ++j) {
-                const int k = k0 + kb + KS * j;  // wave-uniform
-                const bool k_ok = k < k_end;
-                const int r = g.dCB.div(k_ok ? k : 0), c = (k_ok ? k : 0) - r * g.CB;
-                const int kh = r / KW, kw = r - kh * KW;
-                const int off = k_ok ? tap_offset(kh, kw) : -1;
-                const float *pb = off >= 0 ? xb + (size_t)c * plane + off : g.zp;
-                br[j] = *pb;
-            }
+            const int off = k_ok ? tap_offset(kh, kw) : -1;
+            const float *pb = off >= 0 ? xb + (size_t)c * plane + off : g.zp;
+            br[j] = *pb;
         }
     };
     auto sstore = [&](int buf) {
-        if (FAST) {
 #pragma unroll
-            for (int j = 0; j < T::A_ELEMS / 4; ++j)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) As(buf)[(4 * qa + i) * T::LDA + rva + 64 * j] = ar[4 * j + i];
-        } else {
-#pragma unroll
-            for (int j = 0; j < T::A_ELEMS; ++j) As(buf)[ka * T::LDA + ra + 16 * j] = ar[j];
-        }
+        for (int j = 0; j < T::A_ELEMS; ++j) As(buf)[ka * T::LDA + ra + 16 * j] = ar[j];
 #pragma unroll
         for (int j = 0; j < T::B_ELEMS; ++j) Bs(buf)[(kb + KS * j) * T::LDB + nb] = br[j];
     };
@@ -187,32 +206,123 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float *__restrict
         __syncthreads();
         buf ^= 1;
     }
+    conv_epilogue<BM, BN>(acc, g, e, m0, n0, tz, wm, wn, lane);
+}
 
-    // epilogue: lanes run along N (pixels) -> 128B coalesced row segments
-    const int lr = lane & 31;
+// ---- (2) direct-to-LDS kernel: channel count % 16 == 0 (every VGG / RPN / decoder / discriminator body layer) -----------
+// Both operands go global -> LDS with global_load_lds (no VGPR round trip, no ds_write pass):
+//   A  weights packed [K][mpad], M contiguous: one dwordx4 instruction lays down 256 consecutive floats = 256/BM k-rows
+//   B  one dword instruction = 64 consecutive pixels of one (tap, channel) row; each lane owns ONE pixel for all of its
+//      rows, so the tap decode / bounds test is done once per slab and the per-row address is base + j*plane; padding and
+//      out-of-range lanes read the zero page (pointer selected before the load)
+// LDS is a ring of NST = 4 stages of [16][BM] + [16][BN] floats (rows unpadded: the LDS-DMA destination is
+// wave-uniform base + lane*size; the MFMA operand fetch reads 32 consecutive words per half-wave, conflict-free).
+// Schedule per K-slab s: issue the loads of slab s+2, wait until this wave's loads of slab s have landed
+// (s_waitcnt vmcnt(2L), counted -- never 0 in the steady state), ONE s_barrier, MFMAs of slab s out of stage s%4 with the
+// operand fragments double-buffered in registers (LDS reads of K-pair p+1 issued before the MFMAs of K-pair p).
+//   WAR: stage (s+2)%4 was last read by the MFMAs of slab s-2; every wave finished those before arriving at barrier s-1.
+//   RAW: each wave counts its own LDS-DMA down, the barrier then orders every wave's data before any ds_read.
+// Measured against the register-staged kernel (scripts/ablate/conv_glds.hip): +10 % conv2_2, +16 % conv3_2, +21 % conv4_2.
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+#define SCDA_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+
+template <int BM, int BN, int KH, int KW, int S, bool DGRAD>
+__global__ __launch_bounds__(256) void conv_igemm_glds_kernel(const float *__restrict__ Wt, const float *__restrict__ X,
+                                                              const ConvGeom g, const Epi e) {
+    constexpr int NST = 4, STAGE = BK * (BM + BN);
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    constexpr int A_LPR = BM / 4;             // lanes per weight row (dwordx4 each)
+    constexpr int A_RPI = 64 / A_LPR;         // rows per wave-instruction
+    constexpr int A_PW = BK / A_RPI / 4;      // A instructions per wave per slab
+    constexpr int HALVES = BN / 64;           // 64-pixel pieces per B row
+    constexpr int B_PW = 4 * HALVES;          // B instructions (= rows) per wave per slab
+    constexpr int L = A_PW + B_PW;            // LDS-DMA instructions per wave per slab
+    __shared__ __attribute__((aligned(16))) float lds[NST * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    int tx, ty, tz;
+    tile_coords(g.nx, g.ny, g.swz, tx, ty, tz);
+    const int m0 = ty * BM, n0 = tx * BN;
+    const int s_begin = tz * (g.k_per_split / BK);
+    const int s_end = min(g.K, (tz + 1) * g.k_per_split) / BK;
+
+    // B: this lane's pixel
+    const int half = wave % HALVES, kg = wave / HALVES;
+    const int n_glob = n0 + half * 64 + lane;
+    const bool n_ok = n_glob < g.N;
+    int img, pix, py, px;
+    g.dPHW.divmod(n_ok ? n_glob : 0, img, pix);
+    g.dPW.divmod(pix, py, px);
+    const int plane = g.HB * g.WB;
+    const float *xb = X + (size_t)img * g.CB * plane + (size_t)(kg * B_PW) * plane;
+    // A: this lane's 4 consecutive output channels of row (wave*A_PW + i)*A_RPI + lane/A_LPR
+    const float *wsrc = Wt + (size_t)(wave * A_PW * A_RPI + lane / A_LPR) * g.mpad + m0 + (lane % A_LPR) * 4;
+
+    auto issue = [&](int s, int buf) {
+        float *Ab = lds + buf * STAGE;
+        float *Bb = Ab + BK * BM;
+        const float *wa = wsrc + (size_t)s * BK * g.mpad;
 #pragma unroll
-    for (int j = 0; j < T::TN; ++j) {
-        const int n = n0 + wn * T::WN + j * 32 + lr;
-        if (n >= g.N) continue;
-        int oimg, opix;
-        g.dPHW.divmod(n, oimg, opix);
+        for (int i = 0; i < A_PW; ++i)
+            __builtin_amdgcn_global_load_lds((glb_void_t *)(wa + (size_t)i * A_RPI * g.mpad),
+                                             (lds_void_t *)(Ab + (wave * A_PW + i) * A_RPI * BM), 16, 0, 0);
+        const int cb = s / (KH * KW), r = s - cb * (KH * KW);
+        const int kh = r / KW, kw = r - kh * KW;
+        const int off = conv_tap_offset<S, DGRAD>(g, n_ok, py, px, kh, kw);
+        const float *src = off >= 0 ? xb + (size_t)(cb * BK) * plane + off : g.zp;
+        const size_t stride = off >= 0 ? (size_t)plane : 0;
 #pragma unroll
-        for (int i = 0; i < T::TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * T::WM + i * 32 + frag_row(r, lane);
-                if (m >= g.M) continue;
-                float v = acc[i][j][r];
-                if (e.splits > 1) {
-                    e.ws[((size_t)blockIdx.z * g.M + m) * g.N + n] = v;
-                } else {
-                    if (e.bias) v += e.bias[m];
-                    v = apply_act(v, e.act, e.slope);
-                    e.out[((size_t)oimg * g.M + m) * g.dPHW.d + opix] = v;
-                }
-            }
+        for (int j = 0; j < B_PW; ++j)
+            __builtin_amdgcn_global_load_lds((glb_void_t *)(src + j * stride),
+                                             (lds_void_t *)(Bb + (kg * B_PW + j) * BN + half * 64), 4, 0, 0);
+    };
+
+    f32x16 acc[TM][TN];
+    zero_acc<BM, BN>(acc);
+    const int lr = lane & 31, lk = lane >> 5;
+
+    if (s_begin < s_end) issue(s_begin, 0);
+    if (s_begin + 1 < s_end) issue(s_begin + 1, 1);
+    int buf = 0, nbuf = 2;
+    for (int s = s_begin; s < s_end; ++s) {
+        if (s + 2 < s_end) {
+            issue(s + 2, nbuf);
+            SCDA_WAIT_VMCNT(2 * L);
+        } else if (s + 1 < s_end) {
+            SCDA_WAIT_VMCNT(L);
+        } else {
+            SCDA_WAIT_VMCNT(0);
         }
+        __builtin_amdgcn_s_barrier();
+        const float *ap = lds + buf * STAGE + lk * BM + wm * WM + lr;
+        const float *bp = lds + buf * STAGE + BK * BM + lk * BN + wn * WN + lr;
+        float a[2][TM], b[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[0][i] = ap[i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[0][j] = bp[j * 32];
+#pragma unroll
+        for (int kp = 0; kp < BK / 2; ++kp) {
+            const int cur = kp & 1, nxt = cur ^ 1;
+            if (kp + 1 < BK / 2) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[nxt][i] = ap[(2 * kp + 2) * BM + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[nxt][j] = bp[(2 * kp + 2) * BN + j * 32];
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+        }
+        buf = (buf + 1) & (NST - 1);
+        nbuf = (nbuf + 1) & (NST - 1);
     }
+    conv_epilogue<BM, BN>(acc, g, e, m0, n0, tz, wm, wn, lane);
 }
 
 // split-K reduce for conv outputs: fixed summation order s = 0..splits-1
@@ -241,6 +351,7 @@ struct WgradGeom {
     int batch, Cin, IH, IW, Cout, OH, OW, pad;
     int M, N, K;  // Cout, Cin*KH*KW, batch*OH*OW
     int k_per_split;
+    int nx, ny, swz;  // see tile_coords
     int a_vec4;   // OH*OW % 4 == 0 and dY 16-byte aligned: float4 loads of dY
     const float *zp;
     Div dOHW, dOW;
@@ -259,8 +370,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int k_begin = blockIdx.z * g.k_per_split;
+    int tx, ty, tz;
+    tile_coords(g.nx, g.ny, g.swz, tx, ty, tz);
+    const int m0 = ty * BM, n0 = tx * BN;
+    const int k_begin = tz * g.k_per_split;
     const int k_end = min(g.K, k_begin + g.k_per_split);
 
     // both operands are contiguous along K (= output pixels): lanes along K
@@ -369,7 +482,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * T::WM + i * 32 + frag_row(r, lane);
-                if (m < g.M) ws[((size_t)blockIdx.z * g.M + m) * g.N + n] = acc[i][j][r];
+                if (m < g.M) ws[((size_t)tz * g.M + m) * g.N + n] = acc[i][j][r];
             }
     }
 }
@@ -399,6 +512,7 @@ struct GemmGeom {
     int M, N, K, lda, ldb, ldc;
     int k_per_split;
     const float *zp;
+    int nx, ny, swz;  // see tile_coords
 };
 
 template <int BM, int BN, bool TA, bool TB>
@@ -410,8 +524,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float *__restrict__ A, 
     auto Bs = [&](int b) -> float * { return lds + 2 * BK * T::LDA + b * (BK * T::LDB); };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int k_begin = blockIdx.z * g.k_per_split;
+    int tx, ty, tz;
+    tile_coords(g.nx, g.ny, g.swz, tx, ty, tz);
+    const int m0 = ty * BM, n0 = tx * BN;
+    const int k_begin = tz * g.k_per_split;
     const int k_end = min(g.K, k_begin + g.k_per_split);
 
     // K-contiguous operand: lanes along K; MN-contiguous operand: lanes along MN
@@ -487,7 +603,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float *__restrict__ A, 
                 if (m >= g.M) continue;
                 float v = acc[i][j][r];
                 if (e.splits > 1) {
-                    e.ws[((size_t)blockIdx.z * g.M + m) * g.N + n] = v;
+                    e.ws[((size_t)tz * g.M + m) * g.N + n] = v;
                 } else {
                     if (e.bias) v += e.bias_on_n ? e.bias[n] : e.bias[m];
                     v = apply_act(v, e.act, e.slope);
@@ -498,28 +614,36 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float *__restrict__ A, 
     }
 }
 
-// weight packing for the tap-major GEMM:  w[Cout][Cin][R]  ->
-//   forward : out[Cout][R][Cin]      (M = Cout, k = r*Cin  + ci)
-//   dgrad   : out[Cin][R][Cout]      (M = Cin,  k = r*Cout + co)
+// weight packing for conv_igemm*_kernel:  w[Cout][Cin][R]  ->  the GEMM's A operand; C = the reduced channel dim
+//   forward : M = Cout, C = Cin        dgrad : M = Cin, C = Cout
+//   C % 16 == 0 : out[K][mpad], k = ((c/16)*R + r)*16 + c%16, columns m >= M zero   (direct-to-LDS kernel)
+//   otherwise   : out[M][K],    k = r*C + c                                          (gather kernel)
+__host__ __device__ inline int conv_packed_mpad(int M) { return M <= 64 ? 64 : (M + 127) / 128 * 128; }
+
 __global__ __launch_bounds__(256) void pack_weight_kernel(const float *__restrict__ w, float *__restrict__ out,
                                                           const int Cout, const int Cin, const int R,
                                                           const int for_dgrad) {
-    const long long total = (long long)Cout * Cin * R;
+    const int C = for_dgrad ? Cout : Cin, M = for_dgrad ? Cin : Cout;
+    const bool blocked = (C % BK) == 0;
+    const int mpad = blocked ? conv_packed_mpad(M) : M;
+    const long long K = (long long)C * R, total = K * mpad;
     for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
          idx += (long long)blockDim.x * gridDim.x) {
-        int co, ci, r;
-        if (!for_dgrad) {  // idx enumerates out[co][r][ci]
-            ci = (int)(idx % Cin);
-            const long long t = idx / Cin;
-            r = (int)(t % R);
-            co = (int)(t / R);
-        } else {           // idx enumerates out[ci][r][co]
-            co = (int)(idx % Cout);
-            const long long t = idx / Cout;
-            r = (int)(t % R);
-            ci = (int)(t / R);
+        int k, m, c, r;
+        if (blocked) {
+            m = (int)(idx % mpad);
+            k = (int)(idx / mpad);
+            const int sl = k / BK, cb = sl / R;
+            r = sl - cb * R;
+            c = cb * BK + (k & (BK - 1));
+        } else {
+            k = (int)(idx % K);
+            m = (int)(idx / K);
+            r = k / C;
+            c = k - r * C;
         }
-        out[idx] = w[((size_t)co * Cin + ci) * R + r];
+        const int co = for_dgrad ? c : m, ci = for_dgrad ? m : c;
+        out[idx] = m < M ? w[((size_t)co * Cin + ci) * R + r] : 0.f;
     }
 }
 
@@ -567,13 +691,17 @@ static int launch_conv(const float *Wm, const float *X, const ConvGeom &g0, Epi 
     splits = cdiv(g.K, g.k_per_split);
     e.splits = splits;
     e.ws = ws;
-    dim3 grid(cdiv(g.N, BNv), cdiv(g.M, BMv), splits);
-    prof_begin(PK_CONV + ((DGRAD ? 2 : 0) + (small_m ? 1 : 0)) * 3 + prof_shape(KH, S), 2.0 * g.M * (double)g.N * g.K, st);
-    const bool fast = g.a_vec4 && g.slab_aligned;
-#define CONV_LAUNCH(BM_, BN_)                                                                                       \
-    do {                                                                                                            \
-        if (fast) hipLaunchKernelGGL((conv_igemm_kernel<BM_, BN_, KH, KW, S, DGRAD, true>), grid, dim3(256), 0, st, Wm, X, g, e);  \
-        else hipLaunchKernelGGL((conv_igemm_kernel<BM_, BN_, KH, KW, S, DGRAD, false>), grid, dim3(256), 0, st, Wm, X, g, e);      \
+    g.nx = cdiv(g.N, BNv); g.ny = cdiv(g.M, BMv); g.swz = xcd_swizzle_enabled();
+    dim3 grid((unsigned)g.nx * g.ny * splits);
+    prof_begin(g.slab_aligned ? PK_CONV + ((DGRAD ? 2 : 0) + (small_m ? 1 : 0)) * 3 + prof_shape(KH, S) : (int)PK_CONV_GATHER,
+               2.0 * g.M * (double)g.N * g.K, st);
+    g.mpad = conv_packed_mpad(g.M);
+#define CONV_LAUNCH(BM_, BN_)                                                                                            \
+    do {                                                                                                                 \
+        if (g.slab_aligned)                                                                                              \
+            hipLaunchKernelGGL((conv_igemm_glds_kernel<BM_, BN_, KH, KW, S, DGRAD>), grid, dim3(256), 0, st, Wm, X, g, e);  \
+        else                                                                                                             \
+            hipLaunchKernelGGL((conv_igemm_kernel<BM_, BN_, KH, KW, S, DGRAD>), grid, dim3(256), 0, st, Wm, X, g, e);        \
     } while (0)
     if (small_m && BNv == 64) CONV_LAUNCH(64, 64);
     else if (small_m) CONV_LAUNCH(64, 128);
@@ -599,7 +727,8 @@ static int launch_wgrad(const float *dY, const float *X, WgradGeom g, float *dW,
     if ((size_t)splits * g.M * g.N * sizeof(float) > ws_bytes) { set_error("conv wgrad: workspace too small"); return SCDA_EINVAL; }
     g.k_per_split = (round_k_per_split(g.K, splits) + 31) / 32 * 32;
     splits = cdiv(g.K, g.k_per_split);
-    dim3 grid(cdiv(g.N, BNv), cdiv(g.M, BMv), splits);
+    g.nx = cdiv(g.N, BNv); g.ny = cdiv(g.M, BMv); g.swz = xcd_swizzle_enabled();
+    dim3 grid((unsigned)g.nx * g.ny * splits);
     prof_begin(PK_CONV_WGRAD + prof_shape(KH, S), 2.0 * g.M * (double)g.N * g.K, st);
     static const char *wbk_env = getenv("SCDA_WGRAD_BK");
     // measured (SCDA_WGRAD_BK=16|32 A/B): 32-deep slabs gain 10-17 % for the 64-row tiles (conv1_x, decoder heads), lose
@@ -664,9 +793,7 @@ SCDA_API int scda_conv2d_fwd_hip(const float *x, const float *w, const float *bi
     g.M = Cout; g.N = batch * OH * OW; g.K = Cin * KH * KW; g.k_per_split = 0;
     g.dPHW = Div(OH * OW); g.dPW = Div(OW); g.dCB = Div(Cin);
     g.slab_aligned = (Cin % BK) == 0;
-    g.a_vec4 = (g.K % 4) == 0 && (((uintptr_t)w) & 15) == 0;
     g.zp = zero_page();
-    g.b_vec4 = S == 1 && g.slab_aligned && (OW % 4) == 0 && (g.N % 4) == 0 && !getenv("SCDA_CONV_NO_BVEC");
     Epi e{y, nullptr, bias, 0, act, slope, 1, 0};
     CONV_DISPATCH(launch_conv, , false > (w, x, g, e, (float *)ws, ws_bytes, as_stream(stream)))
 }
@@ -681,17 +808,21 @@ SCDA_API int scda_conv2d_dgrad_hip(const float *dy, const float *wt, float *dx, 
     g.M = Cin; g.N = batch * IH * IW; g.K = Cout * KH * KW; g.k_per_split = 0;
     g.dPHW = Div(IH * IW); g.dPW = Div(IW); g.dCB = Div(Cout);
     g.slab_aligned = (Cout % BK) == 0;
-    g.a_vec4 = (g.K % 4) == 0 && (((uintptr_t)wt) & 15) == 0;
     g.zp = zero_page();
-    g.b_vec4 = S == 1 && g.slab_aligned && (IW % 4) == 0 && (g.N % 4) == 0 && !getenv("SCDA_CONV_NO_BVEC");
     Epi e{dx, nullptr, nullptr, 0, (int)ACT_NONE, 0.f, 1, 0};
     CONV_DISPATCH(launch_conv, , true > (wt, dy, g, e, (float *)ws, ws_bytes, as_stream(stream)))
+}
+
+SCDA_API size_t scda_conv2d_packed_elems(int Cout, int Cin, int KH, int KW, int for_dgrad) {
+    const int C = for_dgrad ? Cout : Cin, M = for_dgrad ? Cin : Cout;
+    const int mpad = (C % BK) == 0 ? conv_packed_mpad(M) : M;
+    return (size_t)mpad * C * KH * KW;
 }
 
 SCDA_API int scda_conv2d_pack_weight_hip(const float *w, float *out, int Cout, int Cin, int KH, int KW, int for_dgrad,
                                          void *stream) {
     if (!w || !out || Cout <= 0 || Cin <= 0) { set_error("scda_conv2d_pack_weight_hip: bad arguments"); return SCDA_EINVAL; }
-    const long long total = (long long)Cout * Cin * KH * KW;
+    const long long total = (long long)scda_conv2d_packed_elems(Cout, Cin, KH, KW, for_dgrad);
     hipLaunchKernelGGL(pack_weight_kernel, dim3(ew_grid(total)), dim3(256), 0, as_stream(stream), w, out, Cout, Cin, KH * KW,
                        for_dgrad);
     return launch_status("pack_weight_kernel");
@@ -728,11 +859,12 @@ SCDA_API int scda_gemm_hip(const float *A, const float *B, float *C, int M, int 
     int splits = pick_splits(tiles, K);
     while (splits > 1 && (size_t)splits * M * N * sizeof(float) > ws_bytes) --splits;
     if (splits > 1 && ldc != N) { set_error("scda_gemm_hip: split-K needs ldc == N"); return SCDA_EINVAL; }
-    GemmGeom g{M, N, K, lda, ldb, ldc, round_k_per_split(K, splits), zero_page()};
+    GemmGeom g{M, N, K, lda, ldb, ldc, round_k_per_split(K, splits), zero_page(), cdiv(N, BNv), cdiv(M, BMv),
+               xcd_swizzle_enabled()};
     if (!g.zp) { set_error("scda_gemm_hip: could not allocate the zero page"); return SCDA_ELAUNCH; }
     splits = cdiv(K, g.k_per_split);
     Epi e{C, (float *)ws, bias, bias_on_n, act, slope, splits, accumulate};
-    dim3 grid(cdiv(N, BNv), cdiv(M, BMv), splits);
+    dim3 grid((unsigned)g.nx * g.ny * splits);
 #define GEMM_LAUNCH(BM_, BN_)                                                                            \
     do {                                                                                                 \
         if (!trans_a && !trans_b) hipLaunchKernelGGL((gemm_kernel<BM_, BN_, false, false>), grid, dim3(256), 0, st, A, B, g, e); \

@@ -69,18 +69,26 @@ __device__ __forceinline__ void mma_slab(const float *__restrict__ As, const flo
     const int lr = lane & 31, lk = lane >> 5;
     const float *ap = As + lk * T::LDA + wm * T::WM + lr;
     const float *bp = Bs + lk * T::LDB + wn * T::WN + lr;
+    // operand fragments double-buffered in registers: the LDS reads of K-pair kp+1 are issued before the MFMAs of kp
+    float a[2][T::TM], b[2][T::TN];
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i) a[0][i] = ap[i * 32];
+#pragma unroll
+    for (int j = 0; j < T::TN; ++j) b[0][j] = bp[j * 32];
 #pragma unroll
     for (int kp = 0; kp < BKT / 2; ++kp) {
-        float a[T::TM], b[T::TN];
+        const int cur = kp & 1, nxt = cur ^ 1;
+        if (kp + 1 < BKT / 2) {
 #pragma unroll
-        for (int i = 0; i < T::TM; ++i) a[i] = ap[(2 * kp) * T::LDA + i * 32];
+            for (int i = 0; i < T::TM; ++i) a[nxt][i] = ap[(2 * kp + 2) * T::LDA + i * 32];
 #pragma unroll
-        for (int j = 0; j < T::TN; ++j) b[j] = bp[(2 * kp) * T::LDB + j * 32];
+            for (int j = 0; j < T::TN; ++j) b[nxt][j] = bp[(2 * kp + 2) * T::LDB + j * 32];
+        }
 #pragma unroll
         for (int i = 0; i < T::TM; ++i)
 #pragma unroll
             for (int j = 0; j < T::TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
     }
 }
 

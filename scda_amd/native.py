@@ -232,12 +232,10 @@ _PACK_CACHE = {}
 
 
 def conv2d_pack_weight(w, for_dgrad=False, cache=True):
-    """[Cout,Cin,KH,KW] -> GEMM-ready [Cout,KH*KW,Cin] (forward) or [Cin,KH*KW,Cout] (dgrad); 1x1 forward is the
-    identity.  Cached per (storage, direction) until the weight changes (tensor version or optimiser epoch)."""
+    """[Cout,Cin,KH,KW] -> the library's GEMM-ready layout for the forward / data-gradient kernel (see scda_ops.h).
+    Cached per (storage, direction) until the weight changes (tensor version or optimiser epoch)."""
     _req(w, "w")
     Cout, Cin, KH, KW = w.shape
-    if KH * KW == 1 and not for_dgrad:
-        return w
     key = (w.data_ptr(), for_dgrad)
     flat = getattr(w, "_scda_flat", None)
     tag = (w._version, flat.epoch if flat is not None else WEIGHT_EPOCH[0], tuple(w.shape))
@@ -246,7 +244,9 @@ def conv2d_pack_weight(w, for_dgrad=False, cache=True):
         # valid only for the very same tensor object (a freed temporary's address may be reused by another weight)
         if hit is not None and hit[0] == tag and hit[2]() is w:
             return hit[1]
-    out = torch.empty(w.numel(), dtype=torch.float32, device=w.device)
+    lib().scda_conv2d_packed_elems.restype = ctypes.c_size_t
+    n = lib().scda_conv2d_packed_elems(i32(Cout), i32(Cin), i32(KH), i32(KW), i32(int(for_dgrad)))
+    out = torch.empty(n, dtype=torch.float32, device=w.device)
     _check(lib().scda_conv2d_pack_weight_hip(_p(w), _p(out), i32(Cout), i32(Cin), i32(KH), i32(KW), i32(int(for_dgrad)),
                                              _stream()), "scda_conv2d_pack_weight_hip")
     if cache:
