@@ -285,54 +285,123 @@ __global__ __launch_bounds__(256) void smooth_l1_bwd_kernel(const float *__restr
 }
 
 // ------------------------------------------------------ instance norm -------
-// nn.InstanceNorm2d(affine=False, eps) (+ optional fused ReLU / LeakyReLU), one workgroup per (b,c) plane.
+// nn.InstanceNorm2d(affine=False, eps) (+ optional fused ReLU / LeakyReLU), one 1024-thread workgroup per (b,c) plane.
 // common_net.py:69-72 (INSResBlock), :288-289 (LeakyReLUConvTranspose2d_2)
-__global__ __launch_bounds__(256) void instnorm_fwd_kernel(const float *__restrict__ x, float *__restrict__ y,
-                                                           float *__restrict__ mean_out, float *__restrict__ rstd_out,
-                                                           const int HW, const float eps, const int act,
-                                                           const float slope) {
+// HBM-bound: the plane is read ONCE with float4 loads and kept in registers across the mean / centred-variance /
+// normalise passes when it fits (VPT float4 per thread: 64x64, 128x128 and 256x256 planes = VPT 1, 4, 16); other sizes
+// take the generic path, which re-reads the plane (L2) with scalar loads.  Two-pass statistics (mean, then centred sum of
+// squares), fixed reduction order.
+__device__ __forceinline__ float inorm_act(float o, const int act, const float slope) {
+    if (act == 1) return o > 0.f ? o : 0.f;
+    if (act == 2) return o > 0.f ? o : o * slope;
+    return o;
+}
+
+template <int VPT>
+__global__ __launch_bounds__(1024) void instnorm_fwd_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                            float *__restrict__ mean_out, float *__restrict__ rstd_out,
+                                                            const int HW, const float eps, const int act,
+                                                            const float slope) {
     __shared__ float red[16];
     const size_t base = (size_t)blockIdx.x * HW;
-    float s = 0.f;
-    for (int i = threadIdx.x; i < HW; i += blockDim.x) s += x[base + i];
-    const float mean = block_sum(s, red) / (float)HW;
-    float v = 0.f;
-    for (int i = threadIdx.x; i < HW; i += blockDim.x) { const float d = x[base + i] - mean; v += d * d; }
-    const float var = block_sum(v, red) / (float)HW;
-    const float rstd = 1.f / sqrtf(var + eps);
-    for (int i = threadIdx.x; i < HW; i += blockDim.x) {
-        float o = (x[base + i] - mean) * rstd;
-        if (act == 1) o = o > 0.f ? o : 0.f;
-        else if (act == 2) o = o > 0.f ? o : o * slope;
-        y[base + i] = o;
+    float mean, rstd;
+    if (VPT > 0) {
+        const float4 *x4 = reinterpret_cast<const float4 *>(x + base);
+        float4 v[VPT > 0 ? VPT : 1];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) {
+            v[j] = x4[j * 1024 + threadIdx.x];
+            s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+        }
+        mean = block_sum(s, red) / (float)HW;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) {
+            const float a = v[j].x - mean, b = v[j].y - mean, c = v[j].z - mean, d = v[j].w - mean;
+            q += (a * a + b * b) + (c * c + d * d);
+        }
+        rstd = 1.f / sqrtf(block_sum(q, red) / (float)HW + eps);
+        float4 *y4 = reinterpret_cast<float4 *>(y + base);
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) {
+            float4 o;
+            o.x = inorm_act((v[j].x - mean) * rstd, act, slope);
+            o.y = inorm_act((v[j].y - mean) * rstd, act, slope);
+            o.z = inorm_act((v[j].z - mean) * rstd, act, slope);
+            o.w = inorm_act((v[j].w - mean) * rstd, act, slope);
+            y4[j * 1024 + threadIdx.x] = o;
+        }
+    } else {
+        float s = 0.f;
+        for (int i = threadIdx.x; i < HW; i += blockDim.x) s += x[base + i];
+        mean = block_sum(s, red) / (float)HW;
+        float q = 0.f;
+        for (int i = threadIdx.x; i < HW; i += blockDim.x) { const float d = x[base + i] - mean; q += d * d; }
+        rstd = 1.f / sqrtf(block_sum(q, red) / (float)HW + eps);
+        for (int i = threadIdx.x; i < HW; i += blockDim.x) y[base + i] = inorm_act((x[base + i] - mean) * rstd, act, slope);
     }
     if (threadIdx.x == 0) { mean_out[blockIdx.x] = mean; rstd_out[blockIdx.x] = rstd; }
 }
 
-__global__ __launch_bounds__(256) void instnorm_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ x,
-                                                           const float *__restrict__ mean_in,
-                                                           const float *__restrict__ rstd_in, float *__restrict__ dx,
-                                                           const int HW, const int act, const float slope) {
+// dx = rstd * (g - mean(g) - xh * mean(g * xh)),  g = dy gated by the fused activation, xh = (x - mean) * rstd.
+// VPT > 0: g (and, with CACHE_X, xh) stay in registers between the reduction and the output pass (VPT float4 each);
+// the 256x256 planes keep g only (64 VGPRs) and re-read x for the output pass.
+template <int VPT, bool CACHE_X>
+__global__ __launch_bounds__(1024) void instnorm_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ x,
+                                                            const float *__restrict__ mean_in,
+                                                            const float *__restrict__ rstd_in, float *__restrict__ dx,
+                                                            const int HW, const int act, const float slope) {
     __shared__ float red[16];
     const size_t base = (size_t)blockIdx.x * HW;
     const float mean = mean_in[blockIdx.x], rstd = rstd_in[blockIdx.x];
-    float s1 = 0.f, s2 = 0.f;
-    for (int i = threadIdx.x; i < HW; i += blockDim.x) {
-        const float xh = (x[base + i] - mean) * rstd;
-        float g = dy[base + i];
-        if (act == 1) g = xh > 0.f ? g : 0.f;
-        else if (act == 2) g = xh > 0.f ? g : g * slope;
-        s1 += g;
-        s2 += g * xh;
-    }
-    const float m1 = block_sum(s1, red) / (float)HW;
-    const float m2 = block_sum(s2, red) / (float)HW;
-    for (int i = threadIdx.x; i < HW; i += blockDim.x) {
-        const float xh = (x[base + i] - mean) * rstd;
-        float g = dy[base + i];
-        if (act == 1) g = xh > 0.f ? g : 0.f;
-        else if (act == 2) g = xh > 0.f ? g : g * slope;
-        dx[base + i] = rstd * (g - m1 - xh * m2);
+    auto gate = [&](float g, float xh) -> float {
+        if (act == 1) return xh > 0.f ? g : 0.f;
+        if (act == 2) return xh > 0.f ? g : g * slope;
+        return g;
+    };
+    if (VPT > 0) {
+        const float4 *x4 = reinterpret_cast<const float4 *>(x + base), *g4 = reinterpret_cast<const float4 *>(dy + base);
+        float4 xc[(VPT > 0 && CACHE_X) ? VPT : 1], g[VPT > 0 ? VPT : 1];
+        auto norm4 = [&](const float4 xv) -> float4 {
+            float4 h;
+            h.x = (xv.x - mean) * rstd; h.y = (xv.y - mean) * rstd; h.z = (xv.z - mean) * rstd; h.w = (xv.w - mean) * rstd;
+            return h;
+        };
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) {
+            const float4 xh = norm4(x4[j * 1024 + threadIdx.x]), gv = g4[j * 1024 + threadIdx.x];
+            if (CACHE_X) xc[j] = xh;
+            g[j].x = gate(gv.x, xh.x); g[j].y = gate(gv.y, xh.y); g[j].z = gate(gv.z, xh.z); g[j].w = gate(gv.w, xh.w);
+            s1 += (g[j].x + g[j].y) + (g[j].z + g[j].w);
+            s2 += (g[j].x * xh.x + g[j].y * xh.y) + (g[j].z * xh.z + g[j].w * xh.w);
+        }
+        const float m1 = block_sum(s1, red) / (float)HW;
+        const float m2 = block_sum(s2, red) / (float)HW;
+        float4 *d4 = reinterpret_cast<float4 *>(dx + base);
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) {
+            const float4 xh = CACHE_X ? xc[j] : norm4(x4[j * 1024 + threadIdx.x]);
+            float4 o;
+            o.x = rstd * (g[j].x - m1 - xh.x * m2); o.y = rstd * (g[j].y - m1 - xh.y * m2);
+            o.z = rstd * (g[j].z - m1 - xh.z * m2); o.w = rstd * (g[j].w - m1 - xh.w * m2);
+            d4[j * 1024 + threadIdx.x] = o;
+        }
+    } else {
+        float s1 = 0.f, s2 = 0.f;
+        for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+            const float xh = (x[base + i] - mean) * rstd;
+            const float g = gate(dy[base + i], xh);
+            s1 += g;
+            s2 += g * xh;
+        }
+        const float m1 = block_sum(s1, red) / (float)HW;
+        const float m2 = block_sum(s2, red) / (float)HW;
+        for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+            const float xh = (x[base + i] - mean) * rstd;
+            dx[base + i] = rstd * (gate(dy[base + i], xh) - m1 - xh * m2);
+        }
     }
 }
 
@@ -718,14 +787,26 @@ SCDA_API int scda_smooth_l1_bwd_hip(const float *pred, const float *mask, const 
 SCDA_API int scda_instnorm_fwd_hip(const float *x, float *y, float *mean, float *rstd, int planes, int HW, float eps,
                                    int act, float slope, void *stream) {
     NN_CHECK(x && y && mean && rstd && planes > 0 && HW > 0, "scda_instnorm_fwd_hip")
-    hipLaunchKernelGGL(instnorm_fwd_kernel, dim3(planes), dim3(256), 0, as_stream(stream), x, y, mean, rstd, HW, eps, act, slope);
+    const bool al = ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0;
+#define INORM_FWD(V) hipLaunchKernelGGL(instnorm_fwd_kernel<V>, dim3(planes), dim3(1024), 0, as_stream(stream), x, y, mean, rstd, HW, eps, act, slope)
+    if (al && HW == 4096) INORM_FWD(1);
+    else if (al && HW == 16384) INORM_FWD(4);
+    else if (al && HW == 65536) INORM_FWD(16);
+    else INORM_FWD(0);
+#undef INORM_FWD
     return launch_status("instnorm_fwd_kernel");
 }
 
 SCDA_API int scda_instnorm_bwd_hip(const float *dy, const float *x, const float *mean, const float *rstd, float *dx,
                                    int planes, int HW, int act, float slope, void *stream) {
     NN_CHECK(dy && x && mean && rstd && dx && planes > 0 && HW > 0, "scda_instnorm_bwd_hip")
-    hipLaunchKernelGGL(instnorm_bwd_kernel, dim3(planes), dim3(256), 0, as_stream(stream), dy, x, mean, rstd, dx, HW, act, slope);
+    const bool al = ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx)) & 15) == 0;
+#define INORM_BWD(V, CX) hipLaunchKernelGGL((instnorm_bwd_kernel<V, CX>), dim3(planes), dim3(1024), 0, as_stream(stream), dy, x, mean, rstd, dx, HW, act, slope)
+    if (al && HW == 4096) INORM_BWD(1, true);
+    else if (al && HW == 16384) INORM_BWD(4, true);
+    else if (al && HW == 65536) INORM_BWD(16, false);
+    else INORM_BWD(0, false);
+#undef INORM_BWD
     return launch_status("instnorm_bwd_kernel");
 }
 

@@ -100,10 +100,12 @@ def test_smooth_l1(cuda, with_mask):
     close(lg, l, 1e-5); close(pg.grad, pr.grad, 1e-5)
 
 
+# plane sizes: generic path (16x16, 24x40) and the register-cached float4 paths (64x64, 128x128, 256x256 planes)
+@pytest.mark.parametrize("shape", [(4, 6, 16, 16), (2, 3, 24, 40), (2, 5, 64, 64), (2, 3, 128, 128), (1, 2, 256, 256)])
 @pytest.mark.parametrize("act", [0, 1, 2])
-def test_instance_norm(cuda, act):
+def test_instance_norm(cuda, act, shape):
     from scda_amd import autograd_ops as A
-    x = torch.randn(4, 6, 16, 16, generator=gen(13)) * 2 + 0.5
+    x = torch.randn(*shape, generator=gen(13)) * 2 + 0.5
     xr = x.clone().requires_grad_()
     y = F.instance_norm(xr, eps=1e-5)
     y = [lambda v: v, F.relu, lambda v: F.leaky_relu(v, 0.01)][act](y)
