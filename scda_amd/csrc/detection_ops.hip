@@ -350,6 +350,76 @@ __global__ __launch_bounds__(256) void roi_pool_bwd_kernel(const float *__restri
     }
 }
 
+// Backward, ORDERED SCATTER form (the one the C ABI launches when PH*PW <= 64 and a plane fits in LDS).
+// The gradient of one (image, channel) plane is the sum, over (roi, ph, pw) in ascending order, of top[roi,c,ph,pw] at
+// pixel argmax[roi,c,ph,pw] -- exactly what the reference's gather loop adds up, in its order.  One WAVE owns one plane,
+// kept in LDS; lane = bin.  (Eight waves share a plane, each owning a contiguous eighth of its pixels and ignoring the
+// bins that land elsewhere: 8x the waves to hide the LDS round-trip chain, and most RoIs miss most slices.)  For each RoI (ascending) the wave reads its 49 argmax/top values with two coalesced loads and
+// adds them into the plane.  Bins of one RoI can share a pixel (floor/ceil bin edges overlap; tiny RoIs collapse onto one
+// pixel), and fp32 addition order matters, so equal targets are serialised lowest-bin-first: every pending lane posts its
+// lane id with an LDS atomicMin on a tag word of its pixel, the lane that finds its own id there adds and retires, the
+// rest go round again (1 round unless bins collide).  No window tests, no divisions, argmax/top read exactly once
+// (~100 MB for 512 RoIs x 512 channels); bit-identical to the gather kernel above, which remains the fallback.
+constexpr int kScatterBands = 8;   // waves per plane
+
+__global__ __launch_bounds__(64 * kScatterBands) void roi_pool_bwd_scatter_kernel(const float *__restrict__ top,
+                                                                                 const int32_t *__restrict__ argmax,
+                                                                                 const float *__restrict__ rois, const int R,
+                                                                                 const int C, const int HW, const int bins,
+                                                                                 float *__restrict__ bottom) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p = blockIdx.x;                   // plane = n * C + c
+    const int n = p / C, c = p - n * C;
+    // this wave's slice of the plane: pixels [lo, hi)
+    const int per = (HW + kScatterBands - 1) / kScatterBands;
+    const int lo = wave * per, hi = min(HW, lo + per);
+    float *plane = reinterpret_cast<float *>(smem_raw) + (size_t)wave * per * 2;
+    int *tag = reinterpret_cast<int *>(plane + per);
+    for (int i = lane; i < per; i += 64) { plane[i] = 0.f; tag[i] = 64; }
+    const int base = p * HW + lo, span = hi - lo;
+    constexpr int U = 8;
+    int idx[2][U];
+    float g[2][U];
+    auto fetch = [&](int r0, int (&ix)[U], float (&gv)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = r0 + u;
+            ix[u] = -1;
+            gv[u] = 0.f;
+            if (r < R && lane < bins && (int)rois[(size_t)r * 5] == n) {
+                const size_t o = ((size_t)r * C + c) * bins + lane;
+                const int a = argmax[o] - base;
+                if (a >= 0 && a < span) { ix[u] = a; gv[u] = top[o]; }
+            }
+        }
+    };
+    fetch(0, idx[0], g[0]);
+    int cur = 0;
+    for (int r0 = 0; r0 < R; r0 += U) {
+        if (r0 + U < R) {
+            if (cur == 0) fetch(r0 + U, idx[1], g[1]);
+            else fetch(r0 + U, idx[0], g[0]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int ix = cur == 0 ? idx[0][u] : idx[1][u];
+            const float gv = cur == 0 ? g[0][u] : g[1][u];
+            bool pending = ix >= 0;
+            while (__ballot(pending)) {
+                if (pending) atomicMin(&tag[ix], lane);
+                if (pending && tag[ix] == lane) {
+                    plane[ix] += gv;
+                    tag[ix] = 64;
+                    pending = false;
+                }
+            }
+        }
+        cur ^= 1;
+    }
+    for (int i = lane; i < span; i += 64) bottom[(size_t)base + i] = plane[i];
+}
+
 // ---------------------------------------------------------------------------
 // RoIAlign (old single-sample form).  Reference: extensions/_roi_align/src/roi_align_kernel.cu
 // The reference mixes float and double literals; the double sub-expressions are
@@ -680,6 +750,13 @@ SCDA_API int scda_roi_pool_bwd_hip(const float *top_grad, const int32_t *argmax,
         return e == hipSuccess ? SCDA_OK : SCDA_ELAUNCH;
     }
     if (!top_grad || !argmax || !rois) { set_error("scda_roi_pool_bwd_hip: null pointer"); return SCDA_EINVAL; }
+    static const bool force_gather = getenv("SCDA_ROIPOOL_BWD_GATHER") != nullptr;   // A/B knob
+    const size_t per = ((size_t)H * W + kScatterBands - 1) / kScatterBands;
+    if (PH * PW <= 64 && per * 8 * kScatterBands <= 64 * 1024 && !force_gather) {
+        hipLaunchKernelGGL(roi_pool_bwd_scatter_kernel, dim3(B * C), dim3(64 * kScatterBands), per * 8 * kScatterBands, as_stream(stream),
+                           top_grad, argmax, rois, R, C, H * W, PH * PW, bottom_grad);
+        return launch_status("roi_pool_bwd_scatter_kernel");
+    }
     const size_t lds = (size_t)R * 5 * sizeof(int);
     if (lds > 96 * 1024) { set_error("scda_roi_pool_bwd_hip: R=%d too large", R); return SCDA_EINVAL; }
     const int bands = (H + kBandRows - 1) / kBandRows;

@@ -76,6 +76,10 @@ def test_roi_pool_fwd_bwd_bit_exact(cuda, shape, R):
     feat[0, 0, 1:5, 2:9] = 2.5  # ties
     rois = rand_rois(rs, R, B=B, W=W * 16, H=H * 16)
     rois[-1] = [0, -50, -50, W * 16 + 80, H * 16 + 80]
+    # tiny RoIs: all 49 bins collapse onto 1-4 feature pixels (the ordered-scatter backward must serialise them in bin order)
+    rois[-2] = [0, 37, 21, 40, 24]
+    rois[-3] = [B - 1, 100, 60, 119, 70]
+    rois[-4] = rois[-2]
     eo, ea = orc.roi_pool_fwd(feat, rois, 7, 7, 1 / 16.)
     out, arg = native.roi_pool_fwd(dev(feat, cuda), dev(rois, cuda), 7, 7, 1 / 16.)
     np.testing.assert_array_equal(out.cpu().numpy(), eo)
