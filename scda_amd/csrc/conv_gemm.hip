@@ -29,6 +29,8 @@
 // vertically adjacent pixel tiles) run on the same XCD at about the same time and share its L2.
 #include <stdlib.h>
 
+#include <vector>
+
 #include "mfma_tile.h"
 
 namespace scda {
@@ -226,6 +228,60 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float *__restrict
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
 #define SCDA_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+
+// ---- operand staging shared by the dense GEMM and the weight-gradient kernels ------------------------------------------
+// They use the ring / vmcnt / barrier schedule of conv_igemm_glds_kernel (below); what differs is how a tile lands in LDS:
+//   MC (stored [K][MN], MN contiguous): rows of the tile are K-rows, laid down as [16][BMN] by dwordx4 LDS-DMA; the MFMA
+//      operand fetch is one ds_read_b32 per K value (32 consecutive words per half-wave).
+//   KC (stored [MN][K], K contiguous -- activations and nn.Linear weights): a dwordx4 covers 4 consecutive K of one row, 4
+//      lanes cover the 16-deep slab of that row, so the tile lands as [BMN][16].  The MFMA wants, per lane, one value per K
+//      step; lane (i = lane&31, h = lane>>5) therefore takes K = 8q + 4h + t (q = 0,1; t = 0..3) -- FOUR consecutive K in one
+//      ds_read_b128 -- and MFMA (q,t) contracts K = {8q+t, 8q+4+t}.  (Any pairing is valid as long as A and B agree; MC
+//      operands simply read rows 8q+4h+t.)  16-byte pieces of a row are XOR-swizzled with row bits 2..3 so that the 16
+//      lanes of one b128 pass hit 16 distinct 16-byte slots of the 256-byte bank row; the LDS-DMA destination is linear, so
+//      the permutation is applied to the per-lane SOURCE address (chunk c of row r is fetched by the lane whose slot is
+//      c ^ ((r>>2)&3)) and undone by the reader.
+template <int BMN, bool MC>
+struct GldsOperand {
+    static constexpr int PW = BMN / 64;   // LDS-DMA instructions per wave per 16-deep slab (both layouts)
+    // issue this wave's share of one slab: tile rows/cols start at mn0, K at k0
+    __device__ static __forceinline__ void issue(const float *__restrict__ base, const int ld, const int extent, const int mn0,
+                                                 const int k0, float *stage, const int wave, const int lane,
+                                                 const float *zp) {
+        if (MC) {
+            constexpr int LPR = BMN / 4, RPI = 64 / LPR;
+            const int col = (lane % LPR) * 4;
+            const bool ok = mn0 + col < extent;
+#pragma unroll
+            for (int i = 0; i < PW; ++i) {
+                const int row0 = (wave * PW + i) * RPI;
+                const float *src = ok ? base + (size_t)(k0 + row0 + lane / LPR) * ld + mn0 + col : zp;
+                __builtin_amdgcn_global_load_lds((glb_void_t *)src, (lds_void_t *)(stage + row0 * BMN), 16, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < PW; ++i) {
+                const int row0 = (wave * PW + i) * 16, row = row0 + (lane >> 2);
+                const int c = (lane & 3) ^ ((row >> 2) & 3);
+                const float *src = mn0 + row < extent ? base + (size_t)(mn0 + row) * ld + k0 + 4 * c : zp;
+                __builtin_amdgcn_global_load_lds((glb_void_t *)src, (lds_void_t *)(stage + row0 * 16), 16, 0, 0);
+            }
+        }
+    }
+    // fragment for K-group q of the 32-row MFMA tile starting at tile row `r0`: f[t] = operand[r0 + lr][8q + 4h + t]
+    __device__ static __forceinline__ void frag(const float *stage, const int r0, const int lr, const int h, const int q,
+                                                float (&f)[4]) {
+        if (MC) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) f[t] = stage[(8 * q + 4 * h + t) * BMN + r0 + lr];
+        } else {
+            const int row = r0 + lr, p = (2 * q + h) ^ ((row >> 2) & 3);
+            const float4 v = *reinterpret_cast<const float4 *>(stage + row * 16 + 4 * p);
+            f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+        }
+    }
+};
+
 
 template <int BM, int BN, int KH, int KW, int S, bool DGRAD>
 __global__ __launch_bounds__(256) void conv_igemm_glds_kernel(const float *__restrict__ Wt, const float *__restrict__ X,
@@ -487,6 +543,122 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
     }
 }
 
+// ---- weight gradient, direct-to-LDS ------------------------------------------------------------------------------------
+// Both operands are K-contiguous (K = output pixels), i.e. the KC layout of GldsOperand: tiles land as [rows][16 pixels],
+// fragments are ds_read_b128 with the K = 8q + 4h + t assignment and the 16-byte XOR swizzle.
+//   A = dY rows (output channels): dwordx4 LDS-DMA, GldsOperand<BM, false> (needs OH*OW % 16 == 0: a slab never straddles
+//       two images and stays 16-byte aligned)
+//   B = gathered X rows n = (ci, kh, kw): dword LDS-DMA, one instruction = 4 rows x 16 pixels.  The swizzle moves a lane's
+//       pixel with (row>>2)&3, so wave w takes the row groups whose (row>>2)&3 == w: every lane then owns ONE pixel of the
+//       slab for all 8 of its instructions and decodes (oy, ox) + the 9-bit tap-validity mask once per slab.
+template <int BM, int BN, int KH, int KW, int S>
+__global__ __launch_bounds__(256) void conv_wgrad_glds_kernel(const float *__restrict__ dY, const float *__restrict__ X,
+                                                              const WgradGeom g, float *__restrict__ ws) {
+    using OA = GldsOperand<BM, false>;
+    using OB = GldsOperand<BN, false>;   // fragment reader only; staging is the gather below
+    constexpr int NST = 4, STAGE = BK * (BM + BN);
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    constexpr int B_PW = BN / 16;        // B instructions per wave per slab (4 rows each)
+    constexpr int L = OA::PW + B_PW;
+    __shared__ __attribute__((aligned(16))) float lds[NST * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    int tx, ty, tz;
+    tile_coords(g.nx, g.ny, g.swz, tx, ty, tz);
+    const int m0 = ty * BM, n0 = tx * BN;
+    const int s_begin = tz * (g.k_per_split / BK);
+    const int s_end = min(g.K, (tz + 1) * g.k_per_split) / BK;
+    const int ohw = g.dOHW.d, ihw = g.IH * g.IW;
+
+    // B gather: this lane's pixel inside a slab (after the swizzle) and the (ci, tap) constants of its 8 rows
+    const int kl = 4 * (((lane & 15) >> 2) ^ wave) + (lane & 3);
+    int b_base[B_PW], b_tap[B_PW];
+#pragma unroll
+    for (int j = 0; j < B_PW; ++j) {
+        const int n = n0 + 16 * j + 4 * wave + (lane >> 4);
+        const int c = n / (KH * KW), rem = n - c * (KH * KW);
+        const int kh = rem / KW, kw = rem - kh * KW;
+        b_base[j] = c * ihw + (kh - g.pad) * g.IW + (kw - g.pad);
+        b_tap[j] = (n < g.N) ? kh * KW + kw : 31;   // bit 31 of the mask is never set
+    }
+
+    auto issue = [&](int s, int buf) {
+        float *st = lds + buf * STAGE;
+        const int k0 = s * BK;
+        int img0, pix0;
+        g.dOHW.divmod(k0, img0, pix0);
+        OA::issue(dY + (size_t)img0 * g.Cout * ohw, ohw, g.M, m0, pix0, st, wave, lane, g.zp);
+        int oy, ox;
+        g.dOW.divmod(pix0 + kl, oy, ox);
+        unsigned mask = 0;
+#pragma unroll
+        for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < KW; ++kw) {
+                const int iy = oy * S + kh - g.pad, ix = ox * S + kw - g.pad;
+                if ((unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW) mask |= 1u << (kh * KW + kw);
+            }
+        const float *xb = X + (size_t)img0 * g.Cin * ihw + (oy * S) * g.IW + ox * S;
+        float *Bb = st + BK * BM;
+#pragma unroll
+        for (int j = 0; j < B_PW; ++j) {
+            const float *src = ((mask >> b_tap[j]) & 1u) ? xb + b_base[j] : g.zp;
+            __builtin_amdgcn_global_load_lds((glb_void_t *)src, (lds_void_t *)(Bb + (16 * j + 4 * wave) * 16), 4, 0, 0);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+    zero_acc<BM, BN>(acc);
+    const int lr = lane & 31, lh = lane >> 5;
+    if (s_begin < s_end) issue(s_begin, 0);
+    if (s_begin + 1 < s_end) issue(s_begin + 1, 1);
+    int buf = 0, nbuf = 2;
+    for (int s = s_begin; s < s_end; ++s) {
+        if (s + 2 < s_end) {
+            issue(s + 2, nbuf);
+            SCDA_WAIT_VMCNT(2 * L);
+        } else if (s + 1 < s_end) {
+            SCDA_WAIT_VMCNT(L);
+        } else {
+            SCDA_WAIT_VMCNT(0);
+        }
+        __builtin_amdgcn_s_barrier();
+        const float *as = lds + buf * STAGE, *bs = as + BK * BM;
+        float a[2][TM][4], b[2][TN][4];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) OA::frag(as, wm * WM + i * 32, lr, lh, q, a[q][i]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) OB::frag(bs, wn * WN + j * 32, lr, lh, q, b[q][j]);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][i][t], b[q][j][t], acc[i][j], 0, 0, 0);
+        buf = (buf + 1) & (NST - 1);
+        nbuf = (nbuf + 1) & (NST - 1);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WN + j * 32 + lr;
+        if (n >= g.N) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * WM + i * 32 + frag_row(r, lane);
+                if (m < g.M) ws[((size_t)tz * g.M + m) * g.N + n] = acc[i][j][r];
+            }
+    }
+}
+
 // out[idx] = (accumulate ? out[idx] : 0) + sum_s ws[s][idx] (+ bias[col]) -> act
 __global__ __launch_bounds__(256) void dense_splitk_reduce_kernel(const float *__restrict__ ws, const int splits,
                                                                   const long long total, const int N,
@@ -614,6 +786,93 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float *__restrict__ A, 
     }
 }
 
+// ---- dense GEMM, direct-to-LDS (operand staging: GldsOperand above) -------------------------------------------------
+template <int BM, int BN, bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_glds_kernel(const float *__restrict__ A, const float *__restrict__ B,
+                                                        const GemmGeom g, const Epi e) {
+    using OA = GldsOperand<BM, TA>;
+    using OB = GldsOperand<BN, TB>;
+    constexpr int NST = 4, STAGE = BK * (BM + BN);
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    constexpr int L = OA::PW + OB::PW;
+    __shared__ __attribute__((aligned(16))) float lds[NST * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    int tx, ty, tz;
+    tile_coords(g.nx, g.ny, g.swz, tx, ty, tz);
+    const int m0 = ty * BM, n0 = tx * BN;
+    const int s_begin = tz * (g.k_per_split / BK);
+    const int s_end = min(g.K, (tz + 1) * g.k_per_split) / BK;
+
+    auto issue = [&](int s, int buf) {
+        float *st = lds + buf * STAGE;
+        OA::issue(A, g.lda, g.M, m0, s * BK, st, wave, lane, g.zp);
+        OB::issue(B, g.ldb, g.N, n0, s * BK, st + BK * BM, wave, lane, g.zp);
+    };
+
+    f32x16 acc[TM][TN];
+    zero_acc<BM, BN>(acc);
+    const int lr = lane & 31, lh = lane >> 5;
+
+    if (s_begin < s_end) issue(s_begin, 0);
+    if (s_begin + 1 < s_end) issue(s_begin + 1, 1);
+    int buf = 0, nbuf = 2;
+    for (int s = s_begin; s < s_end; ++s) {
+        if (s + 2 < s_end) {
+            issue(s + 2, nbuf);
+            SCDA_WAIT_VMCNT(2 * L);
+        } else if (s + 1 < s_end) {
+            SCDA_WAIT_VMCNT(L);
+        } else {
+            SCDA_WAIT_VMCNT(0);
+        }
+        __builtin_amdgcn_s_barrier();
+        const float *as = lds + buf * STAGE, *bs = as + BK * BM;
+        float a[2][TM][4], b[2][TN][4];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) OA::frag(as, wm * WM + i * 32, lr, lh, 0, a[0][i]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) OB::frag(bs, wn * WN + j * 32, lr, lh, 0, b[0][j]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) OA::frag(as, wm * WM + i * 32, lr, lh, 1, a[1][i]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) OB::frag(bs, wn * WN + j * 32, lr, lh, 1, b[1][j]);
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][i][t], b[q][j][t], acc[i][j], 0, 0, 0);
+        buf = (buf + 1) & (NST - 1);
+        nbuf = (nbuf + 1) & (NST - 1);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WN + j * 32 + lr;
+        if (n >= g.N) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * WM + i * 32 + frag_row(r, lane);
+                if (m >= g.M) continue;
+                float v = acc[i][j][r];
+                if (e.splits > 1) {
+                    e.ws[((size_t)tz * g.M + m) * g.N + n] = v;
+                } else {
+                    if (e.bias) v += e.bias_on_n ? e.bias[n] : e.bias[m];
+                    v = apply_act(v, e.act, e.slope);
+                    float *dst = e.out + (size_t)m * g.ldc + n;
+                    *dst = e.accumulate ? *dst + v : v;
+                }
+            }
+    }
+}
+
 // weight packing for conv_igemm*_kernel:  w[Cout][Cin][R]  ->  the GEMM's A operand; C = the reduced channel dim
 //   forward : M = Cout, C = Cin        dgrad : M = Cin, C = Cout
 //   C % 16 == 0 : out[K][mpad], k = ((c/16)*R + r)*16 + c%16, columns m >= M zero   (direct-to-LDS kernel)
@@ -648,15 +907,76 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float *__restric
 }
 
 // ----------------------------- host-side dispatch --------------------------
-static int pick_splits(long long tiles, int K, int want_blocks = 512) {
-    if (tiles >= 256) return 1;
-    int s = (int)((want_blocks + tiles - 1) / tiles);
-    int max_s = K / (BK * 4);  // at least 4 K-steps per split
+// Launch plan = (N-tile width, split-K count), chosen with a small occupancy model instead of fixed thresholds.
+// At these sizes a launch has only a few workgroups per CU, so WAVE QUANTISATION decides the speed: the direct-to-LDS
+// kernels keep 64 KB (128x128), 48 KB (128x64 / 64x128) or 32 KB (64x64) of LDS per workgroup = 2 / 3 / 4 resident per CU, a
+// CU needs >= 2 resident workgroups (2 waves per SIMD) to keep its MFMA pipe fed across the per-slab barrier, and a CU
+// that is left with ONE workgroup runs it at about half speed.  Measured: the conv3_2 weight gradient at 756 workgroups
+// (2.95 per CU -> a round of two, then a round of one) ran at 81 TFLOP/s, at 504 (one round of two) 101 TFLOP/s.
+//   time(plan) = flops / (model efficiency x 110 TFLOP/s) + split-K slab traffic (write + read) at 3 TB/s
+struct LaunchPlan { int bn, splits; };
+
+static int resident_per_cu(int bm, int bn) { return (bm == 128 && bn == 128) ? 2 : (bm == 64 && bn == 64) ? 4 : 3; }
+static double tile_efficiency(int bm, int bn) { return (bm == 128 && bn == 128) ? 1.0 : (bm == 64 && bn == 64) ? 0.85 : 0.94; }
+
+// time, in units of one workgroup running at full CU speed, for the busiest CU to finish c workgroups with p resident
+static double cu_rounds(int c, int p) {
+    double t = 0;
+    while (c > 0) {
+        const int r = c < p ? c : p;
+        t += r == 1 ? 2.0 : (double)r;
+        c -= r;
+    }
+    return t;
+}
+
+static double plan_cost(long long tiles, int splits, int bm, int bn, double flops, double out_bytes) {
+    const long long wgs = tiles * splits;
+    const double ideal = (double)wgs / 256.0;
+    const double eff = ideal / cu_rounds(cdiv(wgs, 256), resident_per_cu(bm, bn)) * tile_efficiency(bm, bn);
+    double t = flops / (eff * 110e12);
+    if (splits > 1) t += 2.0 * splits * out_bytes / 3e12;
+    return t;
+}
+
+// bn_lo..bn_hi: candidate N-tile widths (64 and/or 128); must_split: the kernel always writes slabs (weight gradient)
+static LaunchPlan plan_search(int M, int N, int K, int bm, bool allow64, bool allow128, bool must_split, size_t ws_bytes,
+                              int k_granule);
+
+// memoised per thread (the same ~60 shapes recur every iteration; launches come from the main and the autograd thread)
+static LaunchPlan plan_launch(int M, int N, int K, int bm, bool allow64, bool allow128, bool must_split, size_t ws_bytes,
+                              int k_granule) {
+    struct Key { int M, N, K, flags; size_t ws; };
+    struct Entry { Key k; LaunchPlan p; };
+    static thread_local std::vector<Entry> cache;
+    const Key key{M, N, K, bm | (allow64 << 8) | (allow128 << 9) | (must_split << 10) | (k_granule << 11), ws_bytes};
+    for (const Entry &e : cache)
+        if (e.k.M == key.M && e.k.N == key.N && e.k.K == key.K && e.k.flags == key.flags && e.k.ws == key.ws) return e.p;
+    const LaunchPlan p = plan_search(M, N, K, bm, allow64, allow128, must_split, ws_bytes, k_granule);
+    if (cache.size() < 512) cache.push_back(Entry{key, p});
+    return p;
+}
+
+static LaunchPlan plan_search(int M, int N, int K, int bm, bool allow64, bool allow128, bool must_split, size_t ws_bytes,
+                              int k_granule) {
+    const double flops = 2.0 * M * (double)N * K, out_bytes = (double)M * N * sizeof(float);
+    LaunchPlan best{allow128 ? 128 : 64, 1};
+    double best_t = 1e30;
+    int max_s = K / (k_granule * 4);   // at least 4 K-steps per split
     if (max_s < 1) max_s = 1;
-    if (s > max_s) s = max_s;
-    const int cap = tiles <= 2 ? 256 : 64;   // a single-tile weight gradient (conv1_1: 64x27) still has to fill 256 CUs
-    if (s > cap) s = cap;
-    return s < 1 ? 1 : s;
+    if (max_s > 256) max_s = 256;
+    while (max_s > 1 && (size_t)max_s * M * N * sizeof(float) > ws_bytes) --max_s;
+    for (int bn = 64; bn <= 128; bn += 64) {
+        if ((bn == 64 && !allow64) || (bn == 128 && !allow128)) continue;
+        const long long tiles = (long long)cdiv(M, bm) * cdiv(N, bn);
+        for (int sp = 1; sp <= max_s; ++sp) {
+            if (tiles * sp > 4096 && sp > 1) break;   // plenty of workgroups already: splitting only adds traffic
+            double t = plan_cost(tiles, sp, bm, bn, flops, out_bytes);
+            if (must_split && sp == 1) t += 2.0 * out_bytes / 3e12;
+            if (t < best_t) { best_t = t; best = LaunchPlan{bn, sp}; }
+        }
+    }
+    return best;
 }
 
 static int round_k_per_split(int K, int splits) {
@@ -665,28 +985,17 @@ static int round_k_per_split(int K, int splits) {
     return kps;
 }
 
-// N-tile width.  Measured per VGG layer (gpurun_out/conv_layers_v4.log, SCDA_CONV_BN=64|128 A/B): 64-pixel tiles win
-// ~9 % when the 128-wide grid has about one workgroup per CU (conv4_x: 256 tiles) -- twice the workgroups, no split-K;
-// with fewer tiles split-K on 128-wide tiles is better, with more (>= 2 per CU) the wider tile's reuse wins.
-static int pick_bn(int M, int N, int K) {
-    (void)K;
-    const int BMv = M <= 64 ? 64 : 128;
-    const long long t128 = (long long)cdiv(M, BMv) * cdiv(N, 128);
-    return (t128 >= 192 && t128 < 512) ? 64 : 128;
-}
-
 template <int KH, int KW, int S, bool DGRAD>
 static int launch_conv(const float *Wm, const float *X, const ConvGeom &g0, Epi e, float *ws, size_t ws_bytes,
                        hipStream_t st) {
     ConvGeom g = g0;
     const bool small_m = g.M <= 64;
     const int BMv = small_m ? 64 : 128;
-    int BNv = pick_bn(g.M, g.N, g.K);
     static const char *force = getenv("SCDA_CONV_BN");   // experiment knob: 64 | 128
-    if (force) BNv = atoi(force) == 64 ? 64 : 128;
-    const long long tiles = (long long)cdiv(g.M, BMv) * cdiv(g.N, BNv);
-    int splits = pick_splits(tiles, g.K);
-    while (splits > 1 && (size_t)splits * g.M * g.N * sizeof(float) > ws_bytes) --splits;
+    const int fbn = force ? (atoi(force) == 64 ? 64 : 128) : 0;
+    const LaunchPlan plan = plan_launch(g.M, g.N, g.K, BMv, fbn != 128, fbn != 64, false, ws_bytes, BK);
+    const int BNv = plan.bn;
+    int splits = plan.splits;
     g.k_per_split = round_k_per_split(g.K, splits);
     splits = cdiv(g.K, g.k_per_split);
     e.splits = splits;
@@ -721,9 +1030,7 @@ static int launch_wgrad(const float *dY, const float *X, WgradGeom g, float *dW,
                         size_t ws_bytes, hipStream_t st) {
     const bool small = g.M <= 64;
     const int BMv = small ? 64 : 128, BNv = (g.N <= 64) ? 64 : 128;
-    const long long tiles = (long long)cdiv(g.M, BMv) * cdiv(g.N, BNv);
-    int splits = pick_splits(tiles, g.K, 768);
-    while (splits > 1 && (size_t)splits * g.M * g.N * sizeof(float) > ws_bytes) --splits;
+    int splits = plan_launch(g.M, g.N, g.K, BMv, BNv == 64, BNv == 128, true, ws_bytes, 32).splits;
     if ((size_t)splits * g.M * g.N * sizeof(float) > ws_bytes) { set_error("conv wgrad: workspace too small"); return SCDA_EINVAL; }
     g.k_per_split = (round_k_per_split(g.K, splits) + 31) / 32 * 32;
     splits = cdiv(g.K, g.k_per_split);
@@ -739,11 +1046,20 @@ static int launch_wgrad(const float *dY, const float *X, WgradGeom g, float *dW,
         if (bk32) hipLaunchKernelGGL((conv_wgrad_kernel<BM_, BN_, KH, KW, S, 32>), grid, dim3(256), 0, st, dY, X, g, ws);   \
         else hipLaunchKernelGGL((conv_wgrad_kernel<BM_, BN_, KH, KW, S, 16>), grid, dim3(256), 0, st, dY, X, g, ws);        \
     } while (0)
-    if (small && BNv == 64) WGRAD_LAUNCH(64, 64);
+    static const bool no_glds = getenv("SCDA_WGRAD_NO_GLDS") != nullptr;   // A/B knob
+    const bool glds = !no_glds && g.a_vec4 && (g.dOHW.d % BK) == 0;
+#define WGRAD_GLDS_LAUNCH(BM_, BN_) hipLaunchKernelGGL((conv_wgrad_glds_kernel<BM_, BN_, KH, KW, S>), grid, dim3(256), 0, st, dY, X, g, ws)
+    if (glds) {
+        if (small && BNv == 64) WGRAD_GLDS_LAUNCH(64, 64);
+        else if (small) WGRAD_GLDS_LAUNCH(64, 128);
+        else if (BNv == 64) WGRAD_GLDS_LAUNCH(128, 64);
+        else WGRAD_GLDS_LAUNCH(128, 128);
+    } else if (small && BNv == 64) WGRAD_LAUNCH(64, 64);
     else if (small) WGRAD_LAUNCH(64, 128);
     else if (BNv == 64) WGRAD_LAUNCH(128, 64);
     else WGRAD_LAUNCH(128, 128);
 #undef WGRAD_LAUNCH
+#undef WGRAD_GLDS_LAUNCH
     prof_end(st);
     int rc = launch_status("conv_wgrad_kernel");
     if (rc) return rc;
@@ -773,7 +1089,7 @@ SCDA_API size_t scda_conv2d_workspace_bytes(int batch, int Cin, int IH, int IW, 
     size_t out_elems = (size_t)batch * Cout * OH * OW, in_elems = (size_t)batch * Cin * IH * IW;
     size_t w_elems = (size_t)Cout * Cin * KH * KW;
     size_t a = 8 * (out_elems > in_elems ? out_elems : in_elems);
-    size_t b = (w_elems <= 64 * 128 ? 256 : 64) * w_elems;
+    size_t b = (w_elems <= 128 * 128 * 9 ? 256 : 64) * w_elems;
     size_t cap = (size_t)256 << 20;  // slabs never need to exceed 256 MB: pick_splits shrinks to fit
     size_t need = (a > b ? a : b) * sizeof(float);
     if (need > cap) need = cap;
@@ -854,10 +1170,11 @@ SCDA_API int scda_gemm_hip(const float *A, const float *B, float *C, int M, int 
                            int accumulate, void *ws, size_t ws_bytes, void *stream) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) { set_error("scda_gemm_hip: bad arguments"); return SCDA_EINVAL; }
     hipStream_t st = as_stream(stream);
-    const int BMv = (M <= 64) ? 64 : 128, BNv = (N <= 64) ? 64 : 128;
-    const long long tiles = (long long)cdiv(M, BMv) * cdiv(N, BNv);
-    int splits = pick_splits(tiles, K);
-    while (splits > 1 && (size_t)splits * M * N * sizeof(float) > ws_bytes) --splits;
+    const int BMv = (M <= 64) ? 64 : 128;
+    // (FC6 dgrad: 784 128-wide tiles = 3.06 per CU, the busiest CU carries 4 -> the plan takes 64-wide tiles)
+    const LaunchPlan plan = plan_launch(M, N, K, BMv, true, N > 64, false, ldc == N ? ws_bytes : 0, BK);
+    const int BNv = plan.bn;
+    int splits = plan.splits;
     if (splits > 1 && ldc != N) { set_error("scda_gemm_hip: split-K needs ldc == N"); return SCDA_EINVAL; }
     GemmGeom g{M, N, K, lda, ldb, ldc, round_k_per_split(K, splits), zero_page(), cdiv(N, BNv), cdiv(M, BMv),
                xcd_swizzle_enabled()};
@@ -872,8 +1189,24 @@ SCDA_API int scda_gemm_hip(const float *A, const float *B, float *C, int M, int 
         else if (trans_a && !trans_b) hipLaunchKernelGGL((gemm_kernel<BM_, BN_, true, false>), grid, dim3(256), 0, st, A, B, g, e); \
         else hipLaunchKernelGGL((gemm_kernel<BM_, BN_, true, true>), grid, dim3(256), 0, st, A, B, g, e);  \
     } while (0)
+    // direct-to-LDS kernel: whole 16-deep slabs, 16-byte addressable rows
+    static const bool no_glds = getenv("SCDA_GEMM_NO_GLDS") != nullptr;   // A/B knob
+    const bool glds = !no_glds && (K % BK) == 0 && (lda % 4) == 0 && (ldb % 4) == 0 && ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0 &&
+                      (!trans_a || (M % 4) == 0) && (!trans_b || (N % 4) == 0);
+#define GEMM_GLDS_LAUNCH(BM_, BN_)                                                                       \
+    do {                                                                                                 \
+        if (!trans_a && !trans_b) hipLaunchKernelGGL((gemm_glds_kernel<BM_, BN_, false, false>), grid, dim3(256), 0, st, A, B, g, e); \
+        else if (!trans_a && trans_b) hipLaunchKernelGGL((gemm_glds_kernel<BM_, BN_, false, true>), grid, dim3(256), 0, st, A, B, g, e); \
+        else if (trans_a && !trans_b) hipLaunchKernelGGL((gemm_glds_kernel<BM_, BN_, true, false>), grid, dim3(256), 0, st, A, B, g, e); \
+        else hipLaunchKernelGGL((gemm_glds_kernel<BM_, BN_, true, true>), grid, dim3(256), 0, st, A, B, g, e);  \
+    } while (0)
     prof_begin(PK_GEMM, 2.0 * M * (double)N * K, st);
-    if (BMv == 64 && BNv == 64) GEMM_LAUNCH(64, 64);
+    if (glds) {
+        if (BMv == 64 && BNv == 64) GEMM_GLDS_LAUNCH(64, 64);
+        else if (BMv == 64) GEMM_GLDS_LAUNCH(64, 128);
+        else if (BNv == 64) GEMM_GLDS_LAUNCH(128, 64);
+        else GEMM_GLDS_LAUNCH(128, 128);
+    } else if (BMv == 64 && BNv == 64) GEMM_LAUNCH(64, 64);
     else if (BMv == 64) GEMM_LAUNCH(64, 128);
     else if (BNv == 64) GEMM_LAUNCH(128, 64);
     else GEMM_LAUNCH(128, 128);
