@@ -63,6 +63,20 @@ def _hip_nms(dets, thresh, max_keep=0):
     return host[: int(host[n])].clone()
 
 
+def host_array(x, copy=False):
+    """numpy view of `x` on the host.  Device tensors that were built from host data carry their host original along as
+    `_scda_host` (ground-truth boxes, sampled RoIs): reading that costs nothing, whereas `.cpu()` is a synchronous copy on
+    the compute stream -- the host would sit behind every kernel already queued (both backbone passes, ~8 ms)."""
+    if x is None:
+        return None
+    host = getattr(x, "_scda_host", None)
+    if host is not None:
+        return host.copy() if copy else host
+    if torch.is_tensor(x):
+        return x.detach().cpu().numpy()
+    return np.array(x) if copy else x
+
+
 def use(bbox_overlaps=None, nms=None):
     if bbox_overlaps is not None:
         _impl["bbox_overlaps"] = bbox_overlaps

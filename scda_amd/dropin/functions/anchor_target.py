@@ -6,13 +6,12 @@ positives, one for surplus negatives) so that seeded runs select the same anchor
 import numpy as np
 import torch
 
+from scda_amd.dropin import backend
 from scda_amd.dropin.utils import anchor_helper, bbox_helper
 
 
 def _np(x):
-    if x is None:
-        return None
-    return x.detach().cpu().numpy() if torch.is_tensor(x) else np.array(x)
+    return backend.host_array(x)
 
 
 def _to_dev(a, like):

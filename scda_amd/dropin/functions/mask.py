@@ -9,14 +9,11 @@ As in the reference the result is a NEW leaf tensor: no gradient flows back into
 import numpy as np
 import torch
 
+from scda_amd.dropin import backend
+
 
 def _np(x):
-    if x is None:
-        return None
-    host = getattr(x, "_scda_host", None)   # device tensors built from host data carry their host original along:
-    if host is not None:                    # no device->host copy (which would queue behind everything in flight)
-        return host
-    return x.detach().cpu().numpy() if torch.is_tensor(x) else x
+    return backend.host_array(x)
 
 
 def proposals_to_centers(proposals):

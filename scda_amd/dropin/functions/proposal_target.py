@@ -10,6 +10,7 @@ import logging
 import numpy as np
 import torch
 
+from scda_amd.dropin import backend
 from scda_amd.dropin.utils import bbox_helper
 
 logger = logging.getLogger('global')
@@ -17,9 +18,7 @@ history = [0, 0]
 
 
 def _np(x):
-    if x is None:
-        return None
-    return x.detach().cpu().numpy() if torch.is_tensor(x) else x
+    return backend.host_array(x)
 
 
 def compute_proposal_targets(proposals, cfg, ground_truth_bboxes, image_info, ignore_regions=None, use_ohem=False):

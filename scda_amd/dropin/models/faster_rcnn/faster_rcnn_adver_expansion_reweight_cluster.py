@@ -117,7 +117,9 @@ class FasterRCNN_AdEx(nn.Module):
         dev = image.device
         gts = input['ground_truth_bboxes']
         if torch.is_tensor(gts) and gts.device != dev:
-            gts = gts.to(dev)  # the targets are produced on the device the gts live on
+            gts_host = gts
+            gts = N.upload(gts_host, dev)  # the targets are produced on the device the gts live on
+            gts._scda_host = gts_host.numpy()   # ... and the host-side labelling reads the boxes without a device round trip
         fn = self._pin_args_to_fn(cfg, gts, input['image_info'], input['ignore_regions'])
         outputs = {'losses': [], 'predict': [], 'accuracy': []}
 
