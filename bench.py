@@ -61,6 +61,20 @@ def synth_batch(rank):
     return src, tgt, gts, torch.tensor([[H, W, 1.0]])
 
 
+def pmc_traffic():
+    """L2 memory-side bytes per launch of the dominant kernel.  PMC counters cannot be sampled from inside the timed
+    run; they come from the committed rocprofv3 passes of this same command (scripts/collect_profiles.sh ->
+    profiles/r01_pmc_traffic.json: `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` in separate passes, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  None when that file is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        return int(d["dominant"]["traffic_bytes_per_launch"]), "profiles/r01_pmc_traffic.json"
+    except Exception:
+        return None, None
+
+
 def cpu_baseline():
     """one full-size iteration of the CPU oracle on this box's host cores (bounded sample of the same workload)"""
     from oracle import torch_ref as R
@@ -153,11 +167,14 @@ def main():
         value = 2.0 * world * a.steps / dt
         roof = None
         if DOMINANT in prof:
-            n, tms, fl = prof[DOMINANT]
+            n, tms, fl, by = prof[DOMINANT]
             ach = fl / (tms * 1e-3) / 1e12
+            traffic, src = pmc_traffic()
             roof = {"bound": "mfma", "kernel": DOMINANT, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                    "launches": n, "avg_launch_ms": round(tms / n, 4), "gflop_per_launch": round(fl / n / 1e9, 2)}
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "traffic_unit": "bytes/launch (HBM+Infinity-Cache side of L2: 2*FETCH_SIZE + WRITE_SIZE)", "traffic_source": src,
+                    "algorithmic_bytes_per_launch": round(by / n), "launches": n, "avg_launch_ms": round(tms / n, 4),
+                    "gflop_per_launch": round(fl / n / 1e9, 2)}
         res = {
             "metric": "images/sec (fwd+bwd) VGG16 Faster-RCNN+SCDA 512x1024", "value": round(value, 3), "unit": "images/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,

@@ -43,11 +43,12 @@ const char *scda_last_error(void);
 /* launch profiler for the GEMM-class kernels: for every kernel class k whose bit is set in kernel_mask a hipEvent
  * pair is recorded on the launch stream around each launch of that kernel; after a device synchronisation
  * scda_prof_collect() fills, per class k in [0, scda_prof_num_kernels()), the number of launches, their summed
- * duration (ms) and algorithmic FLOPs.  (Event records are queue markers: keep the mask narrow inside timed regions.) */
+ * duration (ms), algorithmic FLOPs and (bytes may be NULL) algorithmic HBM bytes = operands read once + result written
+ * once.  (Event records are queue markers: keep the mask narrow inside timed regions.) */
 void scda_prof_enable(unsigned kernel_mask);
 int scda_prof_num_kernels(void);
 const char *scda_prof_kernel_name(int k);
-int scda_prof_collect(long long *launches, double *ms, double *flops);
+int scda_prof_collect(long long *launches, double *ms, double *flops, double *bytes);
 
 /* ---------------------------------------------------------------- NMS ---- */
 /* replaces  int gpu_nms(THLongTensor* keep, THLongTensor* num_out, THCudaTensor* boxes, float thresh)

@@ -51,7 +51,7 @@ const float *zero_page();
 //   conv_igemm_kernel<*> (the gather kernel of the layers whose channel count is not a multiple of 16): id = 16
 enum { PK_CONV = 0, PK_CONV_WGRAD = 12, PK_GEMM = 15, PK_CONV_GATHER = 16, PK_COUNT = 17 };
 static inline int prof_shape(int KH, int S) { return KH == 1 ? 2 : (S == 2 ? 1 : 0); }
-void prof_begin(int kernel, double flops, hipStream_t st);
+void prof_begin(int kernel, double flops, hipStream_t st, double bytes = 0.0);   // bytes: algorithmic HBM bytes of the launch
 void prof_end(hipStream_t st);
 
 }  // namespace scda

@@ -1003,7 +1003,8 @@ static int launch_conv(const float *Wm, const float *X, const ConvGeom &g0, Epi 
     g.nx = cdiv(g.N, BNv); g.ny = cdiv(g.M, BMv); g.swz = xcd_swizzle_enabled();
     dim3 grid((unsigned)g.nx * g.ny * splits);
     prof_begin(g.slab_aligned ? PK_CONV + ((DGRAD ? 2 : 0) + (small_m ? 1 : 0)) * 3 + prof_shape(KH, S) : (int)PK_CONV_GATHER,
-               2.0 * g.M * (double)g.N * g.K, st);
+               2.0 * g.M * (double)g.N * g.K, st,
+               4.0 * ((double)g.batch * g.CB * g.HB * g.WB + (double)g.M * g.K + (double)g.M * g.N));
     g.mpad = conv_packed_mpad(g.M);
 #define CONV_LAUNCH(BM_, BN_)                                                                                            \
     do {                                                                                                                 \

@@ -37,7 +37,7 @@ const float *zero_page() {
 }
 
 // ---- launch profiler (see common.h) ----------------------------------------
-struct ProfRec { int kernel; double flops; hipEvent_t a, b; };
+struct ProfRec { int kernel; double flops, bytes; hipEvent_t a, b; };
 static unsigned g_prof_mask = 0;  // bit k set: time launches of kernel class k
 static std::vector<ProfRec> g_prof;
 static std::vector<hipEvent_t> g_prof_pool;
@@ -48,10 +48,10 @@ static hipEvent_t prof_event() {
     return e;
 }
 static bool g_prof_open = false;
-void prof_begin(int kernel, double flops, hipStream_t st) {
+void prof_begin(int kernel, double flops, hipStream_t st, double bytes) {
     g_prof_open = (g_prof_mask >> kernel) & 1u;
     if (!g_prof_open) return;
-    ProfRec r{kernel, flops, prof_event(), prof_event()};
+    ProfRec r{kernel, flops, bytes, prof_event(), prof_event()};
     (void)hipEventRecord(r.a, st);
     g_prof.push_back(r);
 }
@@ -674,15 +674,16 @@ SCDA_API const char *scda_prof_kernel_name(int k) {
         "conv_igemm_glds_kernel<64,*,3,3,1,0>", "conv_igemm_glds_kernel<64,*,3,3,2,0>", "conv_igemm_glds_kernel<64,*,1,1,1,0>",
         "conv_igemm_glds_kernel<128,*,3,3,1,1>", "conv_igemm_glds_kernel<128,*,3,3,2,1>", "conv_igemm_glds_kernel<128,*,1,1,1,1>",
         "conv_igemm_glds_kernel<64,*,3,3,1,1>", "conv_igemm_glds_kernel<64,*,3,3,2,1>", "conv_igemm_glds_kernel<64,*,1,1,1,1>",
-        "conv_wgrad_kernel<*,*,3,3,1>", "conv_wgrad_kernel<*,*,3,3,2>", "conv_wgrad_kernel<*,*,1,1,1>", "gemm_kernel<*>", "conv_igemm_kernel<*>"};
+        "conv_wgrad_glds_kernel<*,*,3,3,1>", "conv_wgrad_glds_kernel<*,*,3,3,2>", "conv_wgrad_glds_kernel<*,*,1,1,1>", "gemm_glds_kernel<*>", "conv_igemm_kernel<*>"};
     return (k >= 0 && k < PK_COUNT) ? names[k] : "";
 }
-SCDA_API int scda_prof_collect(long long *launches, double *ms, double *flops) {
-    for (int k = 0; k < PK_COUNT; ++k) { launches[k] = 0; ms[k] = 0; flops[k] = 0; }
+SCDA_API int scda_prof_collect(long long *launches, double *ms, double *flops, double *bytes) {
+    for (int k = 0; k < PK_COUNT; ++k) { launches[k] = 0; ms[k] = 0; flops[k] = 0; if (bytes) bytes[k] = 0; }
     for (auto &r : g_prof) {
         float t = 0.f;
         if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) {
             launches[r.kernel] += 1; ms[r.kernel] += t; flops[r.kernel] += r.flops;
+            if (bytes) bytes[r.kernel] += r.bytes;
         } else {
             (void)hipGetLastError();
         }

@@ -609,15 +609,17 @@ def prof_enable(kernels):
 
 
 def prof_collect():
-    """after torch.cuda.synchronize(): {kernel name: (launches, total_ms, total_flops)} for kernels that ran"""
+    """after torch.cuda.synchronize(): {kernel name: (launches, total_ms, total_flops, total_algorithmic_bytes)} for the
+    kernel classes that ran"""
     L = lib()
     L.scda_prof_kernel_name.restype = ctypes.c_char_p
     n = L.scda_prof_num_kernels()
     launches = (ctypes.c_longlong * n)()
     ms = (ctypes.c_double * n)()
     fl = (ctypes.c_double * n)()
-    _check(L.scda_prof_collect(launches, ms, fl), "scda_prof_collect")
-    return {L.scda_prof_kernel_name(i32(k)).decode(): (int(launches[k]), float(ms[k]), float(fl[k]))
+    by = (ctypes.c_double * n)()
+    _check(L.scda_prof_collect(launches, ms, fl, by), "scda_prof_collect")
+    return {L.scda_prof_kernel_name(i32(k)).decode(): (int(launches[k]), float(ms[k]), float(fl[k]), float(by[k]))
             for k in range(n) if launches[k] > 0}
 
 

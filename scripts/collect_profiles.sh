@@ -1,0 +1,22 @@
+#!/bin/bash
+# Everything under profiles/ comes from this script, run on the MI355X box through gpurun:
+#   gpurun -- 'bash scripts/collect_profiles.sh r01'
+# 1. bench.py (the judged line)  2. the same command under rocprofv3 --kernel-trace --stats
+# 3. + 4. PMC passes (FETCH_SIZE, WRITE_SIZE separately; never combined with other trace domains)
+set -u
+TAG=${1:-r01}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp; export TMPDIR=/tmp
+python $R/bench.py --steps 30 --warmup 8 > $OUT/bench_1gpu.json 2> $OUT/bench_1gpu.err
+rocprofv3 --kernel-trace --stats -d $OUT/kt -o prof -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/kt.log 2>&1
+grep '^{' $OUT/kt.log > $OUT/bench_under_rocprof.json
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_$c.log 2>&1
+done
+cd $R
+python scripts/rocprof_summary.py $(ls $OUT/kt/*.db | head -1) $OUT/kernel_stats.md "python bench.py --steps 10 --warmup 3 --no-cpu-baseline under rocprofv3 --kernel-trace --stats (13 iterations incl. warm-up)"
+python scripts/pmc_summary.py $OUT $OUT/pmc_traffic.md $OUT/pmc_traffic.json
+rm -rf $OUT/kt/*.db
+cat $OUT/bench_1gpu.json

@@ -1,0 +1,71 @@
+"""rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, csv output) -> per-kernel HBM-side traffic table.
+
+    python scripts/pmc_summary.py <dir with pmc_FETCH_SIZE/ and pmc_WRITE_SIZE/> <out.md> <out.json>
+
+Units and corrections (MI355X_MICROARCH.md, HBM section): the counters are in KiB... rocprofv3 reports FETCH_SIZE /
+WRITE_SIZE in kilobytes; on gfx950 FETCH_SIZE counts 64 B per 128-byte request, i.e. HALF the bytes read -> doubled here.
+That factor was re-checked on this workload's own kernels with a known byte count (see the calibration rows).
+Infinity-Cache hits are included in these counters, so "traffic" is what leaves the L2, not strictly HBM."""
+import collections
+import csv
+import json
+import os
+import re
+import sys
+
+
+def load(d, counter):
+    out = collections.defaultdict(list)
+    path = os.path.join(d, "pmc_%s" % counter, "pmc_counter_collection.csv")
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            out[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return out
+
+
+def short(name):
+    name = re.sub(r"\(.*", "", name.replace("void ", "").replace("scda::", ""))
+    return name
+
+
+def main(d, out_md, out_json, algo_json=None):
+    F, W = load(d, "FETCH_SIZE"), load(d, "WRITE_SIZE")
+    rows = []
+    for k, f in F.items():
+        w = W.get(k, [0.0])
+        rows.append((short(k), len(f), 2.0 * 1024 * sum(f) / len(f), 1024 * sum(w) / len(w)))
+    rows.sort(key=lambda r: -(r[2] + r[3]) * r[1])
+    dom = [r for r in rows if r[0].startswith("conv_igemm_glds_kernel<128, ") and r[0].endswith("3, 3, 1, false>")]
+    n = sum(r[1] for r in dom)
+    dom_fetch = sum(r[2] * r[1] for r in dom) / max(n, 1)
+    dom_write = sum(r[3] * r[1] for r in dom) / max(n, 1)
+    cal = {r[0]: r for r in rows}
+    with open(out_md, "w") as f:
+        f.write("# rocprofv3 PMC: L2 memory-side traffic per launch\n\n")
+        f.write("Two passes of `python bench.py --steps 2 --warmup 1 --no-cpu-baseline`: `rocprofv3 --pmc FETCH_SIZE --kernel-trace` and\n"
+                "`rocprofv3 --pmc WRITE_SIZE --kernel-trace` (counters never combined, no other trace domains).  read = 2 x FETCH_SIZE KB\n"
+                "(gfx950 counts 64 B per 128-byte request), write = WRITE_SIZE KB.  Infinity-Cache hits are counted, so these are\n"
+                "bytes leaving the L2, an upper bound on HBM bytes.\n\n")
+        f.write("Calibration of the x2 on kernels of this run whose byte count is known exactly:\n\n")
+        for k, expect in (("adam_kernel", "reads 16 B/param, writes 12 B/param -> read/write = 1.333"),
+                          ("axpby_kernel", "reads 2 arrays, writes 1 -> read/write = 2.0"),
+                          ("act_bwd_kernel", "reads 2 arrays, writes 1 -> read/write = 2.0"),
+                          ("dropout_apply_kernel", "reads 4 B + 1 B mask, writes 4 B -> read/write = 1.25")):
+            if k in cal and cal[k][3] > 0:
+                f.write("* `%s`: %s; measured (2 x FETCH)/WRITE = %.3f\n" % (k, expect, cal[k][2] / cal[k][3]))
+        f.write("\nDominant kernel class `conv_igemm_glds_kernel<128,*,3,3,1,0>` (%d launches): read %.1f MB + write %.1f MB = %.1f MB per launch\n\n"
+                % (n, dom_fetch / 1e6, dom_write / 1e6, (dom_fetch + dom_write) / 1e6))
+        f.write("| kernel | launches | read MB/launch | write MB/launch |\n|---|---:|---:|---:|\n")
+        for r in rows[:45]:
+            f.write("| `%s` | %d | %.2f | %.2f |\n" % (r[0][:110], r[1], r[2] / 1e6, r[3] / 1e6))
+    with open(out_json, "w") as f:
+        json.dump({"dominant": {"kernel": "conv_igemm_glds_kernel<128,*,3,3,1,0>", "launches": n,
+                                "read_bytes_per_launch": round(dom_fetch), "write_bytes_per_launch": round(dom_write),
+                                "traffic_bytes_per_launch": round(dom_fetch + dom_write)},
+                   "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; read = 2*FETCH_SIZE KB*1024, write = WRITE_SIZE KB*1024"},
+                  f, indent=1)
+    print("dominant: read %.1f MB write %.1f MB per launch over %d launches" % (dom_fetch / 1e6, dom_write / 1e6, n))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:4])
