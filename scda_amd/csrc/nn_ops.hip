@@ -163,14 +163,25 @@ __global__ __launch_bounds__(256) void bias_grad_finish_kernel(const float *__re
     db[c] = accumulate ? db[c] + s : s;
 }
 
-// db[n] (+)= sum_m dy[m][n]    (linear bias): one thread per column, rows in order
+// db[n] (+)= sum_m dy[m][n]    (linear bias).  Workgroup = 32 columns x 8 row groups: thread (g, c) sums rows g, g+8, ...
+// of its column (128-byte coalesced row segments), the 8 partial sums are added in fixed order.  (One thread per column
+// put 4096 columns on 16 workgroups: 80 us for a 8 MB read.)
 __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ dy, float *__restrict__ db, const int M,
                                                      const int N, const int accumulate) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
+    __shared__ float part[8][33];
+    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int n = blockIdx.x * 32 + c;
     float s = 0.f;
-    for (int m = 0; m < M; ++m) s += dy[(size_t)m * N + n];
-    db[n] = accumulate ? db[n] + s : s;
+    if (n < N)
+        for (int m = g; m < M; m += 8) s += dy[(size_t)m * N + n];
+    part[g][c] = s;
+    __syncthreads();
+    if (g == 0 && n < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t += part[i][c];
+        db[n] = accumulate ? db[n] + t : t;
+    }
 }
 
 // ------------------------------------------- soft-max cross entropy (mean) --
@@ -729,7 +740,7 @@ SCDA_API int scda_bias_grad_nchw_hip(const float *dy, float *db, int B, int C, i
 
 SCDA_API int scda_colsum_hip(const float *dy, float *db, int M, int N, int accumulate, void *stream) {
     NN_CHECK(dy && db && M > 0 && N > 0, "scda_colsum_hip")
-    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 256)), dim3(256), 0, as_stream(stream), dy, db, M, N, accumulate);
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 32)), dim3(256), 0, as_stream(stream), dy, db, M, N, accumulate);
     return launch_status("colsum_kernel");
 }
 

@@ -212,6 +212,25 @@ class FasterRCNN_AdEx(nn.Module):
         return outputs
 
 
+def _two_branches(module, fa, fb):
+    """run the independent A / B halves of a GAN module: sequentially (default, as the reference does), or -- when the
+    owner set `module.branch_stream` (scda_amd.train_step does) -- B on that second HIP stream.  The decoder / discriminator
+    convolutions are batch-4 launches of 0.5-1 workgroup per CU; two of them side by side fill the chip.  The autograd engine
+    replays each half's backward on the stream its forward ran on and orders the streams at the graph edges; the two halves
+    own disjoint parameters (disjoint slices of the flat gradient bucket)."""
+    side = getattr(module, 'branch_stream', None)
+    if side is None:
+        return fa(), fb()
+    main = torch.cuda.current_stream()
+    side.wait_stream(main)
+    a = fa()                       # A first: the host-side order (dropout mask draws) stays the reference's A-then-B
+    with torch.cuda.stream(side):
+        b = fb()
+    main.wait_stream(side)
+    b.record_stream(main)
+    return a, b
+
+
 class GAN_dis_AE(nn.Module):
     """two image discriminators (A: source crops, B: target crops): n_layer stride-2 LeakyReLU convs + 1x1 -> 1"""
 
@@ -232,8 +251,7 @@ class GAN_dis_AE(nn.Module):
         return nn.Sequential(*seq)
 
     def forward(self, x_aa, x_bb):
-        a = self.model_A(x_aa)
-        b = self.model_B(x_bb)
+        a, b = _two_branches(self, lambda: self.model_A(x_aa), lambda: self.model_B(x_bb))
         return a.view(a.size(0), -1), b.view(b.size(0), -1)
 
 
@@ -283,4 +301,4 @@ class GAN_decoder_AE(nn.Module):
         self.decode_A.apply(gaussian_weights_init)
 
     def forward(self, x_aa, x_bb):
-        return self.decode_A(x_aa), self.decode_B(x_bb)
+        return _two_branches(self, lambda: self.decode_A(x_aa), lambda: self.decode_B(x_bb))

@@ -29,14 +29,16 @@ def cpu_quota():
 
 
 def configure_host_threads(torch_threads=None):
-    """idempotent; torch intra-op threads -> min(4, quota) unless SCDA_TORCH_THREADS overrides; numpy/scipy/sklearn pools -> 1"""
+    """idempotent; torch intra-op threads -> min(4, quota / ranks on this node) unless SCDA_TORCH_THREADS overrides;
+    numpy/scipy/sklearn pools -> 1.  (With 8 ranks inside one 16-CPU quota every rank gets 2: main thread + autograd thread.)"""
     if _done:
         return
     _done.append(True)
     if os.environ.get("SCDA_KEEP_HOST_THREADS"):
         return
     import torch
-    n = torch_threads or int(os.environ.get("SCDA_TORCH_THREADS", "0")) or min(4, cpu_quota() or 4)
+    ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")) or 1))
+    n = torch_threads or int(os.environ.get("SCDA_TORCH_THREADS", "0")) or max(1, min(4, (cpu_quota() or 4 * ranks) // ranks))
     if torch.get_num_threads() > n:
         torch.set_num_threads(n)
     from .dropin.functions.mask import _limit_host_pools_once

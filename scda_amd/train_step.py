@@ -14,6 +14,8 @@ Each model's parameters and gradients live in one flat fp32 bucket (scda_amd.fla
 one RCCL all-reduce per phase.  With world_size > 1 the all-reduces of phases 1-3 are launched asynchronously and
 waited for just before the corresponding optimiser step.
 """
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -123,9 +125,24 @@ class ScdaTrainer:
         # scheduling: detector backward enqueued as soon as its losses exist; target branch on a high-priority side stream
         self.early_backward = True
         self.side = torch.cuda.Stream(device=device, priority=-1) if device.type == "cuda" else None
+        # the B halves of the decoder / image discriminator run beside their A halves (SCDA_AB_STREAMS=0: one stream)
+        if device.type == "cuda" and os.environ.get("SCDA_AB_STREAMS", "1") != "0":
+            self.branch = torch.cuda.Stream(device=device)
+            self.dec.branch_stream = self.branch
+            self.dis.branch_stream = self.branch
+        else:
+            self.branch = None
 
     # ------------------------------------------------------------------
+    def _join_branch(self):
+        """The B halves' backward kernels accumulate straight into the flat gradient bucket on the branch stream; autograd
+        sees no leaf gradient there (autograd_ops._sink hands it None), so ITS end-of-backward stream sync does not cover
+        them: order the compute stream behind the branch stream before anything reads the bucket."""
+        if self.branch is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self.branch)
+
     def _reduce(self, module, async_op):
+        self._join_branch()
         if self.capture:
             name = {id(self.model): 'det', id(self.dec): 'dec', id(self.dis): 'dis', id(self.dis_patch): 'dis_patch'}[id(module)]
             self.trace[name] = {k: p.grad.detach().clone() for k, p in module.named_parameters()}
