@@ -881,28 +881,53 @@ __host__ __device__ inline int conv_packed_mpad(int M) { return M <= 64 ? 64 : (
 
 __global__ __launch_bounds__(256) void pack_weight_kernel(const float *__restrict__ w, float *__restrict__ out,
                                                           const int Cout, const int Cin, const int R,
-                                                          const int for_dgrad) {
+                                                          const int for_dgrad, const long long total);
+
+// all conv weights of one optimiser group in ONE launch (after its Adam step): desc[j] = {source offset (floats, from
+// `base`), destination offset (floats, from `out`), Cout, Cin, R, for_dgrad}, destinations ascending and contiguous
+__device__ __forceinline__ float packed_weight_elem(const float *__restrict__ w, const long long idx, const int Cout,
+                                                    const int Cin, const int R, const int for_dgrad) {
     const int C = for_dgrad ? Cout : Cin, M = for_dgrad ? Cin : Cout;
     const bool blocked = (C % BK) == 0;
     const int mpad = blocked ? conv_packed_mpad(M) : M;
-    const long long K = (long long)C * R, total = K * mpad;
+    const long long K = (long long)C * R;
+    int k, m, c, r;
+    if (blocked) {
+        m = (int)(idx % mpad);
+        k = (int)(idx / mpad);
+        const int sl = k / BK, cb = sl / R;
+        r = sl - cb * R;
+        c = cb * BK + (k & (BK - 1));
+    } else {
+        k = (int)(idx % K);
+        m = (int)(idx / K);
+        r = k / C;
+        c = k - r * C;
+    }
+    const int co = for_dgrad ? c : m, ci = for_dgrad ? m : c;
+    return m < M ? w[((size_t)co * Cin + ci) * R + r] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float *__restrict__ w, float *__restrict__ out,
+                                                          const int Cout, const int Cin, const int R,
+                                                          const int for_dgrad, const long long total) {
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)blockDim.x * gridDim.x)
+        out[idx] = packed_weight_elem(w, idx, Cout, Cin, R, for_dgrad);
+}
+
+__global__ __launch_bounds__(256) void pack_weights_batched_kernel(const float *__restrict__ base, float *__restrict__ out,
+                                                                   const long long *__restrict__ desc, const int n,
+                                                                   const long long total) {
     for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
          idx += (long long)blockDim.x * gridDim.x) {
-        int k, m, c, r;
-        if (blocked) {
-            m = (int)(idx % mpad);
-            k = (int)(idx / mpad);
-            const int sl = k / BK, cb = sl / R;
-            r = sl - cb * R;
-            c = cb * BK + (k & (BK - 1));
-        } else {
-            k = (int)(idx % K);
-            m = (int)(idx / K);
-            r = k / C;
-            c = k - r * C;
+        int lo = 0, hi = n - 1;   // last descriptor whose destination offset is <= idx
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (desc[mid * 6 + 1] <= idx) lo = mid; else hi = mid - 1;
         }
-        const int co = for_dgrad ? c : m, ci = for_dgrad ? m : c;
-        out[idx] = m < M ? w[((size_t)co * Cin + ci) * R + r] : 0.f;
+        const long long *d = desc + lo * 6;
+        out[idx] = packed_weight_elem(base + d[0], idx - d[1], (int)d[2], (int)d[3], (int)d[4], (int)d[5]);
     }
 }
 
@@ -1141,8 +1166,15 @@ SCDA_API int scda_conv2d_pack_weight_hip(const float *w, float *out, int Cout, i
     if (!w || !out || Cout <= 0 || Cin <= 0) { set_error("scda_conv2d_pack_weight_hip: bad arguments"); return SCDA_EINVAL; }
     const long long total = (long long)scda_conv2d_packed_elems(Cout, Cin, KH, KW, for_dgrad);
     hipLaunchKernelGGL(pack_weight_kernel, dim3(ew_grid(total)), dim3(256), 0, as_stream(stream), w, out, Cout, Cin, KH * KW,
-                       for_dgrad);
+                       for_dgrad, total);
     return launch_status("pack_weight_kernel");
+}
+
+SCDA_API int scda_conv2d_pack_weights_batched_hip(const float *base, float *out, const long long *desc, int n,
+                                                  long long total, void *stream) {
+    if (!base || !out || !desc || n <= 0 || total <= 0) { set_error("scda_conv2d_pack_weights_batched_hip: bad arguments"); return SCDA_EINVAL; }
+    hipLaunchKernelGGL(pack_weights_batched_kernel, dim3(ew_grid(total)), dim3(256), 0, as_stream(stream), base, out, desc, n, total);
+    return launch_status("pack_weights_batched_kernel");
 }
 
 SCDA_API int scda_conv2d_wgrad_hip(const float *dy, const float *x, float *dw, int batch, int Cin, int IH, int IW,

@@ -37,6 +37,10 @@ class FlatParams:
         for p in params:
             p._scda_flat = self
         module._scda_flat = self
+        # conv weights whose GEMM-ready copies are rebuilt in one launch after every optimiser step (native.conv2d_pack_all)
+        self.conv_weights = [m.weight for m in module.modules()
+                             if isinstance(m, torch.nn.Conv2d) and m.weight.requires_grad and m.weight.is_cuda
+                             and tuple(m.weight.shape[2:]) in ((3, 3), (1, 1))]
 
     def zero_grad(self):
         self.grad.zero_()
@@ -67,3 +71,4 @@ class FlatAdam:
         N.adam_step(self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, lr, self.betas[0], self.betas[1],
                     self.eps, self.weight_decay, self.step_count)
         self.flat.epoch += 1   # the kernel wrote through raw pointers: packed-weight caches of this bucket are stale
+        N.conv2d_pack_all(self.flat)   # ... and are rebuilt right here, all layers and both directions in one launch
