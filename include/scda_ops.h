@@ -154,6 +154,14 @@ int scda_conv2d_dgrad_hip(const float *dy, const float *wt, float *dx, int batch
 /* dw [Cout,Cin,KH,KW] (+)= sum over batch and pixels; deterministic split-K (no atomics) */
 int scda_conv2d_wgrad_hip(const float *dy, const float *x, float *dw, int batch, int Cin, int IH, int IW, int Cout,
                           int KH, int KW, int S, int P, int accumulate, void *ws, size_t ws_bytes, void *stream);
+/* the same plus the bias gradient db[Cout] (+)= sum over batch and pixels of dy, fused: the row sums ride along on the
+ * operand fragments of the weight-gradient GEMM and are finished by its split-K reduce (no extra launches, no second read
+ * of dy).  Only when scda_conv2d_wgrad_bias_fusable(...) != 0 (OH*OW % 16 == 0, 16-byte aligned dy); otherwise call
+ * scda_conv2d_wgrad_hip + scda_bias_grad_nchw_hip. */
+int scda_conv2d_wgrad_bias_fusable(int batch, int Cout, int OH, int OW, const float *dy);
+int scda_conv2d_wgrad_bias_hip(const float *dy, const float *x, float *dw, float *db, int batch, int Cin, int IH, int IW,
+                               int Cout, int KH, int KW, int S, int P, int accumulate, int db_accumulate, void *ws,
+                               size_t ws_bytes, void *stream);
 
 /* C[M,N] (row stride ldc) (+)= op(A) op(B) (+ bias) -> act
  * trans_a = 0: A is [M,K] row-major (lda);  1: A is stored [K,M]

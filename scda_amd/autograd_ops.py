@@ -51,12 +51,18 @@ class Conv2dFn(Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = N.conv2d_dgrad(dy, w, x.shape, stride, pad)
-        if ctx.needs_input_grad[1]:
+        want_w, want_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        if want_w and want_b:   # one pass: the bias gradient is fused into the weight-gradient kernel where the shape allows
+            sw, sb = _sink(ctx.w_ref), _sink(ctx.bias_ref)
+            dw, db = N.conv2d_wgrad_bias(dy, x, w.shape, stride, pad, out=sw, db_out=sb)
+            dw = None if sw is not None else dw
+            db = None if sb is not None else db
+        elif want_w:
             sink = _sink(ctx.w_ref)
             dw = N.conv2d_wgrad(dy, x, w.shape, stride, pad, out=sink)
             if sink is not None:
                 dw = None
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        elif want_b:
             sink = _sink(ctx.bias_ref)
             db = N.bias_grad_nchw(dy, out=sink)
             if sink is not None:

@@ -553,7 +553,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
 //       slab for all 8 of its instructions and decodes (oy, ox) + the 9-bit tap-validity mask once per slab.
 template <int BM, int BN, int KH, int KW, int S>
 __global__ __launch_bounds__(256) void conv_wgrad_glds_kernel(const float *__restrict__ dY, const float *__restrict__ X,
-                                                              const WgradGeom g, float *__restrict__ ws) {
+                                                              const WgradGeom g, float *__restrict__ ws,
+                                                              float *__restrict__ db_ws) {
     using OA = GldsOperand<BM, false>;
     using OB = GldsOperand<BN, false>;   // fragment reader only; staging is the gather below
     constexpr int NST = 4, STAGE = BK * (BM + BN);
@@ -611,6 +612,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_glds_kernel(const float *__res
     f32x16 acc[TM][TN];
     zero_acc<BM, BN>(acc);
     const int lr = lane & 31, lh = lane >> 5;
+    // the workgroups of the first N-tile also produce db[m] = sum over pixels of dY[m][.] (one partial per K-split)
+    const bool bias_rows = db_ws != nullptr && tx == 0 && wn == 0;
+    float rs[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) rs[i] = 0.f;
     if (s_begin < s_end) issue(s_begin, 0);
     if (s_begin + 1 < s_end) issue(s_begin + 1, 1);
     int buf = 0, nbuf = 2;
@@ -632,6 +638,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_glds_kernel(const float *__res
             for (int i = 0; i < TM; ++i) OA::frag(as, wm * WM + i * 32, lr, lh, q, a[q][i]);
 #pragma unroll
             for (int j = 0; j < TN; ++j) OB::frag(bs, wn * WN + j * 32, lr, lh, q, b[q][j]);
+        }
+        if (bias_rows) {   // fused bias gradient: row sums of dY ride along on the fragments this lane holds anyway
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) rs[i] += (a[q][i][0] + a[q][i][1]) + (a[q][i][2] + a[q][i][3]);
         }
 #pragma unroll
         for (int q = 0; q < 2; ++q)
@@ -657,6 +669,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_glds_kernel(const float *__res
                 if (m < g.M) ws[((size_t)tz * g.M + m) * g.N + n] = acc[i][j][r];
             }
     }
+    if (bias_rows) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const float t = rs[i] + __shfl_xor(rs[i], 32);   // lanes h = 0 and h = 1 hold the two K halves of a row
+            const int m = m0 + wm * WM + i * 32 + lr;
+            if (lh == 0 && m < g.M) db_ws[(size_t)tz * g.M + m] = t;
+        }
+    }
 }
 
 // out[idx] = (accumulate ? out[idx] : 0) + sum_s ws[s][idx] (+ bias[col]) -> act
@@ -664,7 +684,10 @@ __global__ __launch_bounds__(256) void dense_splitk_reduce_kernel(const float *_
                                                                   const long long total, const int N,
                                                                   const float *__restrict__ bias, const int bias_on_n,
                                                                   const int act, const float slope,
-                                                                  const int accumulate, float *__restrict__ out) {
+                                                                  const int accumulate, float *__restrict__ out,
+                                                                  const float *__restrict__ db_ws = nullptr,
+                                                                  float *__restrict__ db = nullptr, const int db_n = 0,
+                                                                  const int db_accumulate = 0) {
     for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
          idx += (long long)blockDim.x * gridDim.x) {
         float v = 0.f;
@@ -672,6 +695,13 @@ __global__ __launch_bounds__(256) void dense_splitk_reduce_kernel(const float *_
         if (bias) v += bias_on_n ? bias[idx % N] : bias[idx / N];
         v = apply_act(v, act, slope);
         out[idx] = accumulate ? out[idx] + v : v;
+    }
+    if (db_ws) {   // second, tiny job of the same launch: db[m] (+)= sum over splits of the fused bias-gradient partials
+        for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < db_n; m += blockDim.x * gridDim.x) {
+            float v = 0.f;
+            for (int s = 0; s < splits; ++s) v += db_ws[(size_t)s * db_n + m];
+            db[m] = db_accumulate ? db[m] + v : v;
+        }
     }
 }
 
@@ -1053,7 +1083,12 @@ static int launch_conv(const float *Wm, const float *X, const ConvGeom &g0, Epi 
 
 template <int KH, int KW, int S>
 static int launch_wgrad(const float *dY, const float *X, WgradGeom g, float *dW, int accumulate, float *ws,
-                        size_t ws_bytes, hipStream_t st) {
+                        size_t ws_bytes, hipStream_t st, float *db = nullptr, int db_accumulate = 0) {
+    if (db) {   // room for the bias-gradient partials [splits <= 256][M] behind the slabs
+        const size_t need = (size_t)256 * g.M * sizeof(float);
+        if (ws_bytes <= 2 * need) { set_error("conv wgrad: workspace too small for the fused bias gradient"); return SCDA_EINVAL; }
+        ws_bytes -= need;
+    }
     const bool small = g.M <= 64;
     const int BMv = small ? 64 : 128, BNv = (g.N <= 64) ? 64 : 128;
     int splits = plan_launch(g.M, g.N, g.K, BMv, BNv == 64, BNv == 128, true, ws_bytes, 32).splits;
@@ -1074,7 +1109,9 @@ static int launch_wgrad(const float *dY, const float *X, WgradGeom g, float *dW,
     } while (0)
     static const bool no_glds = getenv("SCDA_WGRAD_NO_GLDS") != nullptr;   // A/B knob
     const bool glds = !no_glds && g.a_vec4 && (g.dOHW.d % BK) == 0;
-#define WGRAD_GLDS_LAUNCH(BM_, BN_) hipLaunchKernelGGL((conv_wgrad_glds_kernel<BM_, BN_, KH, KW, S>), grid, dim3(256), 0, st, dY, X, g, ws)
+    if (db && !glds) { set_error("conv wgrad: the fused bias gradient needs OH*OW %% 16 == 0 and 16-byte aligned dy"); return SCDA_EINVAL; }
+    float *db_ws = db ? ws + (size_t)splits * g.M * g.N : nullptr;
+#define WGRAD_GLDS_LAUNCH(BM_, BN_) hipLaunchKernelGGL((conv_wgrad_glds_kernel<BM_, BN_, KH, KW, S>), grid, dim3(256), 0, st, dY, X, g, ws, db_ws)
     if (glds) {
         if (small && BNv == 64) WGRAD_GLDS_LAUNCH(64, 64);
         else if (small) WGRAD_GLDS_LAUNCH(64, 128);
@@ -1091,7 +1128,7 @@ static int launch_wgrad(const float *dY, const float *X, WgradGeom g, float *dW,
     if (rc) return rc;
     const long long total = (long long)g.M * g.N;
     hipLaunchKernelGGL(dense_splitk_reduce_kernel, dim3(ew_grid(total)), dim3(256), 0, st, ws, splits, total, g.N,
-                       (const float *)nullptr, 0, (int)ACT_NONE, 0.f, accumulate, dW);
+                       (const float *)nullptr, 0, (int)ACT_NONE, 0.f, accumulate, dW, (const float *)db_ws, db, g.M, db_accumulate);
     return launch_status("dense_splitk_reduce_kernel");
 }
 
@@ -1190,6 +1227,26 @@ SCDA_API int scda_conv2d_wgrad_hip(const float *dy, const float *x, float *dw, i
     g.zp = zero_page();
     if (!g.zp) { set_error("scda_conv2d_wgrad_hip: could not allocate the zero page"); return SCDA_ELAUNCH; }
     CONV_DISPATCH(launch_wgrad, > (dy, x, g, dw, accumulate, (float *)ws, ws_bytes, as_stream(stream)))
+}
+
+SCDA_API int scda_conv2d_wgrad_bias_fusable(int batch, int Cout, int OH, int OW, const float *dy) {
+    (void)batch; (void)Cout;
+    return ((OH * OW) % BK) == 0 && (((uintptr_t)dy) & 15) == 0 && !getenv("SCDA_WGRAD_NO_GLDS") && !getenv("SCDA_WGRAD_NO_BIAS_FUSE");
+}
+
+SCDA_API int scda_conv2d_wgrad_bias_hip(const float *dy, const float *x, float *dw, float *db, int batch, int Cin, int IH,
+                                        int IW, int Cout, int KH, int KW, int S, int P, int accumulate, int db_accumulate,
+                                        void *ws, size_t ws_bytes, void *stream) {
+    if (!dy || !x || !dw || !db || !ws) { set_error("scda_conv2d_wgrad_bias_hip: bad arguments"); return SCDA_EINVAL; }
+    const int OH = conv_out_dim(IH, KH, S, P), OW = conv_out_dim(IW, KW, S, P);
+    WgradGeom g;
+    g.batch = batch; g.Cin = Cin; g.IH = IH; g.IW = IW; g.Cout = Cout; g.OH = OH; g.OW = OW; g.pad = P;
+    g.M = Cout; g.N = Cin * KH * KW; g.K = batch * OH * OW; g.k_per_split = 0;
+    g.dOHW = Div(OH * OW); g.dOW = Div(OW);
+    g.a_vec4 = ((OH * OW) % 4) == 0 && (((uintptr_t)dy) & 15) == 0;
+    g.zp = zero_page();
+    if (!g.zp) { set_error("scda_conv2d_wgrad_bias_hip: could not allocate the zero page"); return SCDA_ELAUNCH; }
+    CONV_DISPATCH(launch_wgrad, > (dy, x, g, dw, accumulate, (float *)ws, ws_bytes, as_stream(stream), db, db_accumulate))
 }
 
 SCDA_API size_t scda_gemm_workspace_bytes(int M, int N, int K) {

@@ -335,6 +335,32 @@ def conv2d_wgrad(dy, x, w_shape, stride, pad, out=None):
     return out
 
 
+def conv2d_wgrad_bias(dy, x, w_shape, stride, pad, out=None, db_out=None):
+    """(dw, db): weight and bias gradient of a conv layer.  One fused pass (the bias gradient rides on the weight-gradient
+    GEMM's operand fragments) when the library says the shape allows it, otherwise the two separate kernels.  `out` /
+    `db_out` given: accumulate into them."""
+    _req(dy, "dy"); _req(x, "x")
+    B, Cin, IH, IW = x.shape
+    Cout, _, KH, KW = w_shape
+    L = lib()
+    if not L.scda_conv2d_wgrad_bias_fusable(i32(B), i32(Cout), i32(dy.shape[2]), i32(dy.shape[3]), _p(dy)):
+        return conv2d_wgrad(dy, x, w_shape, stride, pad, out=out), bias_grad_nchw(dy, out=db_out)
+    acc = dbacc = 0
+    if out is None:
+        out = torch.empty(tuple(w_shape), dtype=torch.float32, device=x.device)
+    else:
+        _req(out, "out"); acc = 1
+    if db_out is None:
+        db_out = torch.empty(Cout, dtype=torch.float32, device=x.device)
+    else:
+        _req(db_out, "db_out"); dbacc = 1
+    ws, n = _conv_ws(B, Cin, IH, IW, Cout, KH, KW, stride, pad, x.device)
+    _check(L.scda_conv2d_wgrad_bias_hip(_p(dy), _p(x), _p(out), _p(db_out), i32(B), i32(Cin), i32(IH), i32(IW), i32(Cout),
+                                        i32(KH), i32(KW), i32(stride), i32(pad), i32(acc), i32(dbacc), _p(ws), _sz(n),
+                                        _stream()), "scda_conv2d_wgrad_bias_hip")
+    return out, db_out
+
+
 def gemm(a, b, M, N, K, lda, ldb, trans_a=False, trans_b=False, bias=None, bias_on_n=True, act=ACT_NONE, slope=0.01,
          out=None, accumulate=False):
     """C[M,N] (+)= op(A) op(B) (+bias) -> act.  See include/scda_ops.h for the operand layouts."""

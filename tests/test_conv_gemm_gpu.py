@@ -64,6 +64,24 @@ def test_conv2d_dgrad_wgrad(cuda, case):
     close(dw2, 2 * w.grad)
 
 
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_wgrad_with_fused_bias_grad(cuda, case):
+    """(dw, db) in one pass where the shape allows the fusion, two kernels otherwise; fresh outputs and accumulation"""
+    from scda_amd import native
+    B, Cin, H, W, Cout, k, s, p = case
+    g = torch.Generator().manual_seed(sum(case) + 2)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).requires_grad_()
+    b = torch.randn(Cout, generator=g).requires_grad_()
+    y = F.conv2d(x, w, b, stride=s, padding=p)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    dw, db = native.conv2d_wgrad_bias(dy.to(cuda), x.to(cuda), w.shape, s, p)
+    close(dw, w.grad); close(db, b.grad, 2e-5)
+    dw2, db2 = native.conv2d_wgrad_bias(dy.to(cuda), x.to(cuda), w.shape, s, p, out=dw.clone(), db_out=db.clone())
+    close(dw2, 2 * w.grad); close(db2, 2 * b.grad, 2e-5)
+
+
 def test_conv_identity_asymmetric(cuda):
     """A = I with an asymmetric B catches a transposed C/D fragment mapping."""
     from scda_amd import native
