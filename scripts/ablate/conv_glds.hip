@@ -197,6 +197,81 @@ __global__ __launch_bounds__(256) void kglds(const float* __restrict__ Wt, const
     }
 }
 
+// ---- 8 waves, 256 x 128 tile: the gathered B operand is shared by twice as many output channels ------------------------
+template <int NST>
+__global__ __launch_bounds__(512) void kglds8(const float* __restrict__ Wt, const float* __restrict__ X, float* __restrict__ Y, G g, const float* zp) {
+    constexpr int BM = 256, BN = 128, BKK = 16, STAGE = BKK * (BM + BN), WM = 64, WN = 64, TM = 2, TN = 2;
+    __shared__ __attribute__((aligned(16))) float lds[NST * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // 0..7
+    const int wm = wave >> 1, wn = wave & 1;                       // 4 x 2
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // B: 16 rows x 2 halves = 32 instr / 8 waves = 4 per wave: wave -> half = wave&1, rows (wave>>1)*4 .. +3
+    const int half = wave & 1, kg = wave >> 1;
+    const int n = n0 + half * 64 + lane, py = n / g.W, px = n % g.W, plane = g.H * g.W;
+    const int nslab = g.K / BKK;
+    // A: 16 rows x 256 floats = 16 x4-instr (one row each: 64 lanes x 4) / 8 waves = 2 per wave: rows 2*wave, 2*wave+1
+    const float* wsrc = Wt + (size_t)(2 * wave) * g.M + m0 + lane * 4;
+    auto issue = [&](int s, int buf) {
+        float* Ab = lds + buf * STAGE;
+        float* Bb = Ab + BKK * BM;
+        const float* wa = wsrc + (size_t)s * BKK * g.M;
+        __builtin_amdgcn_global_load_lds((glb_void*)wa, (lds_void*)(Ab + (2 * wave) * BM), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void*)(wa + g.M), (lds_void*)(Ab + (2 * wave + 1) * BM), 16, 0, 0);
+        const int cb = s / 9, r = s - cb * 9, kh = r / 3, kw = r - kh * 3;
+        const int iy = py + kh - 1, ix = px + kw - 1;
+        const bool ok = (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+        const float* src = ok ? X + (size_t)(cb * 16 + kg * 4) * plane + iy * g.W + ix : zp;
+        const size_t st = ok ? (size_t)plane : 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_global_load_lds((glb_void*)(src + j * st), (lds_void*)(Bb + (kg * 4 + j) * BN + half * 64), 4, 0, 0);
+    };
+    f32x16 acc[TM][TN];
+    zero_acc<128, 128>(acc);
+    const int lr = lane & 31, lk = lane >> 5;
+    issue(0, 0);
+    if (nslab > 1) issue(1, 1);
+    int buf = 0, nbuf = 2;
+    for (int s = 0; s < nslab; ++s) {
+        if (s + 2 < nslab) { issue(s + 2, nbuf); asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }
+        else if (s + 1 < nslab) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const float* ap = lds + buf * STAGE + lk * BM + wm * WM + lr;
+        const float* bp = lds + buf * STAGE + BKK * BM + lk * BN + wn * WN + lr;
+        float a[2][TM], b[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[0][i] = ap[i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[0][j] = bp[j * 32];
+#pragma unroll
+        for (int kp = 0; kp < BKK / 2; ++kp) {
+            const int cur = kp & 1, nxt = cur ^ 1;
+            if (kp + 1 < BKK / 2) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[nxt][i] = ap[(2 * kp + 2) * BM + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[nxt][j] = bp[(2 * kp + 2) * BN + j * 32];
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+        }
+        buf = buf + 1 == NST ? 0 : buf + 1;
+        nbuf = nbuf + 1 == NST ? 0 : nbuf + 1;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int nn = n0 + wn * WN + j * 32 + lr;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Y[(size_t)(m0 + wm * WM + i * 32 + frag_row(r, lane)) * g.N + nn] = acc[i][j][r];
+    }
+}
+
 template <typename F>
 float timeit(F launch) {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
@@ -247,8 +322,13 @@ int main() {
         check("glds 4 stages, issue before barrier", ms);
         ms = timeit([&] { hipLaunchKernelGGL((kglds<4, false, 3>), grid, dim3(256), 0, 0, Wt, X, Y2, g, zp); });
         check("glds 4 stages, prefetch distance 3", ms);
-        ms = timeit([&] { hipLaunchKernelGGL((kglds<5, false, 3>), grid, dim3(256), 0, 0, Wt, X, Y2, g, zp); });
-        check("glds 5 stages, prefetch distance 3", ms);
+        if (g.M % 256 == 0) {
+            dim3 grid8(g.N / 128, g.M / 256);
+            ms = timeit([&] { hipLaunchKernelGGL((kglds8<4>), grid8, dim3(512), 0, 0, Wt, X, Y2, g, zp); });
+            check("8 waves 256x128, 4 stages", ms);
+            ms = timeit([&] { hipLaunchKernelGGL((kglds8<3>), grid8, dim3(512), 0, 0, Wt, X, Y2, g, zp); });
+            check("8 waves 256x128, 3 stages", ms);
+        }
         hipFree(W); hipFree(Wt); hipFree(X); hipFree(Y); hipFree(Y2);
     }
     return 0;

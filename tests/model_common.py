@@ -30,14 +30,15 @@ def seeded_inputs(H, W, G=6):
     return src, tgt, gts, info
 
 
-def oracle_iteration(H, W, lr=1e-3, record_masks=False, capture=False):
+def oracle_iteration(H, W, lr=1e-3, record_masks=False, capture=False, cfg=None):
     """one RefTrainer step on CPU with the golden seeds; returns (result dict, models, masks)"""
     from oracle import torch_ref as R
+    cfg = cfg or CFG
     R.use_cpu_backend()
     try:
         torch.manual_seed(1)
-        models = seeded_models(lambda: R.build_models(CFG))
-        tr = R.RefTrainer(CFG, models, lr=lr, new_w=W, new_h=H)
+        models = seeded_models(lambda: R.build_models(cfg))
+        tr = R.RefTrainer(cfg, models, lr=lr, new_w=W, new_h=H)
         tr.capture = capture
         src, tgt, gts, info = seeded_inputs(H, W)
         R.RecordingDropout.tape = [] if record_masks else None

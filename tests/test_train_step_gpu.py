@@ -26,6 +26,38 @@ def rel(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 
+LOSS_KEYS = ('rpn_cls', 'rpn_loc', 'rcnn_cls', 'rcnn_loc', 'adloss', 'dis_patch_loss', 'recon_loss', 'fake_loss1_source',
+             'fake_loss_target', 'fake_loss_source', 'loss')
+
+
+def test_few_target_proposals_fall_back_to_source_clusters(cuda):
+    """fewer than 512 target proposals: the reference reuses the SOURCE cluster features / centres for the target side
+    (faster_rcnn_adver_expansion_reweight_cluster.py:255-262); the source RoIs are padded to 512 by resampling.
+    Forced here with post_nms_top_n = 300; every logged loss must still match the oracle."""
+    import copy
+    from scda_amd import layers as L
+    from scda_amd.train_step import ScdaTrainer
+    H, W, lr = 256, 512, 1e-3
+    cfg = copy.deepcopy(mc.CFG)
+    cfg['train_rpn_proposal_cfg']['post_nms_top_n'] = 300
+    ref, _, masks = mc.oracle_iteration(H, W, lr=lr, record_masks=True, cfg=cfg)
+    torch.manual_seed(1)
+    tr = ScdaTrainer(cfg, cuda, lr=lr, new_w=W, new_h=H, models=mc.seeded_models(build_product))
+    src, tgt, gts, info = mc.seeded_inputs(H, W)
+    tape = list(masks)
+    L.Dropout.mask_source = lambda shape, p, device: tape.pop(0).to(device)
+    try:
+        np.random.seed(mc.SEEDS['numpy'])
+        out = tr.step(src.to(cuda), gts, info, tgt.to(cuda))
+        torch.cuda.synchronize()
+    finally:
+        L.Dropout.mask_source = None
+    assert not tape
+    for k in LOSS_KEYS:
+        a, b = float(out[k]), float(ref[k])
+        assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), (k, a, b)
+
+
 def test_iteration_matches_oracle(cuda):
     from scda_amd import layers as L
     from scda_amd.train_step import ScdaTrainer
