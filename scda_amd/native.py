@@ -236,6 +236,9 @@ def conv2d_pack_weight(w, for_dgrad=False, cache=True):
     Cached per (storage, direction) until the weight changes (tensor version or optimiser epoch)."""
     _req(w, "w")
     Cout, Cin, KH, KW = w.shape
+    # only parameters are worth caching: a temporary (e.g. the transposed 1x1 weight of ConvTranspose1x1) gets a new address
+    # on every call and would leave a dead entry behind each time
+    cache = cache and isinstance(w, torch.nn.Parameter)
     key = (w.data_ptr(), for_dgrad)
     flat = getattr(w, "_scda_flat", None)
     tag = (w._version, flat.epoch if flat is not None else WEIGHT_EPOCH[0], tuple(w.shape))
