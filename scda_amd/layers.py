@@ -5,7 +5,6 @@ shapes, `state_dict()` keys and initialisation are identical (checkpoints and
 torchvision's vgg16-397923af.pth load unchanged), but none of them calls a
 torch compute kernel: forward dispatches to scda_amd.autograd_ops.
 """
-import itertools
 
 import torch
 import torch.nn as nn
@@ -87,13 +86,12 @@ class Activation(nn.Module):
         return A.ActFn.apply(x, self.mode, self.slope)
 
 
-_dropout_counter = itertools.count(1)
 
 
 class Dropout(nn.Module):
-    """nn.Dropout(p).  The keep-mask comes from the library's counter-based generator, seeded from
-    torch.initial_seed() and a per-call counter; tests inject masks through `mask_source` so that the
-    CPU oracle and the device see the same Bernoulli draws."""
+    """nn.Dropout(p).  The keep-mask comes from the library's counter-based generator; its 64-bit seed is drawn from
+    torch's CPU generator, so runs are reproducible under torch.manual_seed() and resumable through torch.get_rng_state().
+    Tests inject masks through `mask_source` so that the CPU oracle and the device see the same Bernoulli draws."""
 
     mask_source = None  # callable(shape, p, device) -> uint8 mask, or None
 
@@ -107,7 +105,7 @@ class Dropout(nn.Module):
         if Dropout.mask_source is not None:
             mask = Dropout.mask_source(tuple(x.shape), self.p, x.device)
         else:
-            seed = (torch.initial_seed() * 0x9E3779B1 + next(_dropout_counter)) & 0xFFFFFFFFFFFFFFFF
+            seed = int(torch.randint(0, 1 << 62, (1,), dtype=torch.int64))
             mask = N.dropout_mask(tuple(x.shape), self.p, seed, x.device)
         return A.DropoutFn.apply(x, mask, 1.0 / (1.0 - self.p))
 
