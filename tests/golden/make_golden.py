@@ -194,3 +194,6 @@ if __name__ == "__main__":
     if want("eval"):
         import make_golden_eval
         make_golden_eval.generate(ns, HERE)
+    if want("data"):
+        import make_golden_data
+        make_golden_data.generate(ns, HERE)
