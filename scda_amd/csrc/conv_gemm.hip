@@ -680,21 +680,42 @@ __global__ __launch_bounds__(256) void conv_wgrad_glds_kernel(const float *__res
 }
 
 // out[idx] = (accumulate ? out[idx] : 0) + sum_s ws[s][idx] (+ bias[col]) -> act
+// G = split groups per element: a workgroup covers 256/G consecutive elements, thread (g, e) adds the slabs s = g, g+G, ...
+// (independent, pipelined loads), the G partial sums are combined in fixed order through LDS.  With one thread per element
+// (G = 1) a 150-way split of a small weight matrix was 150 dependent loads on 144 workgroups: 0.8 TB/s, 2.2 ms/iteration.
+template <int G>
 __global__ __launch_bounds__(256) void dense_splitk_reduce_kernel(const float *__restrict__ ws, const int splits,
                                                                   const long long total, const int N,
                                                                   const float *__restrict__ bias, const int bias_on_n,
                                                                   const int act, const float slope,
                                                                   const int accumulate, float *__restrict__ out,
-                                                                  const float *__restrict__ db_ws = nullptr,
-                                                                  float *__restrict__ db = nullptr, const int db_n = 0,
-                                                                  const int db_accumulate = 0) {
-    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
-         idx += (long long)blockDim.x * gridDim.x) {
+                                                                  const float *__restrict__ db_ws, float *__restrict__ db,
+                                                                  const int db_n, const int db_accumulate) {
+    constexpr int E = 256 / G;
+    __shared__ float part[G][E + 1];
+    const int e = threadIdx.x % E, g = threadIdx.x / E;
+    for (long long base = (long long)blockIdx.x * E; base < total; base += (long long)gridDim.x * E) {
+        const long long idx = base + e;
         float v = 0.f;
-        for (int s = 0; s < splits; ++s) v += ws[(size_t)s * total + idx];
-        if (bias) v += bias_on_n ? bias[idx % N] : bias[idx / N];
-        v = apply_act(v, act, slope);
-        out[idx] = accumulate ? out[idx] + v : v;
+        if (idx < total) {
+#pragma unroll 4
+            for (int s = g; s < splits; s += G) v += ws[(size_t)s * total + idx];
+        }
+        if (G > 1) {
+            part[g][e] = v;
+            __syncthreads();
+            if (g == 0) {
+                v = 0.f;
+#pragma unroll
+                for (int i = 0; i < G; ++i) v += part[i][e];
+            }
+        }
+        if (g == 0 && idx < total) {
+            if (bias) v += bias_on_n ? bias[idx % N] : bias[idx / N];
+            v = apply_act(v, act, slope);
+            out[idx] = accumulate ? out[idx] + v : v;
+        }
+        if (G > 1) __syncthreads();
     }
     if (db_ws) {   // second, tiny job of the same launch: db[m] (+)= sum over splits of the fused bias-gradient partials
         for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < db_n; m += blockDim.x * gridDim.x) {
@@ -703,6 +724,19 @@ __global__ __launch_bounds__(256) void dense_splitk_reduce_kernel(const float *_
             db[m] = db_accumulate ? db[m] + v : v;
         }
     }
+}
+
+static int launch_dense_reduce(const float *ws, int splits, long long total, int N, const float *bias, int bias_on_n, int act,
+                               float slope, int accumulate, float *out, const float *db_ws, float *db, int db_n,
+                               int db_accumulate, hipStream_t st) {
+#define DENSE_REDUCE(G_)                                                                                                 \
+    hipLaunchKernelGGL(dense_splitk_reduce_kernel<G_>, dim3(ew_grid(total * G_)), dim3(256), 0, st, ws, splits, total, N, bias, \
+                       bias_on_n, act, slope, accumulate, out, db_ws, db, db_n, db_accumulate)
+    if (splits >= 32) DENSE_REDUCE(8);
+    else if (splits >= 8) DENSE_REDUCE(4);
+    else DENSE_REDUCE(1);
+#undef DENSE_REDUCE
+    return launch_status("dense_splitk_reduce_kernel");
 }
 
 // ---------------------------------------------------------------------------
@@ -1127,9 +1161,8 @@ static int launch_wgrad(const float *dY, const float *X, WgradGeom g, float *dW,
     int rc = launch_status("conv_wgrad_kernel");
     if (rc) return rc;
     const long long total = (long long)g.M * g.N;
-    hipLaunchKernelGGL(dense_splitk_reduce_kernel, dim3(ew_grid(total)), dim3(256), 0, st, ws, splits, total, g.N,
-                       (const float *)nullptr, 0, (int)ACT_NONE, 0.f, accumulate, dW, (const float *)db_ws, db, g.M, db_accumulate);
-    return launch_status("dense_splitk_reduce_kernel");
+    return launch_dense_reduce(ws, splits, total, g.N, nullptr, 0, (int)ACT_NONE, 0.f, accumulate, dW, db_ws, db, g.M,
+                               db_accumulate, st);
 }
 
 }  // namespace scda
@@ -1304,7 +1337,6 @@ SCDA_API int scda_gemm_hip(const float *A, const float *B, float *C, int M, int 
     int rc = launch_status("gemm_kernel");
     if (rc || splits == 1) return rc;
     const long long total = (long long)M * N;
-    hipLaunchKernelGGL(dense_splitk_reduce_kernel, dim3(ew_grid(total)), dim3(256), 0, st, (const float *)ws, splits,
-                       total, N, bias, bias_on_n, act, slope, accumulate, C);
-    return launch_status("dense_splitk_reduce_kernel");
+    return launch_dense_reduce((const float *)ws, splits, total, N, bias, bias_on_n, act, slope, accumulate, C, nullptr, nullptr,
+                               0, 0, st);
 }
