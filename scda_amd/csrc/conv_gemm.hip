@@ -102,10 +102,10 @@ __device__ __forceinline__ int conv_tap_offset(const ConvGeom &g, const bool n_o
 }
 
 // accumulators -> split-K slab, or (+bias) -> activation -> NCHW output; lanes run along N (pixels): 128-byte row segments
-template <int BM, int BN>
-__device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BM / 64][BN / 64], const ConvGeom &g, const Epi &e, const int m0,
+template <int WM, int WN>
+__device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[WM / 32][WN / 32], const ConvGeom &g, const Epi &e, const int m0,
                                               const int n0, const int tz, const int wm, const int wn, const int lane) {
-    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    constexpr int TM = WM / 32, TN = WN / 32;
     const int lr = lane & 31;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float *__restrict
         __syncthreads();
         buf ^= 1;
     }
-    conv_epilogue<BM, BN>(acc, g, e, m0, n0, tz, wm, wn, lane);
+    conv_epilogue<BM / 2, BN / 2>(acc, g, e, m0, n0, tz, wm, wn, lane);
 }
 
 // ---- (2) direct-to-LDS kernel: channel count % 16 == 0 (every VGG / RPN / decoder / discriminator body layer) -----------
@@ -283,22 +283,26 @@ struct GldsOperand {
 };
 
 
+// Wave layout: 2 x 2 waves, except the 64 x 256 tile (layers with <= 64 output channels: conv1_x, the decoder's last
+// stages), which is 1 x 4 so that every wave still owns a 64 x 64 sub-tile = 32 MFMAs per barrier; with 64 x 128 tiles a
+// wave had 32 x 64 = 16 MFMAs per barrier and those layers ran at 75 instead of ~100 TFLOP/s.
 template <int BM, int BN, int KH, int KW, int S, bool DGRAD>
 __global__ __launch_bounds__(256) void conv_igemm_glds_kernel(const float *__restrict__ Wt, const float *__restrict__ X,
                                                               const ConvGeom g, const Epi e) {
     constexpr int NST = 4, STAGE = BK * (BM + BN);
-    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    constexpr int WGN = BN == 256 ? 4 : 2, WGM = 4 / WGN;          // waves along N / M
+    constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
     constexpr int A_LPR = BM / 4;             // lanes per weight row (dwordx4 each)
     constexpr int A_RPI = 64 / A_LPR;         // rows per wave-instruction
     constexpr int A_PW = BK / A_RPI / 4;      // A instructions per wave per slab
     constexpr int HALVES = BN / 64;           // 64-pixel pieces per B row
-    constexpr int B_PW = 4 * HALVES;          // B instructions (= rows) per wave per slab
+    constexpr int B_PW = 4 * HALVES;          // B instructions (= rows) per wave per slab (64 x 256 tile: all 16 rows)
     constexpr int L = A_PW + B_PW;            // LDS-DMA instructions per wave per slab
     __shared__ __attribute__((aligned(16))) float lds[NST * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WGN, wn = wave % WGN;
     int tx, ty, tz;
     tile_coords(g.nx, g.ny, g.swz, tx, ty, tz);
     const int m0 = ty * BM, n0 = tx * BN;
@@ -337,7 +341,12 @@ __global__ __launch_bounds__(256) void conv_igemm_glds_kernel(const float *__res
     };
 
     f32x16 acc[TM][TN];
-    zero_acc<BM, BN>(acc);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const int lr = lane & 31, lk = lane >> 5;
 
     if (s_begin < s_end) issue(s_begin, 0);
@@ -378,7 +387,7 @@ __global__ __launch_bounds__(256) void conv_igemm_glds_kernel(const float *__res
         buf = (buf + 1) & (NST - 1);
         nbuf = (nbuf + 1) & (NST - 1);
     }
-    conv_epilogue<BM, BN>(acc, g, e, m0, n0, tz, wm, wn, lane);
+    conv_epilogue<WM, WN>(acc, g, e, m0, n0, tz, wm, wn, lane);
 }
 
 // split-K reduce for conv outputs: fixed summation order s = 0..splits-1
@@ -1005,8 +1014,8 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const float *
 //   time(plan) = flops / (model efficiency x 110 TFLOP/s) + split-K slab traffic (write + read) at 3 TB/s
 struct LaunchPlan { int bn, splits; };
 
-static int resident_per_cu(int bm, int bn) { return (bm == 128 && bn == 128) ? 2 : (bm == 64 && bn == 64) ? 4 : 3; }
-static double tile_efficiency(int bm, int bn) { return (bm == 128 && bn == 128) ? 1.0 : (bm == 64 && bn == 64) ? 0.85 : 0.94; }
+static int resident_per_cu(int bm, int bn) { return ((bm == 128 && bn == 128) || bn == 256) ? 2 : (bm == 64 && bn == 64) ? 4 : 3; }
+static double tile_efficiency(int bm, int bn) { return ((bm == 128 && bn == 128) || bn == 256) ? 1.0 : (bm == 64 && bn == 64) ? 0.85 : 0.94; }
 
 // time, in units of one workgroup running at full CU speed, for the busiest CU to finish c workgroups with p resident
 static double cu_rounds(int c, int p) {
@@ -1030,24 +1039,24 @@ static double plan_cost(long long tiles, int splits, int bm, int bn, double flop
 
 // bn_lo..bn_hi: candidate N-tile widths (64 and/or 128); must_split: the kernel always writes slabs (weight gradient)
 static LaunchPlan plan_search(int M, int N, int K, int bm, bool allow64, bool allow128, bool must_split, size_t ws_bytes,
-                              int k_granule);
+                              int k_granule, bool allow256);
 
 // memoised per thread (the same ~60 shapes recur every iteration; launches come from the main and the autograd thread)
 static LaunchPlan plan_launch(int M, int N, int K, int bm, bool allow64, bool allow128, bool must_split, size_t ws_bytes,
-                              int k_granule) {
+                              int k_granule, bool allow256 = false) {
     struct Key { int M, N, K, flags; size_t ws; };
     struct Entry { Key k; LaunchPlan p; };
     static thread_local std::vector<Entry> cache;
-    const Key key{M, N, K, bm | (allow64 << 8) | (allow128 << 9) | (must_split << 10) | (k_granule << 11), ws_bytes};
+    const Key key{M, N, K, bm | (allow64 << 8) | (allow128 << 9) | (must_split << 10) | (allow256 << 11) | (k_granule << 12), ws_bytes};
     for (const Entry &e : cache)
         if (e.k.M == key.M && e.k.N == key.N && e.k.K == key.K && e.k.flags == key.flags && e.k.ws == key.ws) return e.p;
-    const LaunchPlan p = plan_search(M, N, K, bm, allow64, allow128, must_split, ws_bytes, k_granule);
+    const LaunchPlan p = plan_search(M, N, K, bm, allow64, allow128, must_split, ws_bytes, k_granule, allow256);
     if (cache.size() < 512) cache.push_back(Entry{key, p});
     return p;
 }
 
 static LaunchPlan plan_search(int M, int N, int K, int bm, bool allow64, bool allow128, bool must_split, size_t ws_bytes,
-                              int k_granule) {
+                              int k_granule, bool allow256) {
     const double flops = 2.0 * M * (double)N * K, out_bytes = (double)M * N * sizeof(float);
     LaunchPlan best{allow128 ? 128 : 64, 1};
     double best_t = 1e30;
@@ -1055,8 +1064,8 @@ static LaunchPlan plan_search(int M, int N, int K, int bm, bool allow64, bool al
     if (max_s < 1) max_s = 1;
     if (max_s > 256) max_s = 256;
     while (max_s > 1 && (size_t)max_s * M * N * sizeof(float) > ws_bytes) --max_s;
-    for (int bn = 64; bn <= 128; bn += 64) {
-        if ((bn == 64 && !allow64) || (bn == 128 && !allow128)) continue;
+    for (int bn = 64; bn <= 256; bn *= 2) {
+        if ((bn == 64 && !allow64) || (bn == 128 && !allow128) || (bn == 256 && !allow256)) continue;
         const long long tiles = (long long)cdiv(M, bm) * cdiv(N, bn);
         for (int sp = 1; sp <= max_s; ++sp) {
             if (tiles * sp > 4096 && sp > 1) break;   // plenty of workgroups already: splitting only adds traffic
@@ -1082,7 +1091,8 @@ static int launch_conv(const float *Wm, const float *X, const ConvGeom &g0, Epi 
     const int BMv = small_m ? 64 : 128;
     static const char *force = getenv("SCDA_CONV_BN");   // experiment knob: 64 | 128
     const int fbn = force ? (atoi(force) == 64 ? 64 : 128) : 0;
-    const LaunchPlan plan = plan_launch(g.M, g.N, g.K, BMv, fbn != 128, fbn != 64, false, ws_bytes, BK);
+    const LaunchPlan plan = plan_launch(g.M, g.N, g.K, BMv, fbn != 128, fbn != 64, false, ws_bytes, BK,
+                                        small_m && g.slab_aligned && !fbn);
     const int BNv = plan.bn;
     int splits = plan.splits;
     g.k_per_split = round_k_per_split(g.K, splits);
@@ -1102,7 +1112,8 @@ static int launch_conv(const float *Wm, const float *X, const ConvGeom &g0, Epi 
         else                                                                                                             \
             hipLaunchKernelGGL((conv_igemm_kernel<BM_, BN_, KH, KW, S, DGRAD>), grid, dim3(256), 0, st, Wm, X, g, e);        \
     } while (0)
-    if (small_m && BNv == 64) CONV_LAUNCH(64, 64);
+    if (small_m && BNv == 256) hipLaunchKernelGGL((conv_igemm_glds_kernel<64, 256, KH, KW, S, DGRAD>), grid, dim3(256), 0, st, Wm, X, g, e);
+    else if (small_m && BNv == 64) CONV_LAUNCH(64, 64);
     else if (small_m) CONV_LAUNCH(64, 128);
     else if (BNv == 64) CONV_LAUNCH(128, 64);
     else CONV_LAUNCH(128, 128);
