@@ -25,6 +25,8 @@ CONV_CASES = [
     (1, 512, 8, 16, 512, 3, 1, 1),    # split-K path (few tiles)
     (4, 3, 64, 64, 32, 3, 2, 1),      # discriminator stride 2
     (4, 32, 32, 32, 64, 3, 2, 1),
+    (2, 16, 15, 21, 32, 3, 2, 1),     # stride 2, odd extents: parity classes of the data gradient have unequal sizes
+    (1, 16, 17, 18, 48, 3, 2, 0),     # stride 2 without padding
     (4, 128, 16, 16, 1, 1, 1, 0),     # 1x1 -> 1 channel
     (1, 512, 8, 16, 30, 1, 1, 0),     # RPN cls head
     (4, 32, 32, 32, 3, 1, 1, 0),      # decoder's final 1x1
