@@ -29,17 +29,31 @@ def cpu_quota():
 
 
 def configure_host_threads(torch_threads=None):
-    """idempotent; torch intra-op threads -> min(4, quota / ranks on this node) unless SCDA_TORCH_THREADS overrides;
-    numpy/scipy/sklearn pools -> 1.  (With 8 ranks inside one 16-CPU quota every rank gets 2: main thread + autograd thread.)"""
+    """idempotent; torch intra-op threads -> 1 unless SCDA_TORCH_THREADS overrides; numpy/scipy/sklearn pools -> 1.
+    Nothing on the host path of the iteration has a parallel region worth a second thread, and idle OpenMP workers spin:
+    measured (scripts/host_cpu_use.py) 4 threads = 3.6 cores busy per rank, 1 thread = 1.7 cores, same 32 ms/iteration --
+    with 8 ranks inside one 16-CPU quota that is the difference between throttling and not."""
     if _done:
         return
     _done.append(True)
     if os.environ.get("SCDA_KEEP_HOST_THREADS"):
         return
     import torch
-    ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")) or 1))
-    n = torch_threads or int(os.environ.get("SCDA_TORCH_THREADS", "0")) or max(1, min(4, (cpu_quota() or 4 * ranks) // ranks))
+    n = torch_threads or int(os.environ.get("SCDA_TORCH_THREADS", "0")) or 1
     if torch.get_num_threads() > n:
         torch.set_num_threads(n)
     from .dropin.functions.mask import _limit_host_pools_once
     _limit_host_pools_once()
+
+
+def prefer_blocking_sync():
+    """Make host-side waits on the device (stream / event synchronise) sleep instead of spin: hipSetDeviceFlags(
+    hipDeviceScheduleBlockingSync).  Call BEFORE the process touches the GPU.  Worth it when several ranks share the host
+    cores (1.7 -> 1.5 cores busy per rank, iteration time unchanged); returns the HIP status (0 = ok) or None if the
+    runtime library is not loadable."""
+    import ctypes
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+    except OSError:
+        return None
+    return int(hip.hipSetDeviceFlags(ctypes.c_uint(4)))
