@@ -123,7 +123,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     if world > 1 or os.environ.get("SCDA_BLOCKING_SYNC"):
         from scda_amd.hostenv import prefer_blocking_sync
-        prefer_blocking_sync()      # ranks share the host cores: sleep, do not spin, while waiting for the device
+        prefer_blocking_sync(local)  # ranks share the host cores: sleep, do not spin, while waiting for the device
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:

@@ -46,14 +46,17 @@ def configure_host_threads(torch_threads=None):
     _limit_host_pools_once()
 
 
-def prefer_blocking_sync():
+def prefer_blocking_sync(device_index=0):
     """Make host-side waits on the device (stream / event synchronise) sleep instead of spin: hipSetDeviceFlags(
-    hipDeviceScheduleBlockingSync).  Call BEFORE the process touches the GPU.  Worth it when several ranks share the host
-    cores (1.7 -> 1.5 cores busy per rank, iteration time unchanged); returns the HIP status (0 = ok) or None if the
-    runtime library is not loadable."""
+    hipDeviceScheduleBlockingSync) on THIS rank's device.  Call before the process touches the GPU.  Worth it when several
+    ranks share the host cores (1.7 -> 1.5 cores busy per rank, iteration time unchanged); returns the HIP status (0 = ok)
+    or None if the runtime library is not loadable."""
     import ctypes
     try:
         hip = ctypes.CDLL("libamdhip64.so")
     except OSError:
         return None
+    rc = int(hip.hipSetDevice(ctypes.c_int(int(device_index))))   # the flags apply to the calling thread's current device
+    if rc:
+        return rc
     return int(hip.hipSetDeviceFlags(ctypes.c_uint(4)))

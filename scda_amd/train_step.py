@@ -125,6 +125,8 @@ class ScdaTrainer:
         # scheduling: detector backward enqueued as soon as its losses exist; target branch on a high-priority side stream
         self.early_backward = True
         self.side = torch.cuda.Stream(device=device, priority=-1) if device.type == "cuda" else None
+        if os.environ.get("SCDA_SIDE_STREAM", "1") == "0":
+            self.side = None
         # the B halves of the decoder / image discriminator run beside their A halves (SCDA_AB_STREAMS=0: one stream)
         if device.type == "cuda" and os.environ.get("SCDA_AB_STREAMS", "1") != "0":
             self.branch = torch.cuda.Stream(device=device)
