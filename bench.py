@@ -117,6 +117,10 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    # test hooks (tests/test_bench_multirank_gpu.py runs the N > 1 branch with two ranks on ONE GPU over gloo)
+    backend = os.environ.get("SCDA_BENCH_BACKEND", "nccl")
+    if "SCDA_BENCH_DEVICE" in os.environ:
+        local = int(os.environ["SCDA_BENCH_DEVICE"])
     if a.gpus > 1 and world != a.gpus:
         raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (a.gpus, a.gpus))
     if not torch.cuda.is_available():
@@ -128,7 +132,7 @@ def main():
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     from scda_amd import native
     from scda_amd.train_step import ScdaTrainer

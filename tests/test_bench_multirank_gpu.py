@@ -1,0 +1,29 @@
+"""bench.py's N > 1 branch end to end (rendezvous, broadcast, barriers, MAX-over-ranks timing, one JSON line from rank 0),
+launched exactly as the driver does -- `python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2` -- but with
+both ranks on the single GPU of the test box and gloo carrying the collectives (SCDA_BENCH_DEVICE / SCDA_BENCH_BACKEND)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def test_bench_two_ranks(cuda):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, SCDA_BENCH_DEVICE="0", SCDA_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                 # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 2 and d["scaling"] == "weak"
+    assert d["config"]["parallelism"] == "dp2" and "cpu_baseline" not in d
+    assert abs(d["value"] - 2 * 2 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-3      # whole-job images/s
+    assert d["roofline"]["launches"] > 0
