@@ -30,7 +30,7 @@ def seeded_inputs(H, W, G=6):
     return src, tgt, gts, info
 
 
-def oracle_iteration(H, W, lr=1e-3, record_masks=False, capture=False, cfg=None):
+def oracle_iteration(H, W, lr=1e-3, record_masks=False, capture=False, cfg=None, steps=1):
     """one RefTrainer step on CPU with the golden seeds; returns (result dict, models, masks)"""
     from oracle import torch_ref as R
     cfg = cfg or CFG
@@ -45,6 +45,11 @@ def oracle_iteration(H, W, lr=1e-3, record_masks=False, capture=False, cfg=None)
         torch.manual_seed(SEEDS['torch'])
         np.random.seed(SEEDS['numpy'])
         res = tr.step(src, gts, info, tgt)
+        history = [res]
+        for _ in range(steps - 1):          # same inputs again; RNG streams simply continue
+            history.append(tr.step(src, gts, info, tgt))
+        if steps > 1:
+            res = dict(history[-1], _history=history)
         masks = R.RecordingDropout.tape
         R.RecordingDropout.tape = None
     finally:

@@ -58,6 +58,37 @@ def test_few_target_proposals_fall_back_to_source_clusters(cuda):
         assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), (k, a, b)
 
 
+def test_two_iterations_track_oracle(cuda):
+    """two consecutive iterations (optimiser state, BN statistics and RNG streams carried along): the logged losses of
+    every step stay on the oracle's trajectory.  Step 1 agrees to 1e-4 (previous test); from step 2 on the tolerance is 2e-2:
+    Adam's first step moves EVERY weight by ~lr whatever its gradient's magnitude, so the (rare) elements whose gradient is
+    within round-off of zero step the other way on the two machines (bounded in the previous test: <= 2 % per tensor), and
+    that one-off perturbation of the weights shows up as ~1e-2 in the next losses (measured: rcnn_cls 0.7939 vs 0.7874; by the
+    third step the two trajectories are 2 % apart and the comparison stops saying anything about the kernels)."""
+    from scda_amd import layers as L
+    from scda_amd.train_step import ScdaTrainer
+    H, W, lr = 256, 512, 1e-4
+    ref, _, masks = mc.oracle_iteration(H, W, lr=lr, record_masks=True, steps=2)
+    torch.manual_seed(1)
+    tr = ScdaTrainer(mc.CFG, cuda, lr=lr, new_w=W, new_h=H, models=mc.seeded_models(build_product))
+    src, tgt, gts, info = mc.seeded_inputs(H, W)
+    src, tgt = src.to(cuda), tgt.to(cuda)
+    tape = list(masks)
+    L.Dropout.mask_source = lambda shape, p, device: tape.pop(0).to(device)
+    try:
+        np.random.seed(mc.SEEDS['numpy'])
+        outs = [tr.step(src, gts, info, tgt) for _ in range(2)]
+        torch.cuda.synchronize()
+    finally:
+        L.Dropout.mask_source = None
+    assert not tape
+    for i, (out, want) in enumerate(zip(outs, ref['_history'])):
+        for k in LOSS_KEYS:
+            a, b = float(out[k]), float(want[k])
+            assert abs(a - b) <= (1e-4 if i == 0 else 2e-2) * max(1.0, abs(b)), (i, k, a, b)
+    assert float(outs[1]['rcnn_cls']) != float(outs[0]['rcnn_cls'])        # the weights did move
+
+
 def test_iteration_matches_oracle(cuda):
     from scda_amd import layers as L
     from scda_amd.train_step import ScdaTrainer
