@@ -94,14 +94,16 @@ def nms_mask(boxes, thresh):
 
 
 # ------------------------------------------------------------- RoIPool ------
-def roi_pool_fwd(features, rois, ph, pw, scale):
+def roi_pool_fwd(features, rois, ph, pw, scale, want_argmax=True):
+    """-> (out [R,C,ph,pw], argmax int32 [R,C,ph,pw] | None).  want_argmax=False (nothing will be differentiated through the
+    call, e.g. the target-domain branch) skips the second 51 MB output."""
     _req(features, "features"); _req(rois, "rois")
     if rois.dim() != 2 or rois.shape[1] != 5:
         raise ValueError("rois must be [R,5]")
     B, C, H, W = features.shape
     R = rois.shape[0]
     out = torch.empty(R, C, ph, pw, dtype=torch.float32, device=features.device)
-    arg = torch.empty(R, C, ph, pw, dtype=torch.int32, device=features.device)
+    arg = torch.empty(R, C, ph, pw, dtype=torch.int32, device=features.device) if want_argmax else None
     _check(lib().scda_roi_pool_fwd_hip(_p(features), _p(rois), i32(R), i32(B), i32(C), i32(H), i32(W), i32(ph), i32(pw),
                                        f32(scale), _p(out), _p(arg), _stream()), "scda_roi_pool_fwd_hip")
     return out, arg
