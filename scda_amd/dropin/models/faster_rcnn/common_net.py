@@ -40,6 +40,20 @@ class LinUnsRes_cluster(nn.Module):
         return x.view(self.cluster_num, self.channel, self.w, self.h)
 
 
+class LinUnsRes_cluster2(nn.Module):
+    """reshape as LinUnsRes_cluster, then a bias-free 3x3 stride-2 conv: [cluster_num, channel, w/2, h/2]
+    (common_net.py:132-157; first stage of GAN_decoder_AE_32)"""
+
+    def __init__(self, channel=128, w=64, h=64, cluster_num=4):
+        super().__init__()
+        self.channel, self.w, self.h, self.cluster_num = channel, w, h, cluster_num
+        self.model = nn.Sequential(L.Conv2d(channel, channel, kernel_size=3, stride=2, padding=1, bias=False))
+        self.model.apply(gaussian_weights_init)
+
+    def forward(self, x):
+        return self.model(x.view(self.cluster_num, self.channel, self.w, self.h))
+
+
 class Interpolate(nn.Module):
     def __init__(self, scale_factor, mode):
         super().__init__()

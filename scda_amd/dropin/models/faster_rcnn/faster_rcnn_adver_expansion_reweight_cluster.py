@@ -21,7 +21,7 @@ from scda_amd.dropin.functions.mask import compute_cluster_targets
 from scda_amd.dropin.functions.predict_bbox import compute_predicted_bboxes
 from scda_amd.dropin.functions.proposal_target import compute_proposal_targets
 from scda_amd.dropin.functions.rpn_proposal import compute_rpn_proposals
-from scda_amd.dropin.models.faster_rcnn.common_net import (INSResBlock, LeakyReLUConv2d, LeakyReLUConvTranspose2d_2,
+from scda_amd.dropin.models.faster_rcnn.common_net import (INSResBlock, LeakyReLUConv2d, LeakyReLUConvTranspose2d_2, LinUnsRes_cluster2,
                                                            LinUnsRes_cluster, ResDis_cluster, gaussian_weights_init)
 
 logger = logging.getLogger('global')
@@ -275,6 +275,8 @@ class GAN_decoder_AE(nn.Module):
     """two decoders (A: source, B: target): reshape -> n_gen_res_blk INSResBlocks -> (n_gen_front_blk-1) x2
     up-sampling blocks -> 1x1 transposed conv -> tanh; cluster features [4, ch, 64*64] -> images [4, 3, S, S]"""
 
+    first_stage = LinUnsRes_cluster
+
     def __init__(self, params):
         super().__init__()
         out_dim, ch = params['input_dim_b'], params['ch']
@@ -283,7 +285,7 @@ class GAN_decoder_AE(nn.Module):
         neww, newh, clusters = params.get('neww', 64), params.get('newh', 64), params.get('cluster_num', 4)
 
         def branch():
-            seq = [LinUnsRes_cluster(ch, neww, newh, clusters)]
+            seq = [type(self).first_stage(ch, neww, newh, clusters)]
             seq += [INSResBlock(ch, ch, dropout=drop) for _ in range(n_res)]
             c = ch
             for _ in range(n_front - 1):
@@ -302,3 +304,9 @@ class GAN_decoder_AE(nn.Module):
 
     def forward(self, x_aa, x_bb):
         return _two_branches(self, lambda: self.decode_A(x_aa), lambda: self.decode_B(x_bb))
+
+
+class GAN_decoder_AE_32(GAN_decoder_AE):
+    """the same decoder behind a stride-2 entry conv (LinUnsRes_cluster2): 32x32 feature maps, images of half the size
+    (faster_rcnn_adver_expansion_reweight_cluster.py:402-465)"""
+    first_stage = LinUnsRes_cluster2

@@ -188,3 +188,18 @@ def test_conv_transpose_1x1_and_layers(cuda):
     y = ref(xr); dy = torch.randn(y.shape, generator=gen(41)); y.backward(dy)
     xg = x.to(cuda).requires_grad_(); yg = mine(xg); yg.backward(dy.to(cuda))
     close(yg, y, 1e-4); close(xg.grad, xr.grad, 1e-4); close(mine.weight.grad, ref.weight.grad, 1e-4); close(mine.bias.grad, ref.bias.grad, 1e-4)
+
+
+def test_decoder_32_forward_backward(cuda):
+    """GAN_decoder_AE_32 end to end on the device: [4,128,64*64] cluster features -> [4,3,128,128] images in (-1,1)"""
+    from scda_amd.dropin.models.faster_rcnn.faster_rcnn_adver_expansion_reweight_cluster import GAN_decoder_AE_32
+    torch.manual_seed(0)
+    m = GAN_decoder_AE_32({'ch': 128, 'input_dim_b': 3, 'n_gen_res_blk': 3, 'n_gen_front_blk': 3, 'res_dropout_ratio': 0.5}).to(cuda)
+    xa = torch.randn(4, 128, 4096, generator=gen(31)).to(cuda)
+    xb = torch.randn(4, 128, 4096, generator=gen(32)).to(cuda)
+    ya, yb = m(xa, xb)
+    assert tuple(ya.shape) == (4, 3, 128, 128) and tuple(yb.shape) == (4, 3, 128, 128)
+    assert float(ya.abs().max()) <= 1.0 and torch.isfinite(ya).all()
+    (ya.mean() + yb.mean()).backward()
+    g = m.decode_A[0].model[0].weight.grad
+    assert g is not None and torch.isfinite(g).all() and float(g.abs().max()) > 0

@@ -49,3 +49,13 @@ def test_state_dict_layout_is_the_reference_layout():
         for k in osd:
             assert osd[k].shape == psd[k].shape, k
     assert len(p_det.state_dict()) == 40 and sum(p.numel() for p in p_det.parameters()) == 136850887
+
+
+def test_decoder_32_variant_layout():
+    """GAN_decoder_AE_32 (module-API boundary): GAN_decoder_AE behind LinUnsRes_cluster2's bias-free stride-2 conv"""
+    from scda_amd.dropin.models.faster_rcnn.faster_rcnn_adver_expansion_reweight_cluster import GAN_decoder_AE, GAN_decoder_AE_32
+    p = {'ch': 128, 'input_dim_b': 3, 'n_gen_res_blk': 3, 'n_gen_front_blk': 3, 'res_dropout_ratio': 0.5}
+    a, b = GAN_decoder_AE(p).state_dict(), GAN_decoder_AE_32(p).state_dict()
+    extra = [k for k in b if k not in a]
+    assert extra == ['decode_B.0.model.0.weight', 'decode_A.0.model.0.weight']
+    assert tuple(b[extra[0]].shape) == (128, 128, 3, 3) and set(a) <= set(b)
