@@ -163,3 +163,27 @@ def test_iteration_matches_oracle(cuda):
                 assert flipped <= max(1, int(0.02 * d.numel())), (k, flipped, d.numel())
     dp = tr.dis_patch.state_dict()
     assert int(dp['model_A_patch.0.model.1.num_batches_tracked']) == 3
+
+
+def test_vgg16_bn_detector_trains(cuda):
+    """the batch-norm backbone variant (vgg16_bn, `--arch vgg16bn_FasterRCNN` in the reference driver): one full iteration
+    through the same step; finite losses, BN statistics updated, torchvision's vgg16_bn key layout"""
+    from scda_amd.dropin.models.faster_rcnn.vgg_adver_expansion_cluster import vgg16_bn
+    from scda_amd.train_step import ScdaTrainer, builder_gan
+    H, W = 256, 512
+    torch.manual_seed(2)
+    det = vgg16_bn(cfg=dict(mc.CFG['shared'], gan_model_flag=2))
+    keys = list(det.state_dict().keys())
+    assert keys[:7] == ['features.0.weight', 'features.0.bias', 'features.1.weight', 'features.1.bias',
+                        'features.1.running_mean', 'features.1.running_var', 'features.1.num_batches_tracked']
+    dis, dec, dis_patch = builder_gan()
+    tr = ScdaTrainer(mc.CFG, cuda, lr=1e-4, new_w=W, new_h=H, models=(det, dec, dis, dis_patch))
+    src, tgt, gts, info = mc.seeded_inputs(H, W)
+    np.random.seed(3)
+    out = tr.step(src.to(cuda), gts, info, tgt.to(cuda))
+    torch.cuda.synchronize()
+    for k in LOSS_KEYS:
+        assert np.isfinite(float(out[k])), k
+    sd = tr.model.state_dict()
+    assert int(sd['features.1.num_batches_tracked']) == 2          # source and target pass
+    assert float(sd['features.1.running_mean'].abs().sum()) > 0
