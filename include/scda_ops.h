@@ -151,6 +151,9 @@ int scda_conv2d_fwd_hip(const float *x, const float *wp, const float *bias /*[Co
 /* dx [batch,Cin,IH,IW] = conv-transpose of dy [batch,Cout,OH,OW] (fully overwritten); wt = pack(w, 1) */
 int scda_conv2d_dgrad_hip(const float *dy, const float *wt, float *dx, int batch, int Cin, int IH, int IW, int Cout,
                           int KH, int KW, int S, int P, void *ws, size_t ws_bytes, void *stream);
+/* the same for a conv with <= 4 input channels (image-side layers), direct form, HBM-bound on dy; w = the UNPACKED weight */
+int scda_conv2d_dgrad_small_cin_hip(const float *dy, const float *w, float *dx, int batch, int Cin, int IH, int IW, int Cout,
+                                    int KH, int KW, int S, int P, void *stream);
 /* dw [Cout,Cin,KH,KW] (+)= sum over batch and pixels; deterministic split-K (no atomics) */
 int scda_conv2d_wgrad_hip(const float *dy, const float *x, float *dw, int batch, int Cin, int IH, int IW, int Cout,
                           int KH, int KW, int S, int P, int accumulate, void *ws, size_t ws_bytes, void *stream);

@@ -315,8 +315,14 @@ def conv2d_dgrad(dy, w, x_shape, stride, pad):
     _req(dy, "dy"); _req(w, "w")
     B, Cin, IH, IW = x_shape
     Cout, _, KH, KW = w.shape
-    wt = conv2d_pack_weight(w, True)
     dx = torch.empty(B, Cin, IH, IW, dtype=torch.float32, device=dy.device)
+    if Cin <= 4 and Cout * KH * KW * 16 <= 65536 and (KH, KW) in ((3, 3), (1, 1)):
+        # image-side layer: 3 rows of a 64-row MFMA tile would be 95 % padding -- direct kernel, unpacked weights
+        _check(lib().scda_conv2d_dgrad_small_cin_hip(_p(dy), _p(w.contiguous()), _p(dx), i32(B), i32(Cin), i32(IH), i32(IW), i32(Cout),
+                                                     i32(KH), i32(KW), i32(stride), i32(pad), _stream()),
+               "scda_conv2d_dgrad_small_cin_hip")
+        return dx
+    wt = conv2d_pack_weight(w, True)
     ws, n = _conv_ws(B, Cin, IH, IW, Cout, KH, KW, stride, pad, dy.device)
     _check(lib().scda_conv2d_dgrad_hip(_p(dy), _p(wt), _p(dx), i32(B), i32(Cin), i32(IH), i32(IW), i32(Cout), i32(KH),
                                        i32(KW), i32(stride), i32(pad), _p(ws), _sz(n), _stream()), "scda_conv2d_dgrad_hip")
