@@ -40,8 +40,14 @@ __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float *__restri
         const int oy = (int)(r % OH);
         const long long pc = r / OH;
         const float *p = x + (pc * H + 2 * oy) * W + 2 * ox;
-        const float2 a = *reinterpret_cast<const float2 *>(p);
-        const float2 b = *reinterpret_cast<const float2 *>(p + W);
+        float2 a, b;
+        if (W & 1) {   // odd width: rows are not 8-byte aligned (floor mode: the last column / row is simply never read)
+            a = make_float2(p[0], p[1]);
+            b = make_float2(p[W], p[W + 1]);
+        } else {
+            a = *reinterpret_cast<const float2 *>(p);
+            b = *reinterpret_cast<const float2 *>(p + W);
+        }
         float m = a.x; int k = 0;
         if (a.y > m || a.y != a.y) { m = a.y; k = 1; }
         if (b.x > m || b.x != b.x) { m = b.x; k = 2; }
@@ -63,8 +69,18 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float *__restri
         const float g = dy[i];
         const int k = idx[i];
         float *p = dx + (pc * H + 2 * oy) * W + 2 * ox;
-        *reinterpret_cast<float2 *>(p) = make_float2(k == 0 ? g : 0.f, k == 1 ? g : 0.f);
-        *reinterpret_cast<float2 *>(p + W) = make_float2(k == 2 ? g : 0.f, k == 3 ? g : 0.f);
+        if (W & 1) {
+            p[0] = k == 0 ? g : 0.f; p[1] = k == 1 ? g : 0.f;
+            p[W] = k == 2 ? g : 0.f; p[W + 1] = k == 3 ? g : 0.f;
+            if (ox == OW - 1) { p[2] = 0.f; p[W + 2] = 0.f; }                  // the column floor mode dropped
+        } else {
+            *reinterpret_cast<float2 *>(p) = make_float2(k == 0 ? g : 0.f, k == 1 ? g : 0.f);
+            *reinterpret_cast<float2 *>(p + W) = make_float2(k == 2 ? g : 0.f, k == 3 ? g : 0.f);
+        }
+        if ((H & 1) && oy == OH - 1) {                                         // the row floor mode dropped
+            p[2 * W] = 0.f; p[2 * W + 1] = 0.f;
+            if ((W & 1) && ox == OW - 1) p[2 * W + 2] = 0.f;
+        }
     }
 }
 
@@ -670,7 +686,7 @@ using namespace scda;
     if (!(cond)) { set_error(name ": bad arguments"); return SCDA_EINVAL; }
 
 SCDA_API int scda_maxpool2x2_fwd_hip(const float *x, float *y, uint8_t *idx, int planes, int H, int W, void *stream) {
-    NN_CHECK(x && y && idx && planes > 0 && H >= 2 && W >= 2 && (W % 2) == 0, "scda_maxpool2x2_fwd_hip")
+    NN_CHECK(x && y && idx && planes > 0 && H >= 2 && W >= 2, "scda_maxpool2x2_fwd_hip")
     const int OH = H / 2, OW = W / 2;
     const long long total = (long long)planes * OH * OW;
     hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(ew_grid(total) * 4), dim3(256), 0, as_stream(stream), x, y, idx, total, H, W, OH, OW);
@@ -679,7 +695,7 @@ SCDA_API int scda_maxpool2x2_fwd_hip(const float *x, float *y, uint8_t *idx, int
 
 SCDA_API int scda_maxpool2x2_bwd_hip(const float *dy, const uint8_t *idx, float *dx, int planes, int H, int W,
                                      void *stream) {
-    NN_CHECK(dy && dx && idx && planes > 0 && (H % 2) == 0 && (W % 2) == 0, "scda_maxpool2x2_bwd_hip")
+    NN_CHECK(dy && dx && idx && planes > 0 && H >= 2 && W >= 2, "scda_maxpool2x2_bwd_hip")
     const int OH = H / 2, OW = W / 2;
     const long long total = (long long)planes * OH * OW;
     hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(ew_grid(total) * 4), dim3(256), 0, as_stream(stream), dy, idx, dx, total, H, W, OH, OW);

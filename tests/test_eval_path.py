@@ -131,3 +131,40 @@ def test_validate_on_device_matches_reference(cuda, tmp_path):
     assert len(got) == len(want)
     frac = match_fraction(want, got)
     assert frac >= 0.95, frac
+
+
+@pytest.mark.gpu
+def test_eval_forward_on_odd_sized_image(cuda):
+    """200x312 input: the pooled feature maps are 100x156, 50x78, 25x39, 12x19 -- odd extents on the way (floor-mode pooling,
+    ragged conv tiles, a 12x19 anchor grid).  Detections of the HIP detector vs the CPU oracle detector, same weights."""
+    import scda_amd.dropin as dropin
+    dropin.install()
+    from models.faster_rcnn import vgg_adver_expansion_cluster as V
+    from oracle import torch_ref as R
+    H, W = 200, 312
+    cfg = dict(CFG)
+    torch.manual_seed(1)
+    ref = R.build_models(CFG)[0]
+    si.seeded_reinit(ref, EVAL_SEEDS['det'], 'det')
+    det = V.vgg16(pretrained=False, cfg=dict(CFG['shared'], gan_model_flag=2))
+    si.seeded_reinit(det, EVAL_SEEDS['det'], 'det')
+    det = det.to(cuda).eval()
+    ref.eval()
+    img = si.synth_images(77, H, W)[0]
+    x = {'cfg': cfg, 'image_info': torch.tensor([[H, W, 1.0]]), 'ground_truth_bboxes': None, 'ignore_regions': None}
+    R.use_cpu_backend()
+    try:
+        with torch.no_grad():
+            want = ref(dict(x, image=img))['predict']
+    finally:
+        R.reset_backend()
+    with torch.no_grad():
+        got = det(dict(x, image=img.to(cuda)))['predict']
+    assert abs(got[0].shape[0] - want[0].shape[0]) <= 3                     # proposals after NMS
+    g, w = got[1].cpu().numpy(), want[1].numpy()
+    assert g.shape[1] == 7 and abs(g.shape[0] - w.shape[0]) <= 2
+    hit = 0
+    for row in w:
+        d = np.abs(g[:, 1:5] - row[1:5]).max(axis=1) + 1e3 * (g[:, 6] != row[6]) + 1e3 * (np.abs(g[:, 5] - row[5]) > 1e-4)
+        hit += d.min() < 0.05
+    assert hit >= 0.95 * len(w), (hit, len(w))

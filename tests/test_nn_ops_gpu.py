@@ -19,9 +19,10 @@ def gen(seed):
     return torch.Generator().manual_seed(seed)
 
 
-def test_maxpool(cuda):
+@pytest.mark.parametrize("hw", [(8, 12), (7, 9), (6, 11), (9, 10)])      # odd extents: floor mode drops the last row / column
+def test_maxpool(cuda, hw):
     from scda_amd import autograd_ops as A
-    x = torch.randn(2, 5, 8, 12, generator=gen(1))
+    x = torch.randn(2, 5, *hw, generator=gen(1))
     x[0, 0, 0, :4] = 1.0  # ties -> first wins
     xr = x.clone().requires_grad_()
     y = F.max_pool2d(xr, 2, 2)
