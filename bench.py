@@ -7,7 +7,7 @@
 
 One "step" = one iteration = 1 source + 1 target 512x1024 image per GPU; images/s = 2 * N * steps / time.
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline      dominant kernel (fp32-MFMA implicit-GEMM conv forward with direct-to-LDS staging, 3x3 stride 1, 128-row tile): algorithmic FLOPs of its
+  roofline      dominant kernel (fp32-MFMA implicit-GEMM conv forward with direct-to-LDS staging, 3x3 stride 1, 128- or 256-row tiles): algorithmic FLOPs of its
                 launches inside the timed region / their summed duration (HIP events recorded on the launch stream by the
                 library's profiler), against the 157.3 TFLOP/s fp32-MFMA peak
   cpu_baseline  the CPU oracle of the same iteration (oracle/torch_ref.py, a faithful PyTorch-CPU restatement of the
@@ -45,7 +45,7 @@ for _k in CFG:
 
 H, W, G = 512, 1024, 12
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
-DOMINANT = "conv_igemm_glds_kernel<128,*,3,3,1,0>"
+DOMINANT = "conv_igemm_glds_kernel<128+,*,3,3,1,0>"   # tile rows 128 or 256 (8 waves), any tile width
 
 
 def synth_batch(rank):

@@ -287,16 +287,21 @@ struct GldsOperand {
 // stages), which is 1 x 4 so that every wave still owns a 64 x 64 sub-tile = 32 MFMAs per barrier; with 64 x 128 tiles a
 // wave had 32 x 64 = 16 MFMAs per barrier and those layers ran at 75 instead of ~100 TFLOP/s.
 template <int BM, int BN, int KH, int KW, int S, bool DGRAD>
-__global__ __launch_bounds__(256) void conv_igemm_glds_kernel(const float *__restrict__ Wt, const float *__restrict__ X,
-                                                              const ConvGeom g, const Epi e) {
+__global__ __launch_bounds__(BM == 256 ? 512 : 256) void conv_igemm_glds_kernel(const float *__restrict__ Wt,
+                                                                                const float *__restrict__ X,
+                                                                                const ConvGeom g, const Epi e) {
     constexpr int NST = 4, STAGE = BK * (BM + BN);
-    constexpr int WGN = BN == 256 ? 4 : 2, WGM = 4 / WGN;          // waves along N / M
+    // 256 x 128 tile: EIGHT waves (4 x 2), one workgroup per CU (96 KB of LDS): the gathered pixel operand is shared by twice
+    // as many output channels (+6.6 % on conv3_2 in scripts/ablate/conv_glds.hip); used when Cout % 256 == 0 and the grid
+    // comes out at a multiple of 256 workgroups (conv3_x, conv4_x, conv5_x all do)
+    constexpr int NW = BM == 256 ? 8 : 4;
+    constexpr int WGN = BN == 256 ? 4 : 2, WGM = NW / WGN;         // waves along N / M
     constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
     constexpr int A_LPR = BM / 4;             // lanes per weight row (dwordx4 each)
     constexpr int A_RPI = 64 / A_LPR;         // rows per wave-instruction
-    constexpr int A_PW = BK / A_RPI / 4;      // A instructions per wave per slab
+    constexpr int A_PW = BK / A_RPI / NW;     // A instructions per wave per slab
     constexpr int HALVES = BN / 64;           // 64-pixel pieces per B row
-    constexpr int B_PW = 4 * HALVES;          // B instructions (= rows) per wave per slab (64 x 256 tile: all 16 rows)
+    constexpr int B_PW = BK * HALVES / NW;    // B instructions (= rows) per wave per slab (64 x 256 tile: all 16 rows)
     constexpr int L = A_PW + B_PW;            // LDS-DMA instructions per wave per slab
     __shared__ __attribute__((aligned(16))) float lds[NST * STAGE];
 
@@ -1063,13 +1068,14 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const float *
 // that is left with ONE workgroup runs it at about half speed.  Measured: the conv3_2 weight gradient at 756 workgroups
 // (2.95 per CU -> a round of two, then a round of one) ran at 81 TFLOP/s, at 504 (one round of two) 101 TFLOP/s.
 //   time(plan) = flops / (model efficiency x 110 TFLOP/s) + split-K slab traffic (write + read) at 3 TB/s
-struct LaunchPlan { int bn, splits; };
+struct LaunchPlan { int bn, splits, bm; };
 
-static int resident_per_cu(int bm, int bn) { return ((bm == 128 && bn == 128) || bn == 256) ? 2 : (bm == 64 && bn == 64) ? 4 : 3; }
-static double tile_efficiency(int bm, int bn) { return ((bm == 128 && bn == 128) || bn == 256) ? 1.0 : (bm == 64 && bn == 64) ? 0.85 : 0.94; }
+static int resident_per_cu(int bm, int bn) { return bm == 256 ? 1 : ((bm == 128 && bn == 128) || bn == 256) ? 2 : (bm == 64 && bn == 64) ? 4 : 3; }
+static double tile_efficiency(int bm, int bn) { return bm == 256 ? 1.06 : ((bm == 128 && bn == 128) || bn == 256) ? 1.0 : (bm == 64 && bn == 64) ? 0.85 : 0.94; }
 
 // time, in units of one workgroup running at full CU speed, for the busiest CU to finish c workgroups with p resident
-static double cu_rounds(int c, int p) {
+static double cu_rounds(int c, int p, bool eight_waves = false) {
+    if (eight_waves) return (double)c;   // an 8-wave workgroup keeps the CU's MFMA pipes fed on its own
     double t = 0;
     while (c > 0) {
         const int r = c < p ? c : p;
@@ -1082,7 +1088,7 @@ static double cu_rounds(int c, int p) {
 static double plan_cost(long long tiles, int splits, int bm, int bn, double flops, double out_bytes) {
     const long long wgs = tiles * splits;
     const double ideal = (double)wgs / 256.0;
-    const double eff = ideal / cu_rounds(cdiv(wgs, 256), resident_per_cu(bm, bn)) * tile_efficiency(bm, bn);
+    const double eff = ideal / cu_rounds(cdiv(wgs, 256), resident_per_cu(bm, bn), bm == 256) * tile_efficiency(bm, bn);
     double t = flops / (eff * 110e12);
     if (splits > 1) t += 2.0 * splits * out_bytes / 3e12;
     return t;
@@ -1090,39 +1096,43 @@ static double plan_cost(long long tiles, int splits, int bm, int bn, double flop
 
 // bn_lo..bn_hi: candidate N-tile widths (64 and/or 128); must_split: the kernel always writes slabs (weight gradient)
 static LaunchPlan plan_search(int M, int N, int K, int bm, bool allow64, bool allow128, bool must_split, size_t ws_bytes,
-                              int k_granule, bool allow256);
+                              int k_granule, bool allow256, bool allow_bm256);
 
 // memoised per thread (the same ~60 shapes recur every iteration; launches come from the main and the autograd thread)
 static LaunchPlan plan_launch(int M, int N, int K, int bm, bool allow64, bool allow128, bool must_split, size_t ws_bytes,
-                              int k_granule, bool allow256 = false) {
+                              int k_granule, bool allow256 = false, bool allow_bm256 = false) {
     struct Key { int M, N, K, flags; size_t ws; };
     struct Entry { Key k; LaunchPlan p; };
     static thread_local std::vector<Entry> cache;
-    const Key key{M, N, K, bm | (allow64 << 8) | (allow128 << 9) | (must_split << 10) | (allow256 << 11) | (k_granule << 12), ws_bytes};
+    const Key key{M, N, K, bm | (allow64 << 8) | (allow128 << 9) | (must_split << 10) | (allow256 << 11) | (k_granule << 12) | (allow_bm256 << 20), ws_bytes};
     for (const Entry &e : cache)
         if (e.k.M == key.M && e.k.N == key.N && e.k.K == key.K && e.k.flags == key.flags && e.k.ws == key.ws) return e.p;
-    const LaunchPlan p = plan_search(M, N, K, bm, allow64, allow128, must_split, ws_bytes, k_granule, allow256);
+    const LaunchPlan p = plan_search(M, N, K, bm, allow64, allow128, must_split, ws_bytes, k_granule, allow256, allow_bm256);
     if (cache.size() < 512) cache.push_back(Entry{key, p});
     return p;
 }
 
 static LaunchPlan plan_search(int M, int N, int K, int bm, bool allow64, bool allow128, bool must_split, size_t ws_bytes,
-                              int k_granule, bool allow256) {
+                              int k_granule, bool allow256, bool allow_bm256) {
     const double flops = 2.0 * M * (double)N * K, out_bytes = (double)M * N * sizeof(float);
-    LaunchPlan best{allow128 ? 128 : 64, 1};
     double best_t = 1e30;
     int max_s = K / (k_granule * 4);   // at least 4 K-steps per split
     if (max_s < 1) max_s = 1;
     if (max_s > 256) max_s = 256;
     while (max_s > 1 && (size_t)max_s * M * N * sizeof(float) > ws_bytes) --max_s;
-    for (int bn = 64; bn <= 256; bn *= 2) {
-        if ((bn == 64 && !allow64) || (bn == 128 && !allow128) || (bn == 256 && !allow256)) continue;
-        const long long tiles = (long long)cdiv(M, bm) * cdiv(N, bn);
-        for (int sp = 1; sp <= max_s; ++sp) {
-            if (tiles * sp > 4096 && sp > 1) break;   // plenty of workgroups already: splitting only adds traffic
-            double t = plan_cost(tiles, sp, bm, bn, flops, out_bytes);
-            if (must_split && sp == 1) t += 2.0 * out_bytes / 3e12;
-            if (t < best_t) { best_t = t; best = LaunchPlan{bn, sp}; }
+    LaunchPlan best{allow128 ? 128 : 64, 1, bm};
+    for (int pass = 0; pass < (allow_bm256 ? 2 : 1); ++pass) {
+        const int tbm = pass ? 256 : bm;
+        for (int bn = 64; bn <= 256; bn *= 2) {
+            if ((bn == 64 && !allow64) || (bn == 128 && !allow128) || (bn == 256 && !allow256)) continue;
+            if (tbm == 256 && bn != 128) continue;
+            const long long tiles = (long long)cdiv(M, tbm) * cdiv(N, bn);
+            for (int sp = 1; sp <= max_s; ++sp) {
+                if (tiles * sp > 4096 && sp > 1) break;   // plenty of workgroups already: splitting only adds traffic
+                double t = plan_cost(tiles, sp, tbm, bn, flops, out_bytes);
+                if (must_split && sp == 1) t += 2.0 * out_bytes / 3e12;
+                if (t < best_t) { best_t = t; best = LaunchPlan{bn, sp, tbm}; }
+            }
         }
     }
     return best;
@@ -1142,15 +1152,22 @@ static int launch_conv(const float *Wm, const float *X, const ConvGeom &g0, Epi 
     const int BMv = small_m ? 64 : 128;
     static const char *force = getenv("SCDA_CONV_BN");   // experiment knob: 64 | 128
     const int fbn = force ? (atoi(force) == 64 ? 64 : 128) : 0;
-    const LaunchPlan plan = plan_launch(g.M, g.N, g.K, BMv, fbn != 128, fbn != 64, false, ws_bytes, BK,
-                                        small_m && g.slab_aligned && !fbn);
+    const char *fbm = getenv("SCDA_CONV_BM");            // experiment / test knob: 256 forces the 8-wave tile where legal
+    const bool bm256_ok = g.slab_aligned && (g.M % 256) == 0 && !fbn;
+    LaunchPlan plan = plan_launch(g.M, g.N, g.K, BMv, fbn != 128, fbn != 64, false, ws_bytes, BK,
+                                  small_m && g.slab_aligned && !fbn, bm256_ok && !(fbm && atoi(fbm) != 256));
+    if (bm256_ok && fbm && atoi(fbm) == 256 && plan.bm != 256) {
+        plan.bm = 256; plan.bn = 128;
+        while (plan.splits > 1 && (size_t)plan.splits * g.M * g.N * sizeof(float) > ws_bytes) --plan.splits;
+    }
     const int BNv = plan.bn;
+    const int BMt = plan.bm;                             // tile rows of this launch (BMv unless the 8-wave tile was chosen)
     int splits = plan.splits;
     g.k_per_split = round_k_per_split(g.K, splits);
     splits = cdiv(g.K, g.k_per_split);
     e.splits = splits;
     e.ws = ws;
-    g.nx = cdiv(g.N, BNv); g.ny = cdiv(g.M, BMv); g.swz = xcd_swizzle_enabled();
+    g.nx = cdiv(g.N, BNv); g.ny = cdiv(g.M, BMt); g.swz = xcd_swizzle_enabled();
     dim3 grid((unsigned)g.nx * g.ny * splits);
     prof_begin(g.slab_aligned ? PK_CONV + ((DGRAD ? 2 : 0) + (small_m ? 1 : 0)) * 3 + prof_shape(KH, S) : (int)PK_CONV_GATHER,
                2.0 * g.M * (double)g.N * g.K, st,
@@ -1163,7 +1180,8 @@ static int launch_conv(const float *Wm, const float *X, const ConvGeom &g0, Epi 
         else                                                                                                             \
             hipLaunchKernelGGL((conv_igemm_kernel<BM_, BN_, KH, KW, S, DGRAD>), grid, dim3(256), 0, st, Wm, X, g, e);        \
     } while (0)
-    if (small_m && BNv == 256) hipLaunchKernelGGL((conv_igemm_glds_kernel<64, 256, KH, KW, S, DGRAD>), grid, dim3(256), 0, st, Wm, X, g, e);
+    if (BMt == 256) hipLaunchKernelGGL((conv_igemm_glds_kernel<256, 128, KH, KW, S, DGRAD>), grid, dim3(512), 0, st, Wm, X, g, e);
+    else if (small_m && BNv == 256) hipLaunchKernelGGL((conv_igemm_glds_kernel<64, 256, KH, KW, S, DGRAD>), grid, dim3(256), 0, st, Wm, X, g, e);
     else if (small_m && BNv == 64) CONV_LAUNCH(64, 64);
     else if (small_m) CONV_LAUNCH(64, 128);
     else if (BNv == 64) CONV_LAUNCH(128, 64);
