@@ -241,9 +241,9 @@ typedef const __attribute__((address_space(1))) void glb_void_t;
 //      lanes of one b128 pass hit 16 distinct 16-byte slots of the 256-byte bank row; the LDS-DMA destination is linear, so
 //      the permutation is applied to the per-lane SOURCE address (chunk c of row r is fetched by the lane whose slot is
 //      c ^ ((r>>2)&3)) and undone by the reader.
-template <int BMN, bool MC>
+template <int BMN, bool MC, int NW = 4>
 struct GldsOperand {
-    static constexpr int PW = BMN / 64;   // LDS-DMA instructions per wave per 16-deep slab (both layouts)
+    static constexpr int PW = BMN / 16 / NW;   // LDS-DMA instructions per wave per 16-deep slab (both layouts), NW waves
     // issue this wave's share of one slab: tile rows/cols start at mn0, K at k0
     __device__ static __forceinline__ void issue(const float *__restrict__ base, const int ld, const int extent, const int mn0,
                                                  const int k0, float *stage, const int wave, const int lane,
@@ -566,19 +566,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
 //       pixel with (row>>2)&3, so wave w takes the row groups whose (row>>2)&3 == w: every lane then owns ONE pixel of the
 //       slab for all 8 of its instructions and decodes (oy, ox) + the 9-bit tap-validity mask once per slab.
 template <int BM, int BN, int KH, int KW, int S>
-__global__ __launch_bounds__(256) void conv_wgrad_glds_kernel(const float *__restrict__ dY, const float *__restrict__ X,
-                                                              const WgradGeom g, float *__restrict__ ws,
-                                                              float *__restrict__ db_ws) {
-    using OA = GldsOperand<BM, false>;
-    using OB = GldsOperand<BN, false>;   // fragment reader only; staging is the gather below
+__global__ __launch_bounds__(BM == 256 ? 512 : 256) void conv_wgrad_glds_kernel(const float *__restrict__ dY,
+                                                                                const float *__restrict__ X,
+                                                                                const WgradGeom g, float *__restrict__ ws,
+                                                                                float *__restrict__ db_ws) {
+    constexpr int NW = BM == 256 ? 8 : 4;          // 256 x 128 tile: 4 x 2 waves (the gathered X rows serve 256 dY rows)
+    using OA = GldsOperand<BM, false, NW>;
+    using OB = GldsOperand<BN, false, NW>;   // fragment reader only; staging is the gather below
     constexpr int NST = 4, STAGE = BK * (BM + BN);
-    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
-    constexpr int B_PW = BN / 16;        // B instructions per wave per slab (4 rows each)
+    constexpr int WGM = NW / 2;
+    constexpr int WM = BM / WGM, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    constexpr int B_PW = BN / 4 / NW;    // B instructions per wave per slab (4 rows each)
+    constexpr int JG = NW / 4;           // waves sharing one swizzle class split the row groups between them
     constexpr int L = OA::PW + B_PW;
     __shared__ __attribute__((aligned(16))) float lds[NST * STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
+    const int wsw = wave & 3, wjg = wave >> 2;     // swizzle class of this wave's B rows, and which share of them it loads
     int tx, ty, tz;
     tile_coords(g.nx, g.ny, g.swz, tx, ty, tz);
     const int m0 = ty * BM, n0 = tx * BN;
@@ -587,11 +592,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_glds_kernel(const float *__res
     const int ohw = g.dOHW.d, ihw = g.IH * g.IW;
 
     // B gather: this lane's pixel inside a slab (after the swizzle) and the (ci, tap) constants of its 8 rows
-    const int kl = 4 * (((lane & 15) >> 2) ^ wave) + (lane & 3);
+    const int kl = 4 * (((lane & 15) >> 2) ^ wsw) + (lane & 3);
     int b_base[B_PW], b_tap[B_PW];
 #pragma unroll
     for (int j = 0; j < B_PW; ++j) {
-        const int n = n0 + 16 * j + 4 * wave + (lane >> 4);
+        const int n = n0 + 16 * (j * JG + wjg) + 4 * wsw + (lane >> 4);
         const int c = n / (KH * KW), rem = n - c * (KH * KW);
         const int kh = rem / KW, kw = rem - kh * KW;
         b_base[j] = c * ihw + (kh - g.pad) * g.IW + (kw - g.pad);
@@ -619,12 +624,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_glds_kernel(const float *__res
 #pragma unroll
         for (int j = 0; j < B_PW; ++j) {
             const float *src = ((mask >> b_tap[j]) & 1u) ? xb + b_base[j] : g.zp;
-            __builtin_amdgcn_global_load_lds((glb_void_t *)src, (lds_void_t *)(Bb + (16 * j + 4 * wave) * 16), 4, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void_t *)src, (lds_void_t *)(Bb + (16 * (j * JG + wjg) + 4 * wsw) * 16), 4, 0, 0);
         }
     };
 
     f32x16 acc[TM][TN];
-    zero_acc<BM, BN>(acc);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int jj = 0; jj < TN; ++jj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
     const int lr = lane & 31, lh = lane >> 5;
     // the workgroups of the first N-tile also produce db[m] = sum over pixels of dY[m][.] (one partial per K-split)
     const bool bias_rows = db_ws != nullptr && tx == 0 && wn == 0;
@@ -1204,8 +1214,16 @@ static int launch_wgrad(const float *dY, const float *X, WgradGeom g, float *dW,
         ws_bytes -= need;
     }
     const bool small = g.M <= 64;
-    const int BMv = small ? 64 : 128, BNv = (g.N <= 64) ? 64 : 128;
-    int splits = plan_launch(g.M, g.N, g.K, BMv, BNv == 64, BNv == 128, true, ws_bytes, 32).splits;
+    const int BNv = (g.N <= 64) ? 64 : 128;
+    static const bool no_glds = getenv("SCDA_WGRAD_NO_GLDS") != nullptr;   // A/B knob
+    const bool glds = !no_glds && g.a_vec4 && (g.dOHW.d % BK) == 0;
+    const char *fbm = getenv("SCDA_CONV_BM");                              // 256 forces the 8-wave tile where legal
+    const bool bm256_ok = glds && BNv == 128 && (g.M % 256) == 0;
+    LaunchPlan plan = plan_launch(g.M, g.N, g.K, small ? 64 : 128, BNv == 64, BNv == 128, true, ws_bytes, 32, false,
+                                  bm256_ok && !(fbm && atoi(fbm) != 256));
+    if (bm256_ok && fbm && atoi(fbm) == 256) plan.bm = 256;
+    const int BMv = plan.bm;
+    int splits = plan.splits;
     if ((size_t)splits * g.M * g.N * sizeof(float) > ws_bytes) { set_error("conv wgrad: workspace too small"); return SCDA_EINVAL; }
     g.k_per_split = (round_k_per_split(g.K, splits) + 31) / 32 * 32;
     splits = cdiv(g.K, g.k_per_split);
@@ -1221,12 +1239,12 @@ static int launch_wgrad(const float *dY, const float *X, WgradGeom g, float *dW,
         if (bk32) hipLaunchKernelGGL((conv_wgrad_kernel<BM_, BN_, KH, KW, S, 32>), grid, dim3(256), 0, st, dY, X, g, ws);   \
         else hipLaunchKernelGGL((conv_wgrad_kernel<BM_, BN_, KH, KW, S, 16>), grid, dim3(256), 0, st, dY, X, g, ws);        \
     } while (0)
-    static const bool no_glds = getenv("SCDA_WGRAD_NO_GLDS") != nullptr;   // A/B knob
-    const bool glds = !no_glds && g.a_vec4 && (g.dOHW.d % BK) == 0;
     if (db && !glds) { set_error("conv wgrad: the fused bias gradient needs OH*OW %% 16 == 0 and 16-byte aligned dy"); return SCDA_EINVAL; }
     float *db_ws = db ? ws + (size_t)splits * g.M * g.N : nullptr;
 #define WGRAD_GLDS_LAUNCH(BM_, BN_) hipLaunchKernelGGL((conv_wgrad_glds_kernel<BM_, BN_, KH, KW, S>), grid, dim3(256), 0, st, dY, X, g, ws, db_ws)
-    if (glds) {
+    if (glds && BMv == 256) {
+        hipLaunchKernelGGL((conv_wgrad_glds_kernel<256, 128, KH, KW, S>), grid, dim3(512), 0, st, dY, X, g, ws, db_ws);
+    } else if (glds) {
         if (small && BNv == 64) WGRAD_GLDS_LAUNCH(64, 64);
         else if (small) WGRAD_GLDS_LAUNCH(64, 128);
         else if (BNv == 64) WGRAD_GLDS_LAUNCH(128, 64);
