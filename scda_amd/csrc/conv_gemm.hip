@@ -876,12 +876,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float *__restrict__ A, 
 
 // ---- dense GEMM, direct-to-LDS (operand staging: GldsOperand above) -------------------------------------------------
 template <int BM, int BN, bool TA, bool TB>
-__global__ __launch_bounds__(256) void gemm_glds_kernel(const float *__restrict__ A, const float *__restrict__ B,
-                                                        const GemmGeom g, const Epi e) {
-    using OA = GldsOperand<BM, TA>;
-    using OB = GldsOperand<BN, TB>;
+__global__ __launch_bounds__(BM == 256 ? 512 : 256) void gemm_glds_kernel(const float *__restrict__ A,
+                                                                          const float *__restrict__ B, const GemmGeom g,
+                                                                          const Epi e) {
+    constexpr int NW = BM == 256 ? 8 : 4;          // 256 x 128 tile: 4 x 2 waves
+    using OA = GldsOperand<BM, TA, NW>;
+    using OB = GldsOperand<BN, TB, NW>;
     constexpr int NST = 4, STAGE = BK * (BM + BN);
-    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    constexpr int WM = BM / (NW / 2), WN = BN / 2, TM = WM / 32, TN = WN / 32;
     constexpr int L = OA::PW + OB::PW;
     __shared__ __attribute__((aligned(16))) float lds[NST * STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -900,7 +902,12 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const float *__restrict_
     };
 
     f32x16 acc[TM][TN];
-    zero_acc<BM, BN>(acc);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int jj = 0; jj < TN; ++jj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
     const int lr = lane & 31, lh = lane >> 5;
 
     if (s_begin < s_end) issue(s_begin, 0);
@@ -1408,9 +1415,18 @@ SCDA_API int scda_gemm_hip(const float *A, const float *B, float *C, int M, int 
                            int accumulate, void *ws, size_t ws_bytes, void *stream) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) { set_error("scda_gemm_hip: bad arguments"); return SCDA_EINVAL; }
     hipStream_t st = as_stream(stream);
-    const int BMv = (M <= 64) ? 64 : 128;
-    // (FC6 dgrad: 784 128-wide tiles = 3.06 per CU, the busiest CU carries 4 -> the plan takes 64-wide tiles)
-    const LaunchPlan plan = plan_launch(M, N, K, BMv, true, N > 64, false, ldc == N ? ws_bytes : 0, BK);
+    // direct-to-LDS kernel: whole 16-deep slabs, 16-byte addressable rows
+    static const bool no_glds = getenv("SCDA_GEMM_NO_GLDS") != nullptr;   // A/B knob
+    const bool glds = !no_glds && (K % BK) == 0 && (lda % 4) == 0 && (ldb % 4) == 0 && ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0 &&
+                      (!trans_a || (M % 4) == 0) && (!trans_b || (N % 4) == 0);
+    const char *fbm = getenv("SCDA_CONV_BM");                              // 256 forces the 8-wave tile where legal
+    // (not for the [K][M] x [K][N] form -- the FC weight gradient: measured 112 vs 115 TFLOP/s)
+    const bool bm256_ok = glds && (M % 256) == 0 && N > 64 && !(trans_a && trans_b);
+    // (FC6 dgrad: 784 128-wide tiles = 3.06 per CU, the busiest CU carries 4 -> the plan takes another tile shape)
+    LaunchPlan plan = plan_launch(M, N, K, (M <= 64) ? 64 : 128, true, N > 64, false, ldc == N ? ws_bytes : 0, BK, false,
+                                  bm256_ok && !(fbm && atoi(fbm) != 256));
+    if (bm256_ok && fbm && atoi(fbm) == 256) { plan.bm = 256; plan.bn = 128; }
+    const int BMv = plan.bm;
     const int BNv = plan.bn;
     int splits = plan.splits;
     if (splits > 1 && ldc != N) { set_error("scda_gemm_hip: split-K needs ldc == N"); return SCDA_EINVAL; }
@@ -1427,20 +1443,17 @@ SCDA_API int scda_gemm_hip(const float *A, const float *B, float *C, int M, int 
         else if (trans_a && !trans_b) hipLaunchKernelGGL((gemm_kernel<BM_, BN_, true, false>), grid, dim3(256), 0, st, A, B, g, e); \
         else hipLaunchKernelGGL((gemm_kernel<BM_, BN_, true, true>), grid, dim3(256), 0, st, A, B, g, e);  \
     } while (0)
-    // direct-to-LDS kernel: whole 16-deep slabs, 16-byte addressable rows
-    static const bool no_glds = getenv("SCDA_GEMM_NO_GLDS") != nullptr;   // A/B knob
-    const bool glds = !no_glds && (K % BK) == 0 && (lda % 4) == 0 && (ldb % 4) == 0 && ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0 &&
-                      (!trans_a || (M % 4) == 0) && (!trans_b || (N % 4) == 0);
 #define GEMM_GLDS_LAUNCH(BM_, BN_)                                                                       \
     do {                                                                                                 \
-        if (!trans_a && !trans_b) hipLaunchKernelGGL((gemm_glds_kernel<BM_, BN_, false, false>), grid, dim3(256), 0, st, A, B, g, e); \
-        else if (!trans_a && trans_b) hipLaunchKernelGGL((gemm_glds_kernel<BM_, BN_, false, true>), grid, dim3(256), 0, st, A, B, g, e); \
-        else if (trans_a && !trans_b) hipLaunchKernelGGL((gemm_glds_kernel<BM_, BN_, true, false>), grid, dim3(256), 0, st, A, B, g, e); \
-        else hipLaunchKernelGGL((gemm_glds_kernel<BM_, BN_, true, true>), grid, dim3(256), 0, st, A, B, g, e);  \
+        if (!trans_a && !trans_b) hipLaunchKernelGGL((gemm_glds_kernel<BM_, BN_, false, false>), grid, dim3(BM_ == 256 ? 512 : 256), 0, st, A, B, g, e); \
+        else if (!trans_a && trans_b) hipLaunchKernelGGL((gemm_glds_kernel<BM_, BN_, false, true>), grid, dim3(BM_ == 256 ? 512 : 256), 0, st, A, B, g, e); \
+        else if (trans_a && !trans_b) hipLaunchKernelGGL((gemm_glds_kernel<BM_, BN_, true, false>), grid, dim3(BM_ == 256 ? 512 : 256), 0, st, A, B, g, e); \
+        else hipLaunchKernelGGL((gemm_glds_kernel<BM_, BN_, true, true>), grid, dim3(BM_ == 256 ? 512 : 256), 0, st, A, B, g, e);  \
     } while (0)
     prof_begin(PK_GEMM, 2.0 * M * (double)N * K, st);
     if (glds) {
-        if (BMv == 64 && BNv == 64) GEMM_GLDS_LAUNCH(64, 64);
+        if (BMv == 256) GEMM_GLDS_LAUNCH(256, 128);
+        else if (BMv == 64 && BNv == 64) GEMM_GLDS_LAUNCH(64, 64);
         else if (BMv == 64) GEMM_GLDS_LAUNCH(64, 128);
         else if (BNv == 64) GEMM_GLDS_LAUNCH(128, 64);
         else GEMM_GLDS_LAUNCH(128, 128);
