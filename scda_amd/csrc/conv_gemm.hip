@@ -1088,7 +1088,7 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const float *
 struct LaunchPlan { int bn, splits, bm; };
 
 static int resident_per_cu(int bm, int bn) { return bm == 256 ? 1 : ((bm == 128 && bn == 128) || bn == 256) ? 2 : (bm == 64 && bn == 64) ? 4 : 3; }
-static double tile_efficiency(int bm, int bn) { return bm == 256 ? 1.06 : ((bm == 128 && bn == 128) || bn == 256) ? 1.0 : (bm == 64 && bn == 64) ? 0.85 : 0.94; }
+static double tile_efficiency(int bm, int bn) { return bm == 256 ? 1.03 : ((bm == 128 && bn == 128) || bn == 256) ? 1.0 : (bm == 64 && bn == 64) ? 0.85 : 0.94; }
 
 // time, in units of one workgroup running at full CU speed, for the busiest CU to finish c workgroups with p resident
 static double cu_rounds(int c, int p, bool eight_waves = false) {
