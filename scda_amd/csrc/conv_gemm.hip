@@ -27,6 +27,7 @@
 // `tile_coords` gives each XCD a CONTIGUOUS run of logical tile ids (bijective for any grid size) ordered M-tile
 // fastest, then N-tile, then K-split, so the workgroups that share an input tile (all M-tiles of one pixel tile, and
 // vertically adjacent pixel tiles) run on the same XCD at about the same time and share its L2.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <vector>
@@ -1088,7 +1089,7 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const float *
 struct LaunchPlan { int bn, splits, bm; };
 
 static int resident_per_cu(int bm, int bn) { return bm == 256 ? 1 : ((bm == 128 && bn == 128) || bn == 256) ? 2 : (bm == 64 && bn == 64) ? 4 : 3; }
-static double tile_efficiency(int bm, int bn) { return bm == 256 ? 1.03 : ((bm == 128 && bn == 128) || bn == 256) ? 1.0 : (bm == 64 && bn == 64) ? 0.85 : 0.94; }
+static double tile_efficiency(int bm, int bn) { return bm == 256 ? 1.05 : ((bm == 128 && bn == 128) || bn == 256) ? 1.0 : (bm == 64 && bn == 64) ? 0.85 : 0.90; }
 
 // time, in units of one workgroup running at full CU speed, for the busiest CU to finish c workgroups with p resident
 static double cu_rounds(int c, int p, bool eight_waves = false) {
@@ -1118,6 +1119,15 @@ static LaunchPlan plan_search(int M, int N, int K, int bm, bool allow64, bool al
 // memoised per thread (the same ~60 shapes recur every iteration; launches come from the main and the autograd thread)
 static LaunchPlan plan_launch(int M, int N, int K, int bm, bool allow64, bool allow128, bool must_split, size_t ws_bytes,
                               int k_granule, bool allow256 = false, bool allow_bm256 = false) {
+    if (const char *f = getenv("SCDA_PLAN_FORCE")) {   // tuning aid: "bm,bn,splits" for every launch (scripts/tune_plans.py)
+        int fb = 0, fn = 0, fs = 0;
+        if (sscanf(f, "%d,%d,%d", &fb, &fn, &fs) == 3) {
+            const bool ok = (fb == bm || (fb == 256 && allow_bm256)) && ((fn == 64 && allow64) || (fn == 128 && allow128) || (fn == 256 && allow256)) &&
+                            !(fb == 256 && fn != 128) && fs >= 1 && (fs == 1 || (size_t)fs * M * N * sizeof(float) <= ws_bytes) &&
+                            fs <= (K / (k_granule * 2) > 0 ? K / (k_granule * 2) : 1);
+            if (ok) return LaunchPlan{fn, fs, fb};
+        }
+    }
     struct Key { int M, N, K, flags; size_t ws; };
     struct Entry { Key k; LaunchPlan p; };
     static thread_local std::vector<Entry> cache;
