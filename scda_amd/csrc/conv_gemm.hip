@@ -1122,7 +1122,7 @@ static LaunchPlan plan_launch(int M, int N, int K, int bm, bool allow64, bool al
     if (const char *f = getenv("SCDA_PLAN_FORCE")) {   // tuning aid: "bm,bn,splits" for every launch (scripts/tune_plans.py)
         int fb = 0, fn = 0, fs = 0;
         if (sscanf(f, "%d,%d,%d", &fb, &fn, &fs) == 3) {
-            const bool ok = (fb == bm || (fb == 256 && allow_bm256)) && ((fn == 64 && allow64) || (fn == 128 && allow128) || (fn == 256 && allow256)) &&
+            const bool ok = (fb == bm || (fb == 256 && allow_bm256) || (fb == 64 && getenv("SCDA_PLAN_ALLOW_BM64"))) && ((fn == 64 && allow64) || (fn == 128 && allow128) || (fn == 256 && allow256)) &&
                             !(fb == 256 && fn != 128) && fs >= 1 && (fs == 1 || (size_t)fs * M * N * sizeof(float) <= ws_bytes) &&
                             fs <= (K / (k_granule * 2) > 0 ? K / (k_granule * 2) : 1);
             if (ok) return LaunchPlan{fn, fs, fb};
@@ -1148,8 +1148,12 @@ static LaunchPlan plan_search(int M, int N, int K, int bm, bool allow64, bool al
     if (max_s > 256) max_s = 256;
     while (max_s > 1 && (size_t)max_s * M * N * sizeof(float) > ws_bytes) --max_s;
     LaunchPlan best{allow128 ? 128 : 64, 1, bm};
-    for (int pass = 0; pass < (allow_bm256 ? 2 : 1); ++pass) {
-        const int tbm = pass ? 256 : bm;
+    // tile-row candidates: the natural one; 256 (8 waves) where legal; 64 for 65..128-row problems (the decoder's 128-channel
+    // layers: 512 half-height tiles and no split-K beat 128 full tiles split four ways by ~6 %)
+    const bool allow_bm64 = bm == 128 && M <= 128 && allow64 && !must_split && k_granule == BK;
+    for (int pass = 0; pass < 3; ++pass) {
+        if ((pass == 1 && !allow_bm256) || (pass == 2 && !allow_bm64)) continue;
+        const int tbm = pass == 1 ? 256 : pass == 2 ? 64 : bm;
         for (int bn = 64; bn <= 256; bn *= 2) {
             if ((bn == 64 && !allow64) || (bn == 128 && !allow128) || (bn == 256 && !allow256)) continue;
             if (tbm == 256 && bn != 128) continue;
@@ -1208,9 +1212,9 @@ static int launch_conv(const float *Wm, const float *X, const ConvGeom &g0, Epi 
             hipLaunchKernelGGL((conv_igemm_kernel<BM_, BN_, KH, KW, S, DGRAD>), grid, dim3(256), 0, st, Wm, X, g, e);        \
     } while (0)
     if (BMt == 256) hipLaunchKernelGGL((conv_igemm_glds_kernel<256, 128, KH, KW, S, DGRAD>), grid, dim3(512), 0, st, Wm, X, g, e);
-    else if (small_m && BNv == 256) hipLaunchKernelGGL((conv_igemm_glds_kernel<64, 256, KH, KW, S, DGRAD>), grid, dim3(256), 0, st, Wm, X, g, e);
-    else if (small_m && BNv == 64) CONV_LAUNCH(64, 64);
-    else if (small_m) CONV_LAUNCH(64, 128);
+    else if (BMt == 64 && BNv == 256) hipLaunchKernelGGL((conv_igemm_glds_kernel<64, 256, KH, KW, S, DGRAD>), grid, dim3(256), 0, st, Wm, X, g, e);
+    else if (BMt == 64 && BNv == 64) CONV_LAUNCH(64, 64);
+    else if (BMt == 64) CONV_LAUNCH(64, 128);
     else if (BNv == 64) CONV_LAUNCH(128, 64);
     else CONV_LAUNCH(128, 128);
 #undef CONV_LAUNCH
