@@ -49,6 +49,9 @@ void scda_prof_enable(unsigned kernel_mask);
 int scda_prof_num_kernels(void);
 const char *scda_prof_kernel_name(int k);
 int scda_prof_collect(long long *launches, double *ms, double *flops, double *bytes);
+/* test aid: {tile rows, tile cols, split-K count, 1 = direct-to-LDS kernel family} of the calling thread's most recent conv /
+ * GEMM launch (the planner's choice, or the SCDA_PLAN_FORCE="bm,bn,splits" override when that is legal for the shape) */
+void scda_debug_last_plan(int *out4);
 
 /* ---------------------------------------------------------------- NMS ---- */
 /* replaces  int gpu_nms(THLongTensor* keep, THLongTensor* num_out, THCudaTensor* boxes, float thresh)

@@ -1,5 +1,12 @@
-"""Builds the one natively-buildable piece of the reference into oracle/_ref/ (git-ignored, travels to the GPU box):
-extensions/_cython_bbox/cython_bbox.pyx, cythonized UNMODIFIED from where it lies under /root/reference.
+"""Builds the natively-buildable pieces of the reference into oracle/_ref/ (git-ignored, travels to the GPU box),
+cythonized UNMODIFIED from where they lie under /root/reference, by this recipe (not the reference's setup.py):
+    extensions/_cython_bbox/cython_bbox.pyx   bbox_overlaps (IoU without +1)           -> builds
+    extensions/_cython_bbox/cython_nms.pyx    greedy NMS (+1 IoU, ">=") and soft-NMS    -> ATTEMPTED, does not build here:
+        it declares `np.ndarray[np.int_t, ndim=1]` (cython_nms.pyx:45,48), and `int_t` is a COMPILE-time ctypedef that numpy
+        2.x removed from its numpy/__init__.cython-30.pxd (Cython 3.2.9 ships no numpy .pxd of its own): "cython_nms.pyx:45:23:
+        Invalid type".  Supplying the missing ctypedef would be writing a stand-in header, so this module counts as
+        unbuildable (the run-time `np.int` at :49 could have been aliased; the compile-time type cannot).  The attempt is kept
+        so the claim can be re-checked: `python oracle/build_ref.py` prints the compiler's message.
 The reference's CUDA (.cu) and TH-API (.c) sources are unbuildable here (no nvcc; TH/THC headers no longer exist in
 torch 2.x) -- see DESIGN.md."""
 import glob
@@ -10,27 +17,52 @@ import sys
 import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = "/root/reference/extensions/_cython_bbox/cython_bbox.pyx"
+SRC_DIR = "/root/reference/extensions/_cython_bbox"
+MODULES = ("cython_bbox", "cython_nms")
 OUT = os.path.join(HERE, "_ref")
 
 
 def main():
-    if not os.path.exists(SRC):
+    if not all(os.path.exists(os.path.join(SRC_DIR, m + ".pyx")) for m in MODULES):
         print("reference not present; keeping whatever is in oracle/_ref/")
         return
     os.makedirs(OUT, exist_ok=True)
     work = tempfile.mkdtemp(prefix="scda_ref_")
-    os.symlink(SRC, os.path.join(work, "cython_bbox.pyx"))
+    for m in MODULES:
+        os.symlink(os.path.join(SRC_DIR, m + ".pyx"), os.path.join(work, m + ".pyx"))
     with open(os.path.join(work, "setup_tmp.py"), "w") as f:
         f.write("from setuptools import setup, Extension\nfrom Cython.Build import cythonize\nimport numpy as np\n"
-                "setup(ext_modules=cythonize([Extension('cython_bbox', ['cython_bbox.pyx'], include_dirs=[np.get_include()],"
-                " extra_compile_args=['-O2'])], language_level=2))\n")
-    subprocess.check_call([sys.executable, "setup_tmp.py", "build_ext", "--inplace"], cwd=work,
-                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    for so in glob.glob(os.path.join(work, "cython_bbox*.so")):
-        shutil.copy(so, OUT)
-        print("built", os.path.join(OUT, os.path.basename(so)))
+                "import os\nmods = [os.environ['SCDA_REF_MODULE']]\n"
+                "setup(ext_modules=cythonize([Extension(m, [m + '.pyx'], include_dirs=[np.get_include()],"
+                " extra_compile_args=['-O2']) for m in mods], language_level=2))\n")
+    for m in MODULES:   # one module per invocation: a module that does not compile must not take the other one down
+        r = subprocess.run([sys.executable, "setup_tmp.py", "build_ext", "--inplace"], cwd=work, capture_output=True, text=True,
+                           env=dict(os.environ, SCDA_REF_MODULE=m))
+        hits = glob.glob(os.path.join(work, m + "*.so"))
+        if r.returncode == 0 and hits:
+            shutil.copy(hits[0], OUT)
+            print("built", os.path.join(OUT, os.path.basename(hits[0])))
+        else:
+            why = [l for l in (r.stdout + r.stderr).splitlines() if ".pyx:" in l]
+            print("NOT built: %s.pyx (%s)" % (m, why[0].strip() if why else "exit %d" % r.returncode))
     shutil.rmtree(work, ignore_errors=True)
+
+
+def load(name):
+    """import oracle/_ref/<name>*.so (None if it has not been built); sets the numpy aliases cython_nms needs"""
+    import importlib.util
+    import numpy as np
+    if not hasattr(np, "int"):
+        np.int = int
+    if not hasattr(np, "float"):
+        np.float = float
+    hits = glob.glob(os.path.join(OUT, name + "*.so"))
+    if not hits:
+        return None
+    spec = importlib.util.spec_from_file_location(name, hits[0])
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
 
 
 if __name__ == "__main__":

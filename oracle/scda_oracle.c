@@ -6,12 +6,22 @@
  * __graft_entry__.smoke() and by bench.py's cpu_baseline leg as the checker.
  *
  * Every function cites the reference file:line (relative to /root/reference)
- * whose arithmetic it restates.  The reference's CUDA sources cannot be built
- * here (no nvcc, TH/THC headers removed from torch), so these restatements
- * are pinned instead by (a) the reference's Cython bbox_overlaps built
- * unmodified in the survey container, (b) the reference Python call sites run
- * end-to-end on CPU, and (c) independent second statements of the same op
- * inside the reference (roi_pool_py.py, nms.c); see tests/golden/make_golden.py.
+ * whose arithmetic it restates.  How each restatement is pinned:
+ *   bbox_overlaps (IoU without +1): BIT-EXACT against the reference's own Cython
+ *     (extensions/_cython_bbox/cython_bbox.pyx built unmodified by
+ *     oracle/build_ref.py; vectors in tests/golden/bbox_overlaps.npz).
+ *   NMS, RoIPool, RoIAlign, focal loss, the "+1/clamped" IoU: PARITY UNPINNED
+ *     against a build of the reference.  Their sources cannot be built or run
+ *     here: the .cu files need nvcc and the TH/THC headers torch 2.x no longer
+ *     ships; nms.c / roi_pooling.c use the removed TH API; cython_nms.pyx needs
+ *     the compile-time ctypedef np.int_t that numpy 2.x dropped (build_ref.py
+ *     keeps the attempt and prints the compiler error); roi_pool_py.py indexes
+ *     0-dim tensors and relies on torch<=0.3 `max` keeping the reduced
+ *     dimension.  The reference holds no tests or vectors for them.  What they
+ *     ARE checked against: independent second statements written from the
+ *     operator definitions (tests/np_restate.py, float64 autograd closed forms:
+ *     tests/test_oracle_golden.py), and their use inside the reference's own
+ *     Python call sites run end to end on CPU (tests/golden/ref_harness.py).
  *
  * Build: gcc -O2 -ffp-contract=off -fno-fast-math -shared -fPIC (oracle/Makefile).
  * -ffp-contract=off is part of the definition: the canonical arithmetic of the

@@ -1088,6 +1088,11 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const float *
 //   time(plan) = flops / (model efficiency x 110 TFLOP/s) + split-K slab traffic (write + read) at 3 TB/s
 struct LaunchPlan { int bn, splits, bm; };
 
+// tile shape / split count / kernel family of this thread's most recent GEMM-class launch (scda_debug_last_plan: the parity
+// tests force every instantiation through SCDA_PLAN_FORCE and must be able to tell that the forced one really ran)
+static thread_local int g_last_plan[4] = {0, 0, 0, 0};
+static void note_plan(int bm, int bn, int splits, int glds) { g_last_plan[0] = bm; g_last_plan[1] = bn; g_last_plan[2] = splits; g_last_plan[3] = glds; }
+
 static int resident_per_cu(int bm, int bn) { return bm == 256 ? 1 : ((bm == 128 && bn == 128) || bn == 256) ? 2 : (bm == 64 && bn == 64) ? 4 : 3; }
 static double tile_efficiency(int bm, int bn) { return bm == 256 ? 1.05 : ((bm == 128 && bn == 128) || bn == 256) ? 1.0 : (bm == 64 && bn == 64) ? 0.85 : 0.90; }
 
@@ -1200,6 +1205,7 @@ static int launch_conv(const float *Wm, const float *X, const ConvGeom &g0, Epi 
     e.ws = ws;
     g.nx = cdiv(g.N, BNv); g.ny = cdiv(g.M, BMt); g.swz = xcd_swizzle_enabled();
     dim3 grid((unsigned)g.nx * g.ny * splits);
+    note_plan(BMt, BNv, splits, g.slab_aligned);
     prof_begin(g.slab_aligned ? PK_CONV + ((DGRAD ? 2 : 0) + (small_m ? 1 : 0)) * 3 + prof_shape(KH, S) : (int)PK_CONV_GATHER,
                2.0 * g.M * (double)g.N * g.K, st,
                4.0 * ((double)g.batch * g.CB * g.HB * g.WB + (double)g.M * g.K + (double)g.M * g.N));
@@ -1250,6 +1256,7 @@ static int launch_wgrad(const float *dY, const float *X, WgradGeom g, float *dW,
     splits = cdiv(g.K, g.k_per_split);
     g.nx = cdiv(g.N, BNv); g.ny = cdiv(g.M, BMv); g.swz = xcd_swizzle_enabled();
     dim3 grid((unsigned)g.nx * g.ny * splits);
+    note_plan(BMv, BNv, splits, glds);
     prof_begin(PK_CONV_WGRAD + prof_shape(KH, S), 2.0 * g.M * (double)g.N * g.K, st);
     static const char *wbk_env = getenv("SCDA_WGRAD_BK");
     // measured (SCDA_WGRAD_BK=16|32 A/B): 32-deep slabs gain 10-17 % for the 64-row tiles (conv1_x, decoder heads), lose
@@ -1418,6 +1425,10 @@ SCDA_API int scda_conv2d_wgrad_bias_hip(const float *dy, const float *x, float *
     CONV_DISPATCH(launch_wgrad, > (dy, x, g, dw, accumulate, (float *)ws, ws_bytes, as_stream(stream), db, db_accumulate))
 }
 
+SCDA_API void scda_debug_last_plan(int *out4) {
+    for (int i = 0; i < 4; ++i) out4[i] = g_last_plan[i];
+}
+
 SCDA_API size_t scda_gemm_workspace_bytes(int M, int N, int K) {
     (void)K;
     return (size_t)16 * M * N * sizeof(float);
@@ -1464,6 +1475,7 @@ SCDA_API int scda_gemm_hip(const float *A, const float *B, float *C, int M, int 
         else if (trans_a && !trans_b) hipLaunchKernelGGL((gemm_glds_kernel<BM_, BN_, true, false>), grid, dim3(BM_ == 256 ? 512 : 256), 0, st, A, B, g, e); \
         else hipLaunchKernelGGL((gemm_glds_kernel<BM_, BN_, true, true>), grid, dim3(BM_ == 256 ? 512 : 256), 0, st, A, B, g, e);  \
     } while (0)
+    note_plan(BMv, BNv, splits, glds);
     prof_begin(PK_GEMM, 2.0 * M * (double)N * K, st);
     if (glds) {
         if (BMv == 256) GEMM_GLDS_LAUNCH(256, 128);

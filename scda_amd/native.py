@@ -657,6 +657,13 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_de
                                f32(eps), f32(weight_decay), i32(step), _stream()), "scda_adam_hip")
 
 
+def last_plan():
+    """(tile rows, tile cols, split-K count, direct-to-LDS?) of this thread's most recent conv / GEMM launch"""
+    out = (ctypes.c_int * 4)()
+    lib().scda_debug_last_plan(out)
+    return out[0], out[1], out[2], bool(out[3])
+
+
 # ------------------------------------------------------------ profiler ------
 def prof_kernel_names():
     L = lib()

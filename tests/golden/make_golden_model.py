@@ -88,7 +88,7 @@ def run_reference_iteration(ns, H, W, lr=1e-3, G=6):
 
 
 def generate(ns, outdir):
-    for (H, W) in ((256, 512),):
+    for (H, W) in ((256, 512), (512, 1024)):   # the second one is BASELINE.json's size (configs[1])
         out = run_reference_iteration(ns, H, W)
         np.savez_compressed(os.path.join(outdir, f"train_step_{H}x{W}.npz"), **out)
         print(f"train_step_{H}x{W}.npz written ({out['seconds']:.1f}s):", out['log_line'])

@@ -1,15 +1,17 @@
 """Pin the model-level CPU oracle (oracle/torch_ref.py) against the reference's own train() iteration
-(tests/golden/train_step_256x512.npz, produced by tests/golden/make_golden_model.py).  CPU only."""
+(tests/golden/train_step_{256x512,512x1024}.npz, produced by tests/golden/make_golden_model.py).  CPU only."""
 import os
 
 import numpy as np
+import pytest
 import torch
 
 import model_common as mc
 
 
-def test_oracle_iteration_matches_reference_train(golden_dir):
-    g = np.load(os.path.join(golden_dir, "train_step_256x512.npz"))
+@pytest.mark.parametrize("size", ["256x512", "512x1024"])   # the second is BASELINE.json's configs[1] size
+def test_oracle_iteration_matches_reference_train(golden_dir, size):
+    g = np.load(os.path.join(golden_dir, "train_step_%s.npz" % size))
     H, W = int(g["H"]), int(g["W"])
     res, (det, dec, dis, dis_patch), _ = mc.oracle_iteration(H, W, lr=float(g["lr"]))
     # logged scalars (the reference prints 5 decimals; accuracies are logged /100)

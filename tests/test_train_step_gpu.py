@@ -89,10 +89,11 @@ def test_two_iterations_track_oracle(cuda):
     assert float(outs[1]['rcnn_cls']) != float(outs[0]['rcnn_cls'])        # the weights did move
 
 
-def test_iteration_matches_oracle(cuda):
+@pytest.mark.parametrize("H,W", [(256, 512), (512, 1024)])   # (512, 1024) = BASELINE.json's configs[1] size
+def test_iteration_matches_oracle(cuda, H, W):
     from scda_amd import layers as L
     from scda_amd.train_step import ScdaTrainer
-    H, W, lr = 256, 512, 1e-3
+    lr = 1e-3
     ref, ref_models, masks = mc.oracle_iteration(H, W, lr=lr, record_masks=True, capture=True)
 
     torch.manual_seed(1)
