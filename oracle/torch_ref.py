@@ -38,10 +38,58 @@ def reset_backend():
 
 
 # ------------------------------------------------------------------ layers --
+class SelectionRecorder:
+    """Records, at every non-differentiable selection of the iteration (ReLU / LeakyReLU sign, 2x2 max-pool winner, RoI
+    max-pool argmax), WHICH element this CPU run selected, keyed by the op's output (kind, shape, three moments).  The GPU parity
+    test replays these selections on the device (scda_amd.autograd_ops.replay), so that the gradient comparison is not
+    dominated by pre-activations that sit within fp32 round-off of a tie (tests/test_train_step_gpu.py)."""
+    active = None
+
+    def __init__(self):
+        self.records = []   # (kind, shape, l1, payload)
+
+    @staticmethod
+    def fingerprint(out):
+        """three float64 moments of |out| (plain, squared, position-weighted): distinct call sites of one shape never share all
+        three to 1e-4, the CPU and the device evaluation of the SAME site agree on each to ~1e-6"""
+        a = out.detach().double().abs().flatten()
+        ramp = torch.linspace(0.5, 1.5, a.numel(), dtype=torch.float64, device=a.device)
+        return float(a.sum()), float((a * a).sum()), float((a * ramp).sum())
+
+    def add(self, kind, out, payload):
+        self.records.append((kind, tuple(out.shape), self.fingerprint(out), payload))
+
+    def attach(self, *models):
+        handles = []
+        for m in models:
+            for mod in m.modules():
+                if isinstance(mod, (nn.ReLU, nn.LeakyReLU)):
+                    handles.append(mod.register_forward_hook(lambda _m, _i, out: self.add("act", out, (out > 0).clone())))
+                elif isinstance(mod, nn.MaxPool2d):
+                    def pool_hook(_m, inp, out):
+                        x = inp[0].detach()
+                        _, idx = F.max_pool2d(x, 2, 2, return_indices=True)     # flat index inside the input plane
+                        W = x.shape[-1]
+                        oy = torch.arange(out.shape[-2]).view(-1, 1)
+                        ox = torch.arange(out.shape[-1]).view(1, -1)
+                        code = (idx // W - 2 * oy) * 2 + (idx % W - 2 * ox)    # 0..3 = (dy, dx) of the winner in its window
+                        self.add("pool", out, code.to(torch.uint8))
+                    handles.append(mod.register_forward_hook(pool_hook))
+        SelectionRecorder.active = self
+        return handles
+
+    def detach(self, handles):
+        for h in handles:
+            h.remove()
+        SelectionRecorder.active = None
+
+
 class _RoIPoolFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feat, rois, ph, pw, scale):
         out, arg = orc.roi_pool_fwd(feat.detach().numpy(), rois.detach().numpy(), ph, pw, scale)
+        if SelectionRecorder.active is not None:
+            SelectionRecorder.active.add("roi", torch.from_numpy(out), torch.from_numpy(arg.copy()))
         ctx.save_for_backward(rois)
         ctx.arg, ctx.cfg = arg, (tuple(feat.shape), ph, pw, scale)
         return torch.from_numpy(out)

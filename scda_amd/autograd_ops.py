@@ -12,8 +12,23 @@ from . import native as N
 ACT_NONE, ACT_RELU, ACT_LEAKY = N.ACT_NONE, N.ACT_RELU, N.ACT_LEAKY
 
 
+# Parity-test hook (tests/model_common.py: ReplaySource).  ReLU / LeakyReLU / max-pool / RoI max-pool are not differentiable
+# at ties: two correct fp32 implementations whose activations differ by 1e-7 route a gradient differently wherever a
+# pre-activation sits within round-off of zero.  With `replay` set, each of these ops asks the hook for the selection the
+# CPU oracle made at the same site (matched by the output's shape and L1 norm) and differentiates through THAT instead of
+# its own, so the gradient comparison measures the kernels' arithmetic, not tie-breaking.  None in production.
+replay = None
+
+
 def _c(t):
     return t if t.is_contiguous() else t.contiguous()
+
+
+def _mask_src(ctx, y, kind="act"):
+    """tensor whose sign the backward's act' reads: y itself, or the oracle's selection when a replay hook is installed"""
+    if replay is not None and any(ctx.needs_input_grad):
+        return replay.act(y)
+    return y
 
 
 def _sink(p):
@@ -38,7 +53,7 @@ class Conv2dFn(Function):
         ctx.cfg = (stride, pad, act, slope)
         ctx.has_bias = b is not None
         ctx.bias_ref, ctx.w_ref = b, w   # the Parameter objects themselves (they carry the flat-bucket gradient views)
-        ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
+        ctx.save_for_backward(x, w, _mask_src(ctx, y) if act != ACT_NONE else None)
         return y
 
     @staticmethod
@@ -78,7 +93,7 @@ class LinearFn(Function):
         ctx.act = act
         ctx.has_bias = b is not None
         ctx.bias_ref, ctx.w_ref = b, w   # the Parameter objects themselves (they carry the flat-bucket gradient views)
-        ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
+        ctx.save_for_backward(x, w, _mask_src(ctx, y) if act != ACT_NONE else None)
         return y
 
     @staticmethod
@@ -108,6 +123,8 @@ class MaxPool2x2Fn(Function):
     def forward(ctx, x):
         x = _c(x)
         y, idx = N.maxpool2x2_fwd(x)
+        if replay is not None and any(ctx.needs_input_grad):
+            idx = replay.pool(y, idx)
         ctx.save_for_backward(idx)
         ctx.xshape = tuple(x.shape)
         return y
@@ -125,7 +142,7 @@ class ActFn(Function):
     def forward(ctx, x, mode, slope):
         y = N.act_fwd(_c(x), mode, slope)
         ctx.cfg = (mode, slope)
-        ctx.save_for_backward(y)
+        ctx.save_for_backward(_mask_src(ctx, y) if mode in (0, 1) else y)   # tanh / sigmoid are smooth: nothing to replay
         return y
 
     @staticmethod
@@ -166,6 +183,8 @@ class RoIPoolFn(Function):
         if not features.is_contiguous() or not rois.is_contiguous():
             raise AssertionError("RoIPool needs contiguous features and rois")  # roi_pool.py:25-26
         out, arg = N.roi_pool_fwd(features, rois, ph, pw, scale)
+        if replay is not None and any(ctx.needs_input_grad):
+            arg = replay.roi(out, arg)
         ctx.save_for_backward(rois, arg)
         ctx.cfg = (tuple(features.shape), ph, pw, scale)
         return out

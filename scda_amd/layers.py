@@ -124,6 +124,9 @@ class InstanceNorm2d(nn.Module):
         self.slope = slope
 
     def forward(self, x):
+        if A.replay is not None and self.fused_act != A.ACT_NONE:   # parity tests: activation un-fused so its mask can be replayed
+            y = A.InstanceNormFn.apply(x, self.eps, A.ACT_NONE, self.slope)
+            return A.ActFn.apply(y, 0 if self.fused_act == A.ACT_RELU else 1, self.slope)
         return A.InstanceNormFn.apply(x, self.eps, self.fused_act, self.slope)
 
 
@@ -140,6 +143,10 @@ class BatchNorm2d(nn.BatchNorm2d):
             raise NotImplementedError("scda_amd.BatchNorm2d: eval mode is not on the SCDA training path")
         if self.num_batches_tracked is not None:
             self.num_batches_tracked.add_(1)
+        if A.replay is not None and self.fused_act != A.ACT_NONE:   # parity tests: see InstanceNorm2d
+            y = A.BatchNormTrainFn.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
+                                         self.momentum, A.ACT_NONE, self.slope)
+            return A.ActFn.apply(y, 0 if self.fused_act == A.ACT_RELU else 1, self.slope)
         return A.BatchNormTrainFn.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
                                         self.momentum, self.fused_act, self.slope)
 

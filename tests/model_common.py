@@ -30,7 +30,39 @@ def seeded_inputs(H, W, G=6):
     return src, tgt, gts, info
 
 
-def oracle_iteration(H, W, lr=1e-3, record_masks=False, capture=False, cfg=None, steps=1):
+class ReplaySource:
+    """scda_amd.autograd_ops.replay hook: hands the device ops the selections the CPU oracle made at the same site
+    (oracle.torch_ref.SelectionRecorder), matched by the output's kind, shape and three moments (relative 1e-4; the two
+    implementations agree to ~1e-6, distinct call sites of one shape differ by far more)."""
+
+    def __init__(self, recorder, device):
+        self.by_key, self.device, self.used = {}, device, 0
+        for kind, shape, l1, payload in recorder.records:
+            self.by_key.setdefault((kind, shape), []).append((l1, payload))
+
+    def _find(self, kind, out):
+        cands = self.by_key.get((kind, tuple(out.shape)))
+        assert cands, "no oracle record for a %s output of shape %s" % (kind, tuple(out.shape))
+        from oracle.torch_ref import SelectionRecorder
+        fp = SelectionRecorder.fingerprint(out)
+        dist = lambda c: max(abs(a - b) / max(abs(b), 1e-12) for a, b in zip(c[0], fp))  # noqa: E731
+        best = min(cands, key=dist)
+        assert dist(best) <= 1e-4, (kind, tuple(out.shape), fp, best[0])
+        self.used += 1
+        return best[1].to(self.device)
+
+    def act(self, y):
+        sel = self._find("act", y)
+        return torch.where(sel, 1.0, -1.0).to(torch.float32)   # act' only reads the sign
+
+    def pool(self, y, idx):
+        return self._find("pool", y).reshape(idx.shape).contiguous()
+
+    def roi(self, out, arg):
+        return self._find("roi", out).reshape(arg.shape).contiguous()
+
+
+def oracle_iteration(H, W, lr=1e-3, record_masks=False, capture=False, cfg=None, steps=1, record_selections=False):
     """one RefTrainer step on CPU with the golden seeds; returns (result dict, models, masks)"""
     from oracle import torch_ref as R
     cfg = cfg or CFG
@@ -42,6 +74,8 @@ def oracle_iteration(H, W, lr=1e-3, record_masks=False, capture=False, cfg=None,
         tr.capture = capture
         src, tgt, gts, info = seeded_inputs(H, W)
         R.RecordingDropout.tape = [] if record_masks else None
+        rec = R.SelectionRecorder() if record_selections else None
+        handles = rec.attach(*models) if rec else None
         torch.manual_seed(SEEDS['torch'])
         np.random.seed(SEEDS['numpy'])
         res = tr.step(src, gts, info, tgt)
@@ -52,7 +86,11 @@ def oracle_iteration(H, W, lr=1e-3, record_masks=False, capture=False, cfg=None,
             res = dict(history[-1], _history=history)
         masks = R.RecordingDropout.tape
         R.RecordingDropout.tape = None
+        if rec:
+            rec.detach(handles)
+            res['_selections'] = rec
     finally:
         R.reset_backend()
+        R.SelectionRecorder.active = None
     res['_trace'] = tr.trace
     return res, models, masks

@@ -166,6 +166,54 @@ def test_iteration_matches_oracle(cuda, H, W):
     assert int(dp['model_A_patch.0.model.1.num_batches_tracked']) == 3
 
 
+@pytest.mark.parametrize("H,W", [(256, 512), (512, 1024)])
+def test_gradients_with_replayed_selections(cuda, H, W):
+    """The same iteration with the oracle's non-differentiable SELECTIONS replayed on the device (ReLU / LeakyReLU sign masks,
+    2x2 max-pool winners, RoI max-pool argmax -- scda_amd.autograd_ops.replay) in addition to the dropout masks: what is left
+    is the kernels' arithmetic.  Every gradient tensor of every phase then agrees with the oracle's to 1e-4 relative L2
+    (test_iteration_matches_oracle, which lets each side break its own ties, needs 5e-2)."""
+    from scda_amd import autograd_ops as A
+    from scda_amd import layers as L
+    from scda_amd.train_step import ScdaTrainer
+    lr = 1e-3
+    ref, ref_models, masks = mc.oracle_iteration(H, W, lr=lr, record_masks=True, capture=True, record_selections=True)
+    torch.manual_seed(1)
+    tr = ScdaTrainer(mc.CFG, cuda, lr=lr, new_w=W, new_h=H, models=mc.seeded_models(build_product))
+    tr.capture = True
+    src, tgt, gts, info = mc.seeded_inputs(H, W)
+    tape = list(masks)
+    L.Dropout.mask_source = lambda shape, p, device: tape.pop(0).to(device)
+    A.replay = mc.ReplaySource(ref['_selections'], cuda)
+    try:
+        np.random.seed(mc.SEEDS['numpy'])
+        out = tr.step(src.to(cuda), gts, info, tgt.to(cuda))
+        torch.cuda.synchronize()
+        used = A.replay.used
+    finally:
+        L.Dropout.mask_source = None
+        A.replay = None
+    assert not tape and used >= 40, used
+    for k in LOSS_KEYS:
+        a, b = float(out[k]), float(ref[k])
+        assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), (k, a, b)
+
+    def rel_l2(a, b):
+        a = a.detach().double().cpu(); b = b.detach().double().cpu()
+        return float((a - b).norm() / (b.norm() + 1e-30))
+
+    worst = {}
+    for name in ('dis', 'dis_patch', 'dec', 'det'):
+        rg, pg = ref['_trace'][name], tr.trace[name]
+        scale = float(max(t.abs().max() for t in rg.values()))
+        for k in rg:
+            if float(rg[k].abs().max()) < 1e-6 * scale:     # conv biases in front of InstanceNorm: mathematically zero
+                continue
+            e = rel_l2(pg[k], rg[k])
+            if e > worst.get(name, ('', 0.0))[1]:
+                worst[name] = (k, e)
+    assert all(e <= 1e-4 for _, e in worst.values()), worst
+
+
 def test_vgg16_bn_detector_trains(cuda):
     """the batch-norm backbone variant (vgg16_bn, `--arch vgg16bn_FasterRCNN` in the reference driver): one full iteration
     through the same step; finite losses, BN statistics updated, torchvision's vgg16_bn key layout"""
