@@ -51,6 +51,14 @@ class ReplaySource:
         self.used += 1
         return best[1].to(self.device)
 
+    def rpn(self, cls, loc):
+        """RPN outputs on their way into the proposal ranking: the oracle's, after checking that the device's agree to 1e-5"""
+        want_cls = self._find("rpn_cls", cls.detach()).cpu()
+        want_loc = self._find("rpn_loc", loc.detach()).cpu()
+        assert float((want_cls - cls.detach().cpu()).abs().max()) <= 1e-5
+        assert float((want_loc - loc.detach().cpu()).abs().max()) <= 1e-5 * max(1.0, float(want_loc.abs().max()))
+        return want_cls, want_loc
+
     def act(self, y):
         sel = self._find("act", y)
         return torch.where(sel, 1.0, -1.0).to(torch.float32)   # act' only reads the sign
@@ -76,6 +84,13 @@ def oracle_iteration(H, W, lr=1e-3, record_masks=False, capture=False, cfg=None,
         R.RecordingDropout.tape = [] if record_masks else None
         rec = R.SelectionRecorder() if record_selections else None
         handles = rec.attach(*models) if rec else None
+        from scda_amd.dropin.functions import rpn_proposal
+        if rec:
+            def record_rpn(cls, loc):
+                rec.add("rpn_cls", cls, cls.detach().clone())
+                rec.add("rpn_loc", loc, loc.detach().clone())
+                return cls, loc
+            rpn_proposal.rpn_output_hook = record_rpn
         torch.manual_seed(SEEDS['torch'])
         np.random.seed(SEEDS['numpy'])
         res = tr.step(src, gts, info, tgt)
@@ -92,5 +107,6 @@ def oracle_iteration(H, W, lr=1e-3, record_masks=False, capture=False, cfg=None,
     finally:
         R.reset_backend()
         R.SelectionRecorder.active = None
+        rpn_proposal.rpn_output_hook = None
     res['_trace'] = tr.trace
     return res, models, masks

@@ -89,11 +89,14 @@ def test_two_iterations_track_oracle(cuda):
     assert float(outs[1]['rcnn_cls']) != float(outs[0]['rcnn_cls'])        # the weights did move
 
 
-@pytest.mark.parametrize("H,W", [(256, 512), (512, 1024)])   # (512, 1024) = BASELINE.json's configs[1] size
-def test_iteration_matches_oracle(cuda, H, W):
+def test_iteration_matches_oracle(cuda):
+    """each side breaks its own ties (no replay of selections): possible at 256x512, where no two RPN scores of this seed sit
+    within fp32 round-off of each other; at 512x1024 (30720 anchors) some do, one swapped pair changes the sampled RoIs
+    (scripts/debug_fullsize_parity.py: 130 of 2000 proposals differ) -- the BASELINE-size comparison is
+    test_gradients_with_replayed_selections, which pins the discrete decisions and checks everything else more tightly"""
     from scda_amd import layers as L
     from scda_amd.train_step import ScdaTrainer
-    lr = 1e-3
+    H, W, lr = 256, 512, 1e-3
     ref, ref_models, masks = mc.oracle_iteration(H, W, lr=lr, record_masks=True, capture=True)
 
     torch.manual_seed(1)
@@ -183,7 +186,9 @@ def test_gradients_with_replayed_selections(cuda, H, W):
     src, tgt, gts, info = mc.seeded_inputs(H, W)
     tape = list(masks)
     L.Dropout.mask_source = lambda shape, p, device: tape.pop(0).to(device)
+    from scda_amd.dropin.functions import rpn_proposal
     A.replay = mc.ReplaySource(ref['_selections'], cuda)
+    rpn_proposal.rpn_output_hook = A.replay.rpn     # identical proposal ranking (see rpn_proposal.rpn_output_hook)
     try:
         np.random.seed(mc.SEEDS['numpy'])
         out = tr.step(src.to(cuda), gts, info, tgt.to(cuda))
@@ -192,6 +197,7 @@ def test_gradients_with_replayed_selections(cuda, H, W):
     finally:
         L.Dropout.mask_source = None
         A.replay = None
+        rpn_proposal.rpn_output_hook = None
     assert not tape and used >= 40, used
     for k in LOSS_KEYS:
         a, b = float(out[k]), float(ref[k])
