@@ -224,6 +224,11 @@ int scda_batchnorm_fwd_hip(const float *x, float *y, const float *gamma, const f
 int scda_batchnorm_bwd_hip(const float *dy, const float *x, const float *gamma, const float *beta,
                            const float *save_mean, const float *save_rstd, float *dx /*may be NULL*/, float *dgamma,
                            float *dbeta, int B, int C, int HW, int act, float slope, int accumulate, void *stream);
+/* nn.BatchNorm2d in eval mode (running statistics): out = act((x - mean) * rsqrt(var + eps) * gamma + beta); with dy given,
+ * out = the gradient w.r.t. x instead (dy * act'(y) * gamma * rsqrt(var + eps); statistics and affine parameters are constants) */
+int scda_batchnorm_eval_hip(const float *x, const float *dy_or_null, float *out, const float *gamma, const float *beta,
+                            const float *running_mean, const float *running_var, int B, int C, int HW, float eps, int act,
+                            float slope, void *stream);
 /* Interpolate(scale_factor=2, 'bilinear', align_corners=True) : common_net.py:160-170 */
 int scda_upsample2x_fwd_hip(const float *x, float *y, int planes, int IH, int IW, void *stream);
 int scda_upsample2x_bwd_hip(const float *dy, float *dx, int planes, int IH, int IW, void *stream);

@@ -432,6 +432,11 @@ class RefTrainer:
         self.new_w, self.new_h, self.ws = new_w, new_h, world_size
         self.trace = {}
         self.capture = False
+        self.warmup = None   # (gamma, base_lr, iterations done): tools/faster_rcnn_train_val.py:346-364,510-514
+
+    def begin_warmup(self, warmup_iters, batch_size=1, world_size=None):
+        ws = self.ws if world_size is None else world_size
+        self.warmup = [float(ws * batch_size) ** (1.0 / (warmup_iters - 1)), self.opt.param_groups[0]['lr'], 0]
 
     def _grab(self, name, module):
         """gradients of the phase that is about to step (name -> {param name: grad clone})"""
@@ -440,6 +445,15 @@ class RefTrainer:
 
     def step(self, image, gts, image_info, target):
         bce, ws = F.binary_cross_entropy, self.ws
+        if self.warmup is not None:
+            # utils/lr_helper.py:6-31: the constructor runs step(0) and then resets last_iter to -1, so the FIRST in-loop
+            # lr_scheduler.step() (:510-514, before the forward) is step(0) again: iteration k (1-based) runs at
+            # base * gamma**(k-1), the last warm-up iteration at base * world_size * batch_size
+            gamma, base, done = self.warmup
+            self.warmup[2] = done + 1
+            for o in (self.opt, self.opt_dec, self.opt_dis, self.opt_patch):
+                for g in o.param_groups:
+                    g['lr'] = base * gamma ** done
         x = {'cfg': self.cfg, 'image': image, 'image_info': image_info, 'ground_truth_bboxes': gts,
              'ignore_regions': None, 'cluster_num': self.cluster_num, 'threshold': self.threshold}
         outputs = self.model(x, target)

@@ -286,6 +286,23 @@ class BatchNormTrainFn(Function):
         return dx, dg, db, None, None, None, None, None, None
 
 
+class BatchNormEvalFn(Function):
+    """eval-mode nn.BatchNorm2d (+ fused activation): running statistics and affine parameters are constants"""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, run_mean, run_var, eps, act, slope):
+        x = _c(x)
+        ctx.save_for_backward(x, gamma, beta, run_mean, run_var)
+        ctx.cfg = (eps, act, slope)
+        return N.batchnorm_eval(x, gamma, beta, run_mean, run_var, eps, act, slope)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, run_mean, run_var = ctx.saved_tensors
+        eps, act, slope = ctx.cfg
+        return N.batchnorm_eval(x, gamma, beta, run_mean, run_var, eps, act, slope, dy=_c(dy)), None, None, None, None, None, None, None
+
+
 class Upsample2xFn(Function):
     @staticmethod
     def forward(ctx, x):

@@ -23,7 +23,10 @@ def remove_prefix(state_dict, prefix='module.'):
     return {(k[len(prefix):] if k.startswith(prefix) else k): v for k, v in state_dict.items()}
 
 
-def _load_matching(model, state, what):
+def _load_matching(model, state, what, allow_mismatch=False):
+    """copy every entry of `state` whose key exists in the model.  A key present on both sides with a DIFFERENT shape is an
+    error, as in the reference (`load_state_dict(strict=False)` raises on size mismatches, utils/load_helper.py:22), unless
+    allow_mismatch=True (e.g. deliberately re-using a backbone under a head with another num_classes)."""
     own = model.state_dict()
     used, skipped = [], []
     with torch.no_grad():
@@ -33,6 +36,11 @@ def _load_matching(model, state, what):
                 used.append(k)
             elif k in own:
                 skipped.append(k)
+    if skipped and not allow_mismatch:
+        raise ValueError('%s: shape mismatch for %s (pass allow_mismatch=True to skip them)' % (
+            what, ', '.join('%s %s vs %s' % (k, tuple(state[k].shape), tuple(own[k].shape)) for k in skipped[:8])))
+    if skipped:
+        logger.warning('%s: skipped %d keys with mismatching shapes: %s', what, len(skipped), skipped)
     missing = [k for k in own if k not in state]
     logger.info('%s: used keys:%d missing keys:%d unused checkpoint keys:%d shape mismatches:%d',
                 what, len(used), len(missing), len(state) - len(used) - len(skipped), len(skipped))
@@ -46,28 +54,35 @@ def _read(path_or_state):
     return torch.load(path_or_state, map_location='cpu', weights_only=False)
 
 
-def load_pretrain(model, path_or_state):
+def load_pretrain(model, path_or_state, allow_mismatch=False):
     """-> model (same object); see the module docstring"""
     d = _read(path_or_state)
     if isinstance(d.get('state_dict'), dict):
         d = d['state_dict']
-    _load_matching(model, remove_prefix(d), 'load_pretrain')
+    _load_matching(model, remove_prefix(d), 'load_pretrain', allow_mismatch)
     return model
 
 
 def _adam_state(opt):
+    g = opt.param_groups[0]
     return {'step': opt.step_count, 'exp_avg': opt.exp_avg.detach().cpu().clone(),
-            'exp_avg_sq': opt.exp_avg_sq.detach().cpu().clone(), 'lr': opt.param_groups[0]['lr'], 'betas': tuple(opt.betas),
-            'eps': opt.eps, 'weight_decay': opt.weight_decay}
+            'exp_avg_sq': opt.exp_avg_sq.detach().cpu().clone(), 'lr': g['lr'], 'initial_lr': g.get('initial_lr', g['lr']),
+            'betas': tuple(g['betas']), 'eps': g['eps'], 'weight_decay': g['weight_decay']}
 
 
 def _load_adam(opt, st):
     if st['exp_avg'].numel() != opt.exp_avg.numel():
         raise ValueError('optimizer state has %d elements, the bucket %d' % (st['exp_avg'].numel(), opt.exp_avg.numel()))
+    g = opt.param_groups[0]
+    for k in ('betas', 'eps', 'weight_decay'):       # a checkpoint made with other hyper-parameters must not load silently
+        if k in st and tuple(map(float, st[k] if k == 'betas' else (st[k],))) != tuple(map(float, g[k] if k == 'betas' else (g[k],))):
+            raise ValueError('optimizer %s differs: checkpoint %r, live optimiser %r' % (k, st[k], g[k]))
     opt.step_count = int(st['step'])
     opt.exp_avg.copy_(st['exp_avg'].to(opt.exp_avg.device))
     opt.exp_avg_sq.copy_(st['exp_avg_sq'].to(opt.exp_avg_sq.device))
-    opt.param_groups[0]['lr'] = st['lr']
+    g['lr'] = st['lr']
+    if 'initial_lr' in st:
+        g['initial_lr'] = st['initial_lr']
 
 
 def _cpu_state(m):

@@ -521,6 +521,32 @@ __global__ __launch_bounds__(256) void batchnorm_bwd_kernel(const float *__restr
     }
 }
 
+// nn.BatchNorm2d in EVAL mode (running statistics; validation of the vgg16_bn detector, dis_patch.eval()): a per-channel
+// affine map, HBM-bound (8 B / element).  One float4 per thread where the plane size allows.  The backward (w.r.t. x only:
+// statistics and affine parameters are constants in eval mode) is dx = dy * act'(y) * gamma * rstd.
+__global__ __launch_bounds__(256) void batchnorm_eval_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                             const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                             const float *__restrict__ mean, const float *__restrict__ var,
+                                                             const long long total, const int C, const int HW,
+                                                             const float eps, const int act, const float slope,
+                                                             const float *__restrict__ dy_bwd) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)blockDim.x * gridDim.x) {
+        const int c = (int)((i / HW) % C);
+        const float rstd = 1.f / sqrtf(var[c] + eps);
+        float o = (x[i] - mean[c]) * rstd * gamma[c] + beta[c];
+        if (dy_bwd) {   // backward: y is recomputed from x to get the activation mask
+            float g = dy_bwd[i];
+            if (act == 2) g = o > 0.f ? g : g * slope;
+            else if (act == 1) g = o > 0.f ? g : 0.f;
+            y[i] = g * gamma[c] * rstd;
+        } else {
+            if (act == 2) o = o > 0.f ? o : o * slope;
+            else if (act == 1) o = o > 0.f ? o : 0.f;
+            y[i] = o;
+        }
+    }
+}
+
 // ------------------------------------------- bilinear x2, align_corners -----
 // Interpolate(scale_factor=2, mode='bilinear', align_corners=True): common_net.py:160-170
 // grid: x = plane * OH + output row, y = column blocks (no per-element integer division)
@@ -859,6 +885,16 @@ SCDA_API int scda_batchnorm_bwd_hip(const float *dy, const float *x, const float
     hipLaunchKernelGGL(batchnorm_bwd_kernel, dim3(C), dim3(256), 0, as_stream(stream), dy, x, gamma, beta, save_mean, save_rstd, dx,
                        dgamma, dbeta, B, C, HW, act, slope, accumulate);
     return launch_status("batchnorm_bwd_kernel");
+}
+
+SCDA_API int scda_batchnorm_eval_hip(const float *x, const float *dy_or_null, float *out, const float *gamma, const float *beta,
+                                     const float *running_mean, const float *running_var, int B, int C, int HW, float eps,
+                                     int act, float slope, void *stream) {
+    NN_CHECK(x && out && gamma && beta && running_mean && running_var && B > 0 && C > 0 && HW > 0, "scda_batchnorm_eval_hip")
+    const long long total = (long long)B * C * HW;
+    hipLaunchKernelGGL(batchnorm_eval_kernel, dim3(ew_grid(total) * 4), dim3(256), 0, as_stream(stream), x, out, gamma, beta,
+                       running_mean, running_var, total, C, HW, eps, act, slope, dy_or_null);
+    return launch_status("batchnorm_eval_kernel");
 }
 
 static float up_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }

@@ -24,21 +24,24 @@ def _flat_of(model):
 
 
 def average_gradients(model, async_op=False):
-    """SUM-all-reduce every parameter gradient of `model` across ranks."""
+    """SUM-all-reduce every parameter gradient of `model` across ranks (utils/distributed_utils.py:9-19): ONE collective on
+    the model's flat gradient bucket, in place.
+
+    A module that is not flattened yet -- the reference's own driver builds plain modules and torch.optim.Adam
+    (tools/faster_rcnn_train_val.py:305-316) -- is flattened HERE, on its first call: parameters and the gradients just
+    computed move into one bucket each (FlatParams(keep_grads=True); the Parameter objects, and therefore the optimiser's
+    state, stay the same), and from then on this is the zero-copy path: no temporary, no pack / unpack kernels, and
+    async_op=True really overlaps.  Gradients that the optimiser's zero_grad() set to None and autograd re-created outside the
+    bucket are copied back into it first (FlatParams.check_aliases: one copy per tensor, no allocation)."""
     flat = _flat_of(model)
-    if flat is not None:
-        return dist.all_reduce(flat.grad, async_op=async_op)
-    # un-flattened module: bucket on the fly (coalesced, still a single collective)
-    grads = [p.grad.data for p in model.parameters() if p.requires_grad and p.grad is not None]
-    if not grads:
-        return None
-    bucket = torch.cat([g.reshape(-1) for g in grads])
-    work = dist.all_reduce(bucket, async_op=False)
-    off = 0
-    for g in grads:
-        g.copy_(bucket[off:off + g.numel()].view_as(g))
-        off += g.numel()
-    return work
+    if flat is None:
+        from scda_amd.flat import FlatParams
+        if not any(p.requires_grad and p.grad is not None for p in model.parameters()):
+            return None
+        flat = FlatParams(model, keep_grads=True)
+    else:
+        flat.check_aliases()
+    return dist.all_reduce(flat.grad, async_op=async_op)
 
 
 def broadcast_params(model):
@@ -53,6 +56,18 @@ def broadcast_params(model):
         dist.broadcast(p, 0)
 
 
+def _first_slurm_host(nodelist):
+    """'node[12-15,20],other3' -> 'node12' ; 'gpu-a,gpu-b' -> 'gpu-a'"""
+    import re
+    m = re.match(r'^([^,\[]+)(?:\[([^\]]+)\])?', nodelist.strip())
+    if not m:
+        return None
+    if m.group(2) is None:
+        return m.group(1)
+    first = re.split(r'[,-]', m.group(2))[0]
+    return m.group(1) + first
+
+
 def dist_init(port, backend='nccl'):
     if 'SLURM_PROCID' in os.environ:
         rank = int(os.environ['SLURM_PROCID'])
@@ -62,8 +77,22 @@ def dist_init(port, backend='nccl'):
         rank = int(os.environ.get('RANK', 0))
         world = int(os.environ.get('WORLD_SIZE', 1))
         local = int(os.environ.get('LOCAL_RANK', rank % max(torch.cuda.device_count(), 1)))
-    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    if 'MASTER_ADDR' not in os.environ:
+        # single node: loop-back.  Several SLURM nodes: the first host of the job's node list, as the reference derives it
+        # (utils/distributed_utils.py:27-35); never let every node rendezvous with itself.
+        nnodes = int(os.environ.get('SLURM_NNODES', os.environ.get('SLURM_JOB_NUM_NODES', 1)))
+        if 'SLURM_PROCID' in os.environ and nnodes > 1:
+            addr = os.environ.get('SLURM_LAUNCH_NODE_IPADDR') or _first_slurm_host(os.environ.get('SLURM_NODELIST', ''))
+            if not addr:
+                raise RuntimeError('dist_init: %d SLURM nodes but neither MASTER_ADDR, SLURM_LAUNCH_NODE_IPADDR nor a usable '
+                                   'SLURM_NODELIST is set' % nnodes)
+            os.environ['MASTER_ADDR'] = addr
+        else:
+            os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ.setdefault('MASTER_PORT', str(port))
+    import torch.multiprocessing as mp
+    if mp.get_start_method(allow_none=True) is None:   # as the reference (:22-23): DataLoader workers must not fork a process
+        mp.set_start_method('spawn')                    # that has already initialised HIP
     os.environ['WORLD_SIZE'] = str(world)
     os.environ['RANK'] = str(rank)
     if backend == 'nccl':

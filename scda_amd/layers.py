@@ -139,8 +139,11 @@ class BatchNorm2d(nn.BatchNorm2d):
         self.slope = slope
 
     def forward(self, x):
-        if not self.training:
-            raise NotImplementedError("scda_amd.BatchNorm2d: eval mode is not on the SCDA training path")
+        if not self.training:   # validation of vgg16_bn, dis_patch.eval(): running statistics, nothing is updated
+            if self.running_mean is None:
+                raise NotImplementedError("scda_amd.BatchNorm2d: eval mode without running statistics")
+            return A.BatchNormEvalFn.apply(x, self.weight.detach(), self.bias.detach(), self.running_mean, self.running_var,
+                                           self.eps, self.fused_act, self.slope)
         if self.num_batches_tracked is not None:
             self.num_batches_tracked.add_(1)
         if A.replay is not None and self.fused_act != A.ACT_NONE:   # parity tests: see InstanceNorm2d

@@ -596,6 +596,18 @@ def batchnorm_bwd(dy, x, gamma, beta, mean, rstd, act, slope, need_dx=True, out=
     return dx, dg, db
 
 
+def batchnorm_eval(x, gamma, beta, run_mean, run_var, eps, act, slope, dy=None):
+    """eval-mode batch norm (+act); with dy: the gradient w.r.t. x"""
+    _req(x, "x"); _req(gamma, "gamma"); _req(beta, "beta"); _req(run_mean, "running_mean"); _req(run_var, "running_var")
+    if dy is not None:
+        _req(dy, "dy")
+    B, C, H, W = x.shape
+    out = torch.empty_like(x)
+    _check(lib().scda_batchnorm_eval_hip(_p(x), _p(dy), _p(out), _p(gamma), _p(beta), _p(run_mean), _p(run_var), i32(B), i32(C),
+                                         i32(H * W), f32(eps), i32(act), f32(slope), _stream()), "scda_batchnorm_eval_hip")
+    return out
+
+
 def upsample2x_fwd(x):
     _req(x, "x")
     B, C, H, W = x.shape

@@ -120,8 +120,11 @@ class ScdaTrainer:
         self.flat = {k: FlatParams(m) for k, m in (("det", self.model), ("dec", self.dec), ("dis", self.dis),
                                                    ("dis_patch", self.dis_patch))}
         self.opt = {k: FlatAdam(f, lr, betas=(0.9, 0.999), weight_decay=weight_decay) for k, f in self.flat.items()}
+        self._warmup = None          # per-iteration schedulers while warming up (begin_warmup / end_warmup)
+        self._epoch_sched = None     # per-epoch MultiStepLR (set_epoch_schedule / begin_epoch)
         self.capture = False   # debugging / parity tests: keep a copy of each phase's gradients in self.trace
-        self.trace = {}
+        self.trace = {}        # ... as computed by this rank, and in self.trace_reduced after the all-reduce (world_size > 1)
+        self.trace_reduced = {}
         # scheduling: detector backward enqueued as soon as its losses exist; target branch on a high-priority side stream
         self.early_backward = True
         self.side = torch.cuda.Stream(device=device, priority=-1) if device.type == "cuda" else None
@@ -135,6 +138,39 @@ class ScdaTrainer:
         else:
             self.branch = None
 
+    # ---- learning-rate schedule (tools/faster_rcnn_train_val.py:346-388) ------------------------------------------
+    def begin_warmup(self, warmup_iters, batch_size=1, world_size=None):
+        """exponential per-iteration warm-up of all four optimisers towards lr * world_size * batch_size (:346-364)"""
+        from .lr_schedule import IterExponentialLR, warmup_gamma
+        gamma = warmup_gamma(self.world_size if world_size is None else world_size, batch_size, warmup_iters)
+        self._warmup = [IterExponentialLR(o, gamma) for o in self.opt.values()]
+        return gamma
+
+    def end_warmup(self):
+        """:365-367: the magnified rate becomes the schedule's base rate"""
+        self._warmup = None
+        for o in self.opt.values():
+            for g in o.param_groups:
+                g['initial_lr'] = g['lr']
+
+    def set_epoch_schedule(self, milestones, gamma=0.1, start_epoch=0):
+        """torch MultiStepLR on each optimiser, as :370-376; advance it with begin_epoch() at the top of every epoch (:380-383)"""
+        from torch.optim.lr_scheduler import MultiStepLR
+        self._epoch_sched = [MultiStepLR(o, milestones=list(milestones), gamma=gamma, last_epoch=start_epoch - 1)
+                             for o in self.opt.values()]
+
+    def begin_epoch(self):
+        import warnings
+        with warnings.catch_warnings():   # the reference steps the schedule BEFORE the epoch's optimiser steps, on purpose
+            warnings.simplefilter("ignore", UserWarning)
+            for s in self._epoch_sched or ():
+                s.step()
+        return self.lr
+
+    @property
+    def lr(self):
+        return self.opt['det'].param_groups[0]['lr']
+
     # ------------------------------------------------------------------
     def _join_branch(self):
         """The B halves' backward kernels accumulate straight into the flat gradient bucket on the branch stream; autograd
@@ -142,6 +178,10 @@ class ScdaTrainer:
         them: order the compute stream behind the branch stream before anything reads the bucket."""
         if self.branch is not None:
             torch.cuda.current_stream(self.device).wait_stream(self.branch)
+
+    def _grab_reduced(self, name, module):
+        if self.capture:
+            self.trace_reduced[name] = {k: p.grad.detach().clone() for k, p in module.named_parameters()}
 
     def _reduce(self, module, async_op):
         self._join_branch()
@@ -158,6 +198,8 @@ class ScdaTrainer:
         x = {'cfg': self.cfg, 'image': image, 'image_info': image_info, 'ground_truth_bboxes': gts,
              'ignore_regions': None, 'cluster_num': self.cluster_num, 'threshold': self.threshold}
         pending = {}
+        for sch in self._warmup or ():     # :510-514 -- the warm-up schedulers step at the top of the iteration
+            sch.step()
 
         def detector_backward(losses):
             # Phase (4)'s gradient depends only on the four detector losses (the adversarial term of the reference's
@@ -214,9 +256,11 @@ class ScdaTrainer:
         w2 = self._reduce(self.dis_patch, async_op=True)
         if w1 is not None:
             w1.wait()
+            self._grab_reduced('dis', self.dis)
         self.opt['dis'].step()
         if w2 is not None:
             w2.wait()
+            self._grab_reduced('dis_patch', self.dis_patch)
         self.opt['dis_patch'].step()
         mark('phase2')
 
@@ -257,6 +301,7 @@ class ScdaTrainer:
         det_loss, w4 = pending['det_loss'], pending['w4']
         if w3 is not None:
             w3.wait()
+            self._grab_reduced('dec', self.dec)
         self.opt['dec'].step()
         with torch.no_grad():
             swap_src, swap_tgt = self.dec(tgt_patch, src_patch)
@@ -272,6 +317,7 @@ class ScdaTrainer:
         loss = det_loss + 0.1 * (fake_loss_source + fake_loss_target) / ws
         if w4 is not None:
             w4.wait()
+            self._grab_reduced('det', self.model)
         self.opt['det'].step()
         mark('phase4+det_step')
 

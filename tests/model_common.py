@@ -23,9 +23,10 @@ def seeded_models(build):
     return det, dec, dis, dis_patch
 
 
-def seeded_inputs(H, W, G=6):
-    src, tgt = si.synth_images(SEEDS['images'], H, W)
-    gts = si.synth_gts(G, SEEDS['gts'], H, W)
+def seeded_inputs(H, W, G=6, sample=0):
+    """sample > 0: another (source, target, boxes) triple -- what another data-parallel rank would see"""
+    src, tgt = si.synth_images(SEEDS['images'] + 100 * sample, H, W)
+    gts = si.synth_gts(G, SEEDS['gts'] + 100 * sample, H, W)
     info = torch.tensor([[H, W, 1.0]])
     return src, tgt, gts, info
 
@@ -70,7 +71,8 @@ class ReplaySource:
         return self._find("roi", out).reshape(arg.shape).contiguous()
 
 
-def oracle_iteration(H, W, lr=1e-3, record_masks=False, capture=False, cfg=None, steps=1, record_selections=False):
+def oracle_iteration(H, W, lr=1e-3, record_masks=False, capture=False, cfg=None, steps=1, record_selections=False,
+                     warmup=None, sample=0, world_size=1):
     """one RefTrainer step on CPU with the golden seeds; returns (result dict, models, masks)"""
     from oracle import torch_ref as R
     cfg = cfg or CFG
@@ -78,9 +80,11 @@ def oracle_iteration(H, W, lr=1e-3, record_masks=False, capture=False, cfg=None,
     try:
         torch.manual_seed(1)
         models = seeded_models(lambda: R.build_models(cfg))
-        tr = R.RefTrainer(cfg, models, lr=lr, new_w=W, new_h=H)
+        tr = R.RefTrainer(cfg, models, lr=lr, new_w=W, new_h=H, world_size=world_size)
         tr.capture = capture
-        src, tgt, gts, info = seeded_inputs(H, W)
+        if warmup:                      # (warm-up iterations, world_size x batch it warms up to)
+            tr.begin_warmup(warmup[0], world_size=warmup[1])
+        src, tgt, gts, info = seeded_inputs(H, W, sample=sample)
         R.RecordingDropout.tape = [] if record_masks else None
         rec = R.SelectionRecorder() if record_selections else None
         handles = rec.attach(*models) if rec else None
@@ -94,9 +98,11 @@ def oracle_iteration(H, W, lr=1e-3, record_masks=False, capture=False, cfg=None,
         torch.manual_seed(SEEDS['torch'])
         np.random.seed(SEEDS['numpy'])
         res = tr.step(src, gts, info, tgt)
+        res['_lr'] = tr.opt.param_groups[0]['lr']
         history = [res]
         for _ in range(steps - 1):          # same inputs again; RNG streams simply continue
             history.append(tr.step(src, gts, info, tgt))
+            history[-1]['_lr'] = tr.opt.param_groups[0]['lr']
         if steps > 1:
             res = dict(history[-1], _history=history)
         masks = R.RecordingDropout.tape

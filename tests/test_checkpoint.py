@@ -88,6 +88,16 @@ def test_save_restore_round_trip(tmp_path):
     assert torch.equal(c.model.state_dict()['fc_rcnn_cls.weight'], a.model.state_dict()['fc_rcnn_cls.weight'])
     assert all(torch.equal(v, c.dec.state_dict()[k]) for k, v in dec_before.items())
     assert c.opt['det'].step_count == 0
+    # a head with another class count must not load silently (the reference's load_state_dict raises on size mismatches)
+    bad = {k: v for k, v in a.model.state_dict().items()}
+    bad['fc_rcnn_cls.weight'] = torch.zeros(21, 4096)
+    with pytest.raises(ValueError, match='fc_rcnn_cls.weight'):
+        C.load_pretrain(c.model, bad)
+    C.load_pretrain(c.model, bad, allow_mismatch=True)
+    # ... nor optimiser moments recorded under other hyper-parameters
+    ck['optimizer']['weight_decay'] = 0.5
+    with pytest.raises(ValueError, match='weight_decay'):
+        C.restore(make(5), ck)
 
 
 @pytest.mark.gpu

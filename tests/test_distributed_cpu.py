@@ -57,8 +57,23 @@ def _worker(rank, world, port, results):
     m2 = Tiny()
     for p in m2.parameters():
         p.grad = torch.full_like(p, float(rank + 1))
+    opt2 = torch.optim.Adam(m2.parameters(), 1e-2)     # built BEFORE the lazy flattening, as the reference's driver does
+    before = [p.detach().clone() for p in m2.parameters()]
     average_gradients(m2)
     ok_plain = all(bool((p.grad == 3).all()) for p in m2.parameters())
+    # ... which happened in place: same Parameter objects, now views of one bucket; the second round is the zero-copy async path,
+    # also after the optimiser's zero_grad() (set_to_none) made autograd re-create the gradients outside the bucket
+    flat2 = m2._scda_flat
+    ok_plain &= all(flat2._inside(p.data, flat2.data) and flat2._inside(p.grad, flat2.grad) for p in m2.parameters())
+    opt2.step()
+    ok_plain &= all(not torch.equal(p, b) for p, b in zip(m2.parameters(), before))   # torch's Adam still owns these tensors
+    opt2.zero_grad()
+    ok_plain &= all(p.grad is None for p in m2.parameters())
+    for p in m2.parameters():
+        p.grad = torch.full_like(p, float(5 * (rank + 1)))
+    work = average_gradients(m2, async_op=True)
+    work.wait()
+    ok_plain &= all(bool((p.grad == 15).all()) and flat2._inside(p.grad, flat2.grad) for p in m2.parameters())
     results[rank] = (ok_bcast, ok_bn, ok_sum, ok_async, ok_plain)
     dist.destroy_process_group()
 
@@ -98,3 +113,24 @@ def test_flat_params_views_and_adam_bucket_alignment():
     assert all(bool((p.grad == 2).all()) for p in m.parameters())
     flat.zero_grad()
     assert float(flat.grad.abs().sum()) == 0
+
+
+def test_slurm_master_address_is_not_loopback_on_several_nodes(monkeypatch):
+    from scda_amd.dropin.utils import distributed_utils as D
+    assert D._first_slurm_host("node[12-15,20],other3") == "node12"
+    assert D._first_slurm_host("gpu-a,gpu-b") == "gpu-a"
+    assert D._first_slurm_host("SH-IDC1-10-5-30-[36-37]") == "SH-IDC1-10-5-30-36"
+    seen = {}
+    monkeypatch.setattr(D.dist, "init_process_group", lambda **kw: seen.update(kw))
+    monkeypatch.setattr(D.dist, "get_rank", lambda: 3)
+    monkeypatch.setattr(D.dist, "get_world_size", lambda: 16)
+    for k, v in dict(SLURM_PROCID="3", SLURM_NTASKS="16", SLURM_NNODES="2", SLURM_NODELIST="cn[07-08]").items():
+        monkeypatch.setenv(k, v)
+    for k in ("MASTER_ADDR", "MASTER_PORT", "SLURM_LAUNCH_NODE_IPADDR"):
+        monkeypatch.delenv(k, raising=False)
+    assert D.dist_init("23456", backend="gloo") == (3, 16)
+    assert os.environ["MASTER_ADDR"] == "cn07" and os.environ["MASTER_PORT"] == "23456" and seen["world_size"] == 16
+    monkeypatch.delenv("MASTER_ADDR")
+    monkeypatch.setenv("SLURM_NODELIST", "")
+    with pytest.raises(RuntimeError):
+        D.dist_init("23456", backend="gloo")

@@ -136,6 +136,72 @@ def test_batch_norm_train(cuda, act):
     close(rm_g, rm_r, 1e-5); close(rv_g, rv_r, 1e-5)
 
 
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_batch_norm_eval_mode(cuda, act):
+    """scda_amd.layers.BatchNorm2d in eval mode (vgg16_bn validation, dis_patch.eval()): running statistics, no update; the
+    gradient w.r.t. the input treats statistics and affine parameters as constants"""
+    from scda_amd import layers as L
+    B, C, H, W = 3, 12, 9, 11
+    x = torch.randn(B, C, H, W, generator=gen(41)) * 1.5 + 0.3
+    ref = torch.nn.BatchNorm2d(C)
+    with torch.no_grad():
+        ref.weight.copy_(1 + 0.1 * torch.randn(C, generator=gen(42))); ref.bias.copy_(0.1 * torch.randn(C, generator=gen(43)))
+        ref.running_mean.copy_(0.2 * torch.randn(C, generator=gen(44))); ref.running_var.copy_(0.5 + torch.rand(C, generator=gen(45)))
+    mod = L.BatchNorm2d(C, fused_act=act, slope=0.01)
+    mod.load_state_dict(ref.state_dict())
+    ref.eval(); mod.to(cuda).eval()
+    xr = x.clone().requires_grad_()
+    y = [lambda t: t, F.relu, lambda t: F.leaky_relu(t, 0.01)][act](ref(xr))
+    dy = torch.randn(y.shape, generator=gen(46)); y.backward(dy)
+    xg = x.to(cuda).requires_grad_()
+    yg = mod(xg); yg.backward(dy.to(cuda))
+    close(yg, y, 1e-6); close(xg.grad, xr.grad, 1e-6)
+    sd = mod.state_dict()
+    assert torch.equal(sd['running_mean'].cpu(), ref.running_mean) and int(sd['num_batches_tracked']) == 0
+
+
+@pytest.mark.parametrize("lr_schedule", [False, True])
+def test_flat_adam_matches_torch_adam_under_schedulers(cuda, lr_schedule):
+    """FlatAdam (one fused kernel on the bucket) == torch.optim.Adam on the individual parameters, step for step, also while
+    torch's MultiStepLR and the warm-up scheduler move the learning rate (the lr reaches the kernel through param_groups)"""
+    from torch.optim.lr_scheduler import MultiStepLR
+    from scda_amd.flat import FlatAdam, FlatParams
+    from scda_amd.lr_schedule import IterExponentialLR
+    torch.manual_seed(3)
+    ref = torch.nn.Sequential(torch.nn.Conv2d(3, 5, 3), torch.nn.Linear(7, 3))
+    mine = torch.nn.Sequential(torch.nn.Conv2d(3, 5, 3), torch.nn.Linear(7, 3))
+    mine.load_state_dict(ref.state_dict())
+    mine.to(cuda)
+    flat = FlatParams(mine)
+    o_ref = torch.optim.Adam(ref.parameters(), 1e-2, betas=(0.9, 0.999), weight_decay=1e-4)
+    o_mine = FlatAdam(flat, 1e-2, betas=(0.9, 0.999), weight_decay=1e-4)
+    scheds = []
+    if lr_schedule:
+        scheds = [IterExponentialLR(o_ref, 2.0), IterExponentialLR(o_mine, 2.0)]
+    for it in range(6):
+        if it == 3 and lr_schedule:
+            for o in (o_ref, o_mine):
+                for g in o.param_groups:
+                    g['initial_lr'] = g['lr']
+            scheds = [MultiStepLR(o_ref, [1, 2], 0.1), MultiStepLR(o_mine, [1, 2], 0.1)]
+        for sch in scheds:
+            sch.step()
+        assert o_ref.param_groups[0]['lr'] == pytest.approx(o_mine.param_groups[0]['lr'], rel=1e-12)
+        g = torch.Generator().manual_seed(100 + it)
+        o_mine.zero_grad()
+        for pr, pm in zip(ref.parameters(), mine.parameters()):
+            gr = torch.randn(pr.shape, generator=g) * 0.1
+            pr.grad = gr.clone()
+            pm.grad.copy_(gr)
+        o_ref.step(); o_mine.step()
+    if lr_schedule:
+        assert o_mine.param_groups[0]['lr'] == pytest.approx(1e-2 * 4 * 0.01)
+    for pr, pm in zip(ref.parameters(), mine.parameters()):
+        close(pm, pr, 2e-6)
+    sd = o_mine.state_dict()
+    assert int(sd['state'][0]['step']) == 6 and sd['state'][0]['exp_avg'].numel() == flat.numel
+
+
 @pytest.mark.parametrize("shape", [(4, 3, 64, 64), (1, 2, 5, 7), (4, 8, 128, 128)])
 def test_upsample2x(cuda, shape):
     from scda_amd import autograd_ops as A

@@ -89,6 +89,45 @@ def test_two_iterations_track_oracle(cuda):
     assert float(outs[1]['rcnn_cls']) != float(outs[0]['rcnn_cls'])        # the weights did move
 
 
+def test_three_warmup_iterations_track_oracle(cuda):
+    """the reference's per-iteration exponential warm-up (tools/faster_rcnn_train_val.py:346-364, utils/lr_helper.py:33-49) on
+    the fused optimisers: three iterations warming up to 8x (the 8-GPU, batch-1 run): the learning rate that reaches the Adam
+    kernel follows the oracle's exactly (1, sqrt 8, 8) x base, the losses stay on the oracle's trajectory (tolerances as in
+    test_two_iterations_track_oracle), and end_warmup() turns the magnified rate into the MultiStepLR base (:365-376)"""
+    from scda_amd import layers as L
+    from scda_amd.train_step import ScdaTrainer
+    H, W, lr = 256, 512, 2e-5
+    ref, _, masks = mc.oracle_iteration(H, W, lr=lr, record_masks=True, steps=3, warmup=(3, 8))
+    torch.manual_seed(1)
+    tr = ScdaTrainer(mc.CFG, cuda, lr=lr, new_w=W, new_h=H, models=mc.seeded_models(build_product))
+    gamma = tr.begin_warmup(3, world_size=8)
+    assert abs(gamma - 8 ** 0.5) < 1e-12
+    src, tgt, gts, info = mc.seeded_inputs(H, W)
+    src, tgt = src.to(cuda), tgt.to(cuda)
+    tape = list(masks)
+    L.Dropout.mask_source = lambda shape, p, device: tape.pop(0).to(device)
+    outs, lrs = [], []
+    try:
+        np.random.seed(mc.SEEDS['numpy'])
+        for _ in range(3):
+            outs.append(tr.step(src, gts, info, tgt))
+            lrs.append([o.param_groups[0]['lr'] for o in tr.opt.values()])
+        torch.cuda.synchronize()
+    finally:
+        L.Dropout.mask_source = None
+    assert not tape
+    for i, want in enumerate(ref['_history']):
+        assert all(abs(v - want['_lr']) <= 1e-12 * want['_lr'] for v in lrs[i]), (i, lrs[i], want['_lr'])
+        assert abs(want['_lr'] - lr * 8 ** (i / 2)) <= 1e-12
+        for k in LOSS_KEYS:
+            a, b = float(outs[i][k]), float(want[k])
+            assert abs(a - b) <= (1e-4 if i == 0 else 2e-2) * max(1.0, abs(b)), (i, k, a, b)
+    tr.end_warmup()
+    tr.set_epoch_schedule([2, 3])
+    assert [round(tr.begin_epoch() / lr, 6) for _ in range(3)] == [8.0, 0.8, 0.08]
+    assert all(o.param_groups[0]['initial_lr'] == pytest.approx(8 * lr) for o in tr.opt.values())
+
+
 def test_iteration_matches_oracle(cuda):
     """each side breaks its own ties (no replay of selections): possible at 256x512, where no two RPN scores of this seed sit
     within fp32 round-off of each other; at 512x1024 (30720 anchors) some do, one swapped pair changes the sampled RoIs
