@@ -97,6 +97,11 @@ def _grad_worker(rank, world, port, out_dir):
     src, tgt, gts, info = mc.seeded_inputs(H, W, sample=rank)
     tape = torch.load(os.path.join(out_dir, "masks%d.pt" % rank))
     L.Dropout.mask_source = lambda shape, p, device: tape.pop(0).to(device)
+    # identical proposal ranking on both sides (scda_amd/dropin/functions/rpn_proposal.py: rpn_output_hook)
+    import types
+    from scda_amd.dropin.functions import rpn_proposal
+    rec = types.SimpleNamespace(records=torch.load(os.path.join(out_dir, "rpn%d.pt" % rank)))
+    rpn_proposal.rpn_output_hook = mc.ReplaySource(rec, torch.device("cpu")).rpn
     np.random.seed(mc.SEEDS['numpy'])
     out = tr.step(src.to(dev), gts, info, tgt.to(dev))
     torch.cuda.synchronize()
@@ -120,8 +125,10 @@ def test_reduced_gradient_equals_oracle_sum_of_samples(cuda, tmp_path):
     world, H, W = 2, 256, 512
     want = None
     for r in range(world):
-        ref, _, masks = mc.oracle_iteration(H, W, lr=1e-3, record_masks=True, capture=True, sample=r, world_size=world)
+        ref, _, masks = mc.oracle_iteration(H, W, lr=1e-3, record_masks=True, capture=True, sample=r, world_size=world,
+                                            record_selections=True)
         torch.save(list(masks), str(tmp_path / ("masks%d.pt" % r)))
+        torch.save([rec for rec in ref['_selections'].records if rec[0].startswith("rpn_")], str(tmp_path / ("rpn%d.pt" % r)))
         tr = {n: {k: v.clone() for k, v in g.items()} for n, g in ref['_trace'].items() if n in ('det', 'dis', 'dis_patch')}
         if want is None:
             want = tr
