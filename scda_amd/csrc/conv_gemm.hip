@@ -287,51 +287,14 @@ struct GldsOperand {
 // Wave layout: 2 x 2 waves, except the 64 x 256 tile (layers with <= 64 output channels: conv1_x, the decoder's last
 // stages), which is 1 x 4 so that every wave still owns a 64 x 64 sub-tile = 32 MFMAs per barrier; with 64 x 128 tiles a
 // wave had 32 x 64 = 16 MFMAs per barrier and those layers ran at 75 instead of ~100 TFLOP/s.
-// Branch-free form of conv_tap_offset for the pipelined kernels: everything is evaluated, the predicate is a bit-AND of
-// compares (no short-circuit), so the whole slab preparation stays ONE basic block that the scheduler can lay between MFMAs.
-template <int S, bool DGRAD>
-__device__ __forceinline__ bool conv_tap_offset_nb(const ConvGeom &g, const bool n_ok, const int py, const int px, const int kh,
-                                                   const int kw, int &off) {
-    if (!DGRAD) {
-        const int iy = py * S + kh - g.pad, ix = px * S + kw - g.pad;
-        off = iy * g.WB + ix;
-        return n_ok & ((unsigned)iy < (unsigned)g.HB) & ((unsigned)ix < (unsigned)g.WB);
-    } else {
-        const int ty = py + g.pad - kh, tx = px + g.pad - kw;
-        const int oy = S == 1 ? ty : (ty >> 1), ox = S == 1 ? tx : (tx >> 1);   // S in {1, 2}; negative ty fails the range test
-        off = oy * g.WB + ox;
-        return n_ok & ((unsigned)oy < (unsigned)g.HB) & ((unsigned)ox < (unsigned)g.WB) & (oy * S == ty) & (ox * S == tx);
-    }
-}
-
-// `ok ? a : b` on 64-bit byte offsets without giving the compiler a reason to branch around the (cheap) dead side
-__device__ __forceinline__ long long select64(const bool ok, const long long a, const long long b) {
-    const long long m = -(long long)ok;
-    return (a & m) | (b & ~m);
-}
-
-// nothing may be scheduled across this point (keeps the hand-placed MFMA / LDS-read / LDS-DMA interleave of the K loop)
-#define SCDA_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-
-// Software pipeline of the direct-to-LDS kernels (this one, the weight gradient and the dense GEMM share it):
-//   LDS = ring of NST = 3 stages; at the top of slab s the wave waits until ITS loads of slab s have landed
-//   (s_waitcnt vmcnt(L): the L loads of slab s+1 stay in flight), ONE s_barrier, then the MFMAs of slab s -- and INSIDE that
-//   MFMA stream, one piece after every few MFMAs, the address arithmetic and the L LDS-DMA instructions of slab s+2, plus the
-//   LDS fragment reads of the next K-pair right behind the first MFMA of the current pair.  An fp32 MFMA keeps the matrix
-//   pipe busy for 64 cycles, so all of that issues in the shadow of the MFMAs; in the previous schedule (issue slab s+2, wait,
-//   barrier, THEN 32 back-to-back MFMAs) the ~100 scalar/vector instructions of the issue phase ran with the matrix pipe
-//   idle: ~1400 of every ~5500 cycles per slab (MFMA-busy 73 % for the 8-wave tile, 47-66 % for the 4-wave tiles).
-//   WAR: stage (s+2)%3 was last read by the MFMAs of slab s-1; every wave issued those before arriving at barrier s.
-//   RAW: each wave counts its own LDS-DMA down, the barrier then orders every wave's data before any ds_read.
-//   The last two iterations re-load the final slab into a free stage instead of branching (uniform vmcnt bookkeeping, one
-//   basic block); all LDS-DMA is drained before the epilogue (a DMA must never land after the workgroup's LDS is released).
 template <int BM, int BN, int KH, int KW, int S, bool DGRAD>
 __global__ __launch_bounds__(BM == 256 ? 512 : 256) void conv_igemm_glds_kernel(const float *__restrict__ Wt,
                                                                                 const float *__restrict__ X,
                                                                                 const ConvGeom g, const Epi e) {
-    constexpr int NST = 3, STAGE = BK * (BM + BN);
-    // 256 x 128 tile: EIGHT waves (4 x 2): the gathered pixel operand is shared by twice as many output channels; used when
-    // Cout % 256 == 0 (72 KB of LDS: two workgroups fit a CU)
+    constexpr int NST = 4, STAGE = BK * (BM + BN);
+    // 256 x 128 tile: EIGHT waves (4 x 2), one workgroup per CU (96 KB of LDS): the gathered pixel operand is shared by twice
+    // as many output channels (+6.6 % on conv3_2 in scripts/ablate/conv_glds.hip); used when Cout % 256 == 0 and the grid
+    // comes out at a multiple of 256 workgroups (conv3_x, conv4_x, conv5_x all do)
     constexpr int NW = BM == 256 ? 8 : 4;
     constexpr int WGN = BN == 256 ? 4 : 2, WGM = NW / WGN;         // waves along N / M
     constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
@@ -341,7 +304,6 @@ __global__ __launch_bounds__(BM == 256 ? 512 : 256) void conv_igemm_glds_kernel(
     constexpr int HALVES = BN / 64;           // 64-pixel pieces per B row
     constexpr int B_PW = BK * HALVES / NW;    // B instructions (= rows) per wave per slab (64 x 256 tile: all 16 rows)
     constexpr int L = A_PW + B_PW;            // LDS-DMA instructions per wave per slab
-    constexpr int NP = BK / 2;                // K-pairs per slab (one 32x32x2 MFMA per pair and 32x32 sub-tile)
     __shared__ __attribute__((aligned(16))) float lds[NST * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -361,34 +323,27 @@ __global__ __launch_bounds__(BM == 256 ? 512 : 256) void conv_igemm_glds_kernel(
     g.dPHW.divmod(n_ok ? n_glob : 0, img, pix);
     g.dPW.divmod(pix, py, px);
     const int plane = g.HB * g.WB;
-    const char *xb = reinterpret_cast<const char *>(X + (size_t)img * g.CB * plane + (size_t)(kg * B_PW) * plane);
-    const long long zp_delta = reinterpret_cast<const char *>(g.zp) - xb;
+    const float *xb = X + (size_t)img * g.CB * plane + (size_t)(kg * B_PW) * plane;
     // A: this lane's 4 consecutive output channels of row (wave*A_PW + i)*A_RPI + lane/A_LPR
     const float *wsrc = Wt + (size_t)(wave * A_PW * A_RPI + lane / A_LPR) * g.mpad + m0 + (lane % A_LPR) * 4;
 
-    // sources of the slab that is being staged (set by prep, consumed piece by piece)
-    const float *wa;
-    const char *bsrc;
-    long long bstride;
-    float *stA, *stB;
-    auto prep = [&](const int s, const int buf) {
-        stA = lds + buf * STAGE;
-        stB = stA + BK * BM;
-        wa = wsrc + (size_t)s * BK * g.mpad;
+    auto issue = [&](int s, int buf) {
+        float *Ab = lds + buf * STAGE;
+        float *Bb = Ab + BK * BM;
+        const float *wa = wsrc + (size_t)s * BK * g.mpad;
+#pragma unroll
+        for (int i = 0; i < A_PW; ++i)
+            __builtin_amdgcn_global_load_lds((glb_void_t *)(wa + (size_t)i * A_RPI * g.mpad),
+                                             (lds_void_t *)(Ab + (wave * A_PW + i) * A_RPI * BM), 16, 0, 0);
         const int cb = s / (KH * KW), r = s - cb * (KH * KW);
         const int kh = r / KW, kw = r - kh * KW;
-        int off;
-        const bool ok = conv_tap_offset_nb<S, DGRAD>(g, n_ok, py, px, kh, kw, off);
-        bsrc = xb + select64(ok, ((long long)(cb * BK) * plane + off) * 4, zp_delta);
-        bstride = select64(ok, (long long)plane * 4, 0);
-    };
-    auto piece = [&](const int p) {
-        if (p < A_PW)
-            __builtin_amdgcn_global_load_lds((glb_void_t *)(wa + (size_t)p * A_RPI * g.mpad),
-                                             (lds_void_t *)(stA + (wave * A_PW + p) * A_RPI * BM), 16, 0, 0);
-        else
-            __builtin_amdgcn_global_load_lds((glb_void_t *)(bsrc + (p - A_PW) * bstride),
-                                             (lds_void_t *)(stB + (kg * B_PW + (p - A_PW)) * BN + half * 64), 4, 0, 0);
+        const int off = conv_tap_offset<S, DGRAD>(g, n_ok, py, px, kh, kw);
+        const float *src = off >= 0 ? xb + (size_t)(cb * BK) * plane + off : g.zp;
+        const size_t stride = off >= 0 ? (size_t)plane : 0;
+#pragma unroll
+        for (int j = 0; j < B_PW; ++j)
+            __builtin_amdgcn_global_load_lds((glb_void_t *)(src + j * stride),
+                                             (lds_void_t *)(Bb + (kg * B_PW + j) * BN + half * 64), 4, 0, 0);
     };
 
     f32x16 acc[TM][TN];
@@ -400,53 +355,43 @@ __global__ __launch_bounds__(BM == 256 ? 512 : 256) void conv_igemm_glds_kernel(
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const int lr = lane & 31, lk = lane >> 5;
 
-    if (s_begin < s_end) {
-        const int s_last = s_end - 1;
-        prep(s_begin, 0);
-#pragma unroll
-        for (int p = 0; p < L; ++p) piece(p);
-        prep(min(s_begin + 1, s_last), 1);
-#pragma unroll
-        for (int p = 0; p < L; ++p) piece(p);
-        int buf = 0, nbuf = 2;
-        for (int s = s_begin; s < s_end; ++s) {
+    if (s_begin < s_end) issue(s_begin, 0);
+    if (s_begin + 1 < s_end) issue(s_begin + 1, 1);
+    int buf = 0, nbuf = 2;
+    for (int s = s_begin; s < s_end; ++s) {
+        if (s + 2 < s_end) {
+            issue(s + 2, nbuf);
+            SCDA_WAIT_VMCNT(2 * L);
+        } else if (s + 1 < s_end) {
             SCDA_WAIT_VMCNT(L);
-            __builtin_amdgcn_s_barrier();
-            const float *ap = lds + buf * STAGE + lk * BM + wm * WM + lr;
-            const float *bp = lds + buf * STAGE + BK * BM + lk * BN + wn * WN + lr;
-            float a[2][TM], b[2][TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[0][i] = ap[i * 32];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b[0][j] = bp[j * 32];
-            SCDA_SCHED_FENCE();
-#pragma unroll
-            for (int kp = 0; kp < NP; ++kp) {
-                const int cur = kp & 1, nxt = cur ^ 1;
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][0], b[cur][0], acc[0][0], 0, 0, 0);
-                SCDA_SCHED_FENCE();
-                if (kp + 1 < NP) {   // fragments of the next K-pair: issued now, needed TM*TN MFMAs (>= 64 cycles each) later
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) a[nxt][i] = ap[(2 * kp + 2) * BM + i * 32];
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) b[nxt][j] = bp[(2 * kp + 2) * BN + j * 32];
-                }
-                if (kp == 0) prep(min(s + 2, s_last), nbuf);
-#pragma unroll
-                for (int p = 0; p < L; ++p)
-                    if (1 + p * (NP - 1) / L == kp) piece(p);
-                SCDA_SCHED_FENCE();
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        if (i + j > 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
-                SCDA_SCHED_FENCE();
-            }
-            buf = buf == NST - 1 ? 0 : buf + 1;
-            nbuf = nbuf == NST - 1 ? 0 : nbuf + 1;
+        } else {
+            SCDA_WAIT_VMCNT(0);
         }
-        SCDA_WAIT_VMCNT(0);
+        __builtin_amdgcn_s_barrier();
+        const float *ap = lds + buf * STAGE + lk * BM + wm * WM + lr;
+        const float *bp = lds + buf * STAGE + BK * BM + lk * BN + wn * WN + lr;
+        float a[2][TM], b[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[0][i] = ap[i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[0][j] = bp[j * 32];
+#pragma unroll
+        for (int kp = 0; kp < BK / 2; ++kp) {
+            const int cur = kp & 1, nxt = cur ^ 1;
+            if (kp + 1 < BK / 2) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[nxt][i] = ap[(2 * kp + 2) * BM + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[nxt][j] = bp[(2 * kp + 2) * BN + j * 32];
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+        }
+        buf = (buf + 1) & (NST - 1);
+        nbuf = (nbuf + 1) & (NST - 1);
     }
     conv_epilogue<WM, WN>(acc, g, e, m0, n0, tz, wm, wn, lane);
 }

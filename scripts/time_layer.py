@@ -1,0 +1,23 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from scda_amd import native
+L = {"conv1_2": (1, 64, 512, 1024, 64), "conv2_2": (1, 128, 256, 512, 128), "conv3_2": (1, 256, 128, 256, 256),
+     "conv4_2": (1, 512, 64, 128, 512), "conv5_x": (1, 512, 32, 64, 512), "dec_res": (4, 128, 64, 64, 128),
+     "dec_up2": (4, 64, 256, 256, 32), "conv3_1": (1, 128, 128, 256, 256)}
+name, what = sys.argv[1], sys.argv[2]
+B, Cin, H, W, Cout = L[name]
+dev = torch.device("cuda:0")
+x = torch.randn(B, Cin, H, W, device=dev); w = torch.randn(Cout, Cin, 3, 3, device=dev) * 0.05; b = torch.randn(Cout, device=dev)
+y = native.conv2d_fwd(x, w, b, 1, 1, 1); dy = torch.randn_like(y)
+fn = {"fwd": lambda: native.conv2d_fwd(x, w, b, 1, 1, 1), "dgrad": lambda: native.conv2d_dgrad(dy, w, x.shape, 1, 1),
+      "wgrad": lambda: native.conv2d_wgrad(dy, x, w.shape, 1, 1)}[what]
+for _ in range(3): fn()
+torch.cuda.synchronize()
+s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+s.record()
+for _ in range(20): fn()
+e.record(); torch.cuda.synchronize()
+ms = s.elapsed_time(e) / 20
+fl = 2.0 * y.numel() * Cin * 9
+print("%-8s %-5s dbg=%s plan=%s  %.3f ms  %.1f TF" % (name, what, os.environ.get("SCDA_DBG_NOLOAD", "-"), native.last_plan(), ms, fl / ms / 1e9), flush=True)
