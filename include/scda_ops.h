@@ -154,6 +154,12 @@ int scda_conv2d_fwd_hip(const float *x, const float *wp, const float *bias /*[Co
 /* dx [batch,Cin,IH,IW] = conv-transpose of dy [batch,Cout,OH,OW] (fully overwritten); wt = pack(w, 1) */
 int scda_conv2d_dgrad_hip(const float *dy, const float *wt, float *dx, int batch, int Cin, int IH, int IW, int Cout,
                           int KH, int KW, int S, int P, void *ws, size_t ws_bytes, void *stream);
+/* ... with the gradient of the activation that PRODUCED this conv's input folded into the epilogue (replaces one elementwise
+ * pass of the reference's autograd: ReLU / LeakyReLU backward of models/faster_rcnn/vgg_adver_expansion_cluster.py:108-111,
+ * common_net.py:251-262): dx = dgrad(dy) * (act_src > 0 ? 1 : act_slope); act_src = the conv's input x, or NULL */
+int scda_conv2d_dgrad_act_hip(const float *dy, const float *wt, float *dx, int batch, int Cin, int IH, int IW, int Cout,
+                              int KH, int KW, int S, int P, const float *act_src, float act_slope, void *ws, size_t ws_bytes,
+                              void *stream);
 /* the same for a conv with <= 4 input channels (image-side layers), direct form, HBM-bound on dy; w = the UNPACKED weight */
 int scda_conv2d_dgrad_small_cin_hip(const float *dy, const float *w, float *dx, int batch, int Cin, int IH, int IW, int Cout,
                                     int KH, int KW, int S, int P, void *stream);
@@ -185,6 +191,9 @@ int scda_gemm_hip(const float *A, const float *B, float *C, int M, int N, int K,
 /* nn.MaxPool2d(2,2): vgg_adver_expansion_cluster.py:106.  idx uint8 = winner 0..3 */
 int scda_maxpool2x2_fwd_hip(const float *x, float *y, uint8_t *idx, int planes, int H, int W, void *stream);
 int scda_maxpool2x2_bwd_hip(const float *dy, const uint8_t *idx, float *dx, int planes, int H, int W, void *stream);
+/* max-pool backward + backward of the ReLU in front of the pool (a window's winner is > 0 iff the pooled value y_pooled is) */
+int scda_maxpool2x2_bwd_relu_hip(const float *dy, const uint8_t *idx, const float *y_pooled, float *dx, int planes, int H, int W,
+                                 void *stream);
 /* mode: 0 ReLU, 1 LeakyReLU(slope), 2 tanh, 3 sigmoid; backward takes the forward OUTPUT y */
 int scda_act_fwd_hip(const float *x, float *y, long long n, int mode, float slope, void *stream);
 int scda_act_bwd_hip(const float *dy, const float *y, float *dx, long long n, int mode, float slope, void *stream);
@@ -193,6 +202,17 @@ int scda_axpby_hip(const float *a, const float *b, float *y, long long n, float 
 /* nn.Dropout(p): mask[i] = keep ? 1 : 0 from a counter-based generator; y = mask ? x*scale : 0 */
 int scda_dropout_mask_hip(uint8_t *mask, long long n, float p, uint64_t seed, void *stream);
 int scda_dropout_apply_hip(const float *x, const uint8_t *mask, float *y, long long n, float scale, void *stream);
+/* nn.Dropout with the keep decision recomputed from (seed, index) -- forward and backward, no mask tensor; relu_src (backward,
+ * may be NULL): the dropout's input when it is a ReLU output, whose gradient is then applied in the same pass */
+int scda_dropout_seeded_hip(const float *x, float *y, long long n, float p, uint64_t seed, float scale, const float *relu_src,
+                            void *stream);
+/* out1 (+)= scale * sum_c w[c] * mean_i BCE(sigmoid(x[c][i]), t[c or 0][i]): the per-cluster adversarial loss terms of
+ * tools/faster_rcnn_train_val.py:584-600,675-687,723-732 in one launch (x [C,n] logits; t [t_rows,n], t_rows 1 or C; w [C] or NULL);
+ * prob_out [C,n] (may be NULL) receives sigmoid(x) for the backward, which returns d out1 / d x * grad_scalar */
+int scda_sigmoid_bce_rows_fwd_hip(const float *x, const float *t, int t_rows, const float *w, int C, int n, float scale,
+                                  int accumulate, float *prob_out, float *out1, void *stream);
+int scda_sigmoid_bce_rows_bwd_hip(const float *prob, const float *t, int t_rows, const float *w, int C, int n, float scale,
+                                  const float *grad_scalar, float *dx, void *stream);
 size_t scda_bias_grad_workspace_bytes(int C);
 int scda_bias_grad_nchw_hip(const float *dy, float *db, int B, int C, int HW, int accumulate, float *ws, void *stream);
 int scda_colsum_hip(const float *dy, float *db, int M, int N, int accumulate, void *stream);

@@ -45,27 +45,35 @@ class Conv2dFn(Function):
     """conv (+bias) (+ReLU/LeakyReLU) in one MFMA kernel; backward = act' -> dgrad, wgrad, bias-grad."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, pad, act, slope):
+    def forward(ctx, x, w, b, stride, pad, act, slope, fuse=(None, False)):
+        """fuse = (input_act, defer): static fusion plan of the owning model (scda_amd.layers.plan_act_fusion).
+        input_act = (mode, slope) of the activation that produced x: THIS conv's data gradient applies that activation's
+        gradient in its epilogue.  defer = True: the consumer of y does the same for this conv's own activation, so the
+        backward here receives dy already multiplied by act'(y)."""
         x = _c(x)
         if not w.is_contiguous():
             w = w.contiguous()
         y = N.conv2d_fwd(x, w, b, stride, pad, act, slope)
-        ctx.cfg = (stride, pad, act, slope)
+        in_act, defer = fuse if replay is None else (None, False)   # parity tests replay act masks: plain un-fused backward
+        ctx.cfg = (stride, pad, act, slope, in_act, defer)
         ctx.has_bias = b is not None
         ctx.bias_ref, ctx.w_ref = b, w   # the Parameter objects themselves (they carry the flat-bucket gradient views)
-        ctx.save_for_backward(x, w, _mask_src(ctx, y) if act != ACT_NONE else None)
+        ctx.save_for_backward(x, w, _mask_src(ctx, y) if act != ACT_NONE and not defer else None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w, y = ctx.saved_tensors
-        stride, pad, act, slope = ctx.cfg
+        stride, pad, act, slope, in_act, defer = ctx.cfg
         dy = _c(dy)
-        if act != ACT_NONE:
+        if act != ACT_NONE and not defer:
             dy = N.act_bwd(dy, y, 0 if act == ACT_RELU else 1, slope)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = N.conv2d_dgrad(dy, w, x.shape, stride, pad)
+            if in_act is not None:
+                dx = N.conv2d_dgrad(dy, w, x.shape, stride, pad, act_src=x, act_slope=0.0 if in_act[0] == ACT_RELU else in_act[1])
+            else:
+                dx = N.conv2d_dgrad(dy, w, x.shape, stride, pad)
         want_w, want_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         if want_w and want_b:   # one pass: the bias gradient is fused into the weight-gradient kernel where the shape allows
             sw, sb = _sink(ctx.w_ref), _sink(ctx.bias_ref)
@@ -82,18 +90,20 @@ class Conv2dFn(Function):
             db = N.bias_grad_nchw(dy, out=sink)
             if sink is not None:
                 db = None
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
 class LinearFn(Function):
     @staticmethod
-    def forward(ctx, x, w, b, act):
+    def forward(ctx, x, w, b, act, defer=False):
+        """defer: the consumer of y (a Dropout, see DropoutSeededFn) applies this layer's ReLU gradient"""
         x = _c(x); w = _c(w)
         y = N.linear_fwd(x, w, b, act)
-        ctx.act = act
+        defer = defer and replay is None
+        ctx.act = act if not defer else ACT_NONE
         ctx.has_bias = b is not None
         ctx.bias_ref, ctx.w_ref = b, w   # the Parameter objects themselves (they carry the flat-bucket gradient views)
-        ctx.save_for_backward(x, w, _mask_src(ctx, y) if act != ACT_NONE else None)
+        ctx.save_for_backward(x, w, _mask_src(ctx, y) if ctx.act != ACT_NONE else None)
         return y
 
     @staticmethod
@@ -115,24 +125,26 @@ class LinearFn(Function):
             db = N.colsum(dy, out=sink)
             if sink is not None:
                 db = None
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
 class MaxPool2x2Fn(Function):
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, relu_input=False):
+        """relu_input: x is the output of a ReLU whose owner defers its gradient to this pool's backward (fusion plan)"""
         x = _c(x)
         y, idx = N.maxpool2x2_fwd(x)
         if replay is not None and any(ctx.needs_input_grad):
             idx = replay.pool(y, idx)
-        ctx.save_for_backward(idx)
+        fuse = relu_input and replay is None
+        ctx.save_for_backward(idx, y if fuse else None)
         ctx.xshape = tuple(x.shape)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        (idx,) = ctx.saved_tensors
-        return N.maxpool2x2_bwd(_c(dy), idx, ctx.xshape)
+        idx, y = ctx.saved_tensors
+        return N.maxpool2x2_bwd(_c(dy), idx, ctx.xshape, relu_y=y), None
 
 
 class ActFn(Function):
@@ -163,6 +175,54 @@ class DropoutFn(Function):
     def backward(ctx, dy):
         (mask,) = ctx.saved_tensors
         return N.dropout_apply(_c(dy), mask, ctx.scale), None, None
+
+
+class DropoutSeededFn(Function):
+    """nn.Dropout whose keep decisions are recomputed from a 64-bit seed in both passes (no mask tensor, one launch each way);
+    relu_input: x is a ReLU output whose owner defers its gradient to this backward (fusion plan)"""
+
+    @staticmethod
+    def forward(ctx, x, p, seed, relu_input):
+        x = _c(x)
+        ctx.cfg = (p, seed)
+        ctx.save_for_backward(x if relu_input else None)
+        return N.dropout_seeded(x, p, seed, 1.0 / (1.0 - p))
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        p, seed = ctx.cfg
+        return N.dropout_seeded(_c(dy), p, seed, 1.0 / (1.0 - p), relu_src=x), None, None, None
+
+
+class AdvLossFn(Function):
+    """scale * sum over groups of sum_c w[c] * mean_i BCE(sigmoid(logits[c, i]), labels[c or 0, i]) -> 0-dim loss.
+    One launch per group in each direction (the reference: a sigmoid, a split and 2 x cluster_num BCE + add kernels per group,
+    tools/faster_rcnn_train_val.py:567-600,642-690).  Called as AdvLossFn.apply(scale, n_groups, *logits, *labels, *weights);
+    weights are constants (the per-cluster means of the patch discriminator are detached where the reference zeroes or never
+    uses their gradient -- see scda_amd.train_step)."""
+
+    @staticmethod
+    def forward(ctx, scale, k, *args):
+        logits, labels, weights = args[:k], args[k:2 * k], args[2 * k:3 * k]
+        out, probs = None, []
+        for x, t, w in zip(logits, labels, weights):
+            out, pr = N.sigmoid_bce_rows_fwd(_c(x), _c(t), w, scale, out=out)
+            probs.append(pr)
+        ctx.k, ctx.scale = k, scale
+        ctx.save_for_backward(*probs, *[_c(t) for t in labels], *[w if w is not None else torch.empty(0) for w in weights])
+        ctx.has_w = [w is not None for w in weights]
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        k = ctx.k
+        sv = ctx.saved_tensors
+        probs, labels, weights = sv[:k], sv[k:2 * k], sv[2 * k:3 * k]
+        g = _c(g).reshape(1)
+        grads = [N.sigmoid_bce_rows_bwd(probs[i], labels[i], weights[i] if ctx.has_w[i] else None, ctx.scale, g)
+                 if ctx.needs_input_grad[2 + i] else None for i in range(k)]
+        return (None, None) + tuple(grads) + (None,) * (2 * k)
 
 
 class AddFn(Function):
@@ -340,12 +400,18 @@ class GlobalAvgPoolFn(Function):
 
 
 # functional front-ends -------------------------------------------------------
-def conv2d(x, w, b=None, stride=1, padding=0, act=ACT_NONE, slope=0.01):
-    return Conv2dFn.apply(x, w, b, stride, padding, act, slope)
+def conv2d(x, w, b=None, stride=1, padding=0, act=ACT_NONE, slope=0.01, fuse=(None, False)):
+    return Conv2dFn.apply(x, w, b, stride, padding, act, slope, fuse)
 
 
-def linear(x, w, b=None, act=ACT_NONE):
-    return LinearFn.apply(x, w, b, act)
+def linear(x, w, b=None, act=ACT_NONE, defer_act_bwd=False):
+    return LinearFn.apply(x, w, b, act, defer_act_bwd)
+
+
+def adversarial_loss(groups, scale=1.0):
+    """groups: [(logits [C,n], labels [1,n] | [C,n], weights [C] | None), ...] -> scale * sum of the weighted per-row mean BCEs"""
+    k = len(groups)
+    return AdvLossFn.apply(scale, k, *[g[0] for g in groups], *[g[1] for g in groups], *[g[2] for g in groups])
 
 
 def cross_entropy(logits, targets, ignore_index=-100):

@@ -80,6 +80,11 @@ struct Epi {
     float slope;
     int splits;
     int accumulate;      // splits == 1 only: out += result (one writer per element)
+    // data gradient only: act'() of the PRODUCER of this conv's input, applied here so that the producer's backward does not need
+    // its own elementwise pass.  mask_src = this conv's input x (the producer's ReLU / LeakyReLU output, same shape as the result);
+    // result *= x > 0 ? 1 : mask_slope (0 for ReLU).  null: no masking.
+    const float *mask_src;
+    float mask_slope;
 };
 
 // ---------------------------------------------------------------------------
@@ -126,7 +131,9 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[WM / 32][WN / 32], c
                 } else {
                     if (e.bias) v += e.bias[m];
                     v = apply_act(v, e.act, e.slope);
-                    e.out[((size_t)oimg * g.M + m) * g.dPHW.d + opix] = v;
+                    const size_t o = ((size_t)oimg * g.M + m) * g.dPHW.d + opix;
+                    if (e.mask_src) v = e.mask_src[o] > 0.f ? v : v * e.mask_slope;
+                    e.out[o] = v;
                 }
             }
         }
@@ -400,7 +407,8 @@ __global__ __launch_bounds__(BM == 256 ? 512 : 256) void conv_igemm_glds_kernel(
 __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float *__restrict__ ws, const int splits,
                                                                  const int M, const int N, const Div dPHW,
                                                                  const float *__restrict__ bias, const int act,
-                                                                 const float slope, float *__restrict__ out) {
+                                                                 const float slope, float *__restrict__ out,
+                                                                 const float *__restrict__ mask_src, const float mask_slope) {
     const long long total = (long long)M * N;
     for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
          idx += (long long)blockDim.x * gridDim.x) {
@@ -411,7 +419,9 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float *__
         v = apply_act(v, act, slope);
         int img, pix;
         dPHW.divmod(n, img, pix);
-        out[((size_t)img * M + m) * dPHW.d + pix] = v;
+        const size_t o = ((size_t)img * M + m) * dPHW.d + pix;
+        if (mask_src) v = mask_src[o] > 0.f ? v : v * mask_slope;
+        out[o] = v;
     }
 }
 
@@ -1228,7 +1238,7 @@ static int launch_conv(const float *Wm, const float *X, const ConvGeom &g0, Epi 
     int rc = launch_status("conv_igemm_kernel");
     if (rc || splits == 1) return rc;
     hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(ew_grid((long long)g.M * g.N)), dim3(256), 0, st, ws, splits, g.M,
-                       g.N, g.dPHW, e.bias, e.act, e.slope, e.out);
+                       g.N, g.dPHW, e.bias, e.act, e.slope, e.out, e.mask_src, e.mask_slope);
     return launch_status("conv_splitk_reduce_kernel");
 }
 
@@ -1332,13 +1342,21 @@ SCDA_API int scda_conv2d_fwd_hip(const float *x, const float *w, const float *bi
     g.dPHW = Div(OH * OW); g.dPW = Div(OW); g.dCB = Div(Cin);
     g.slab_aligned = (Cin % BK) == 0;
     g.zp = zero_page();
-    Epi e{y, nullptr, bias, 0, act, slope, 1, 0};
+    Epi e{y, nullptr, bias, 0, act, slope, 1, 0, nullptr, 0.f};
     CONV_DISPATCH(launch_conv, , false > (w, x, g, e, (float *)ws, ws_bytes, as_stream(stream)))
 }
 
 // dx = dgrad(dy, wt) where wt = pack(w, for_dgrad=1) is [Cin][KH*KW][Cout] (scda_conv2d_pack_weight_hip)
 SCDA_API int scda_conv2d_dgrad_hip(const float *dy, const float *wt, float *dx, int batch, int Cin, int IH, int IW,
                                    int Cout, int KH, int KW, int S, int P, void *ws, size_t ws_bytes, void *stream) {
+    return scda_conv2d_dgrad_act_hip(dy, wt, dx, batch, Cin, IH, IW, Cout, KH, KW, S, P, nullptr, 0.f, ws, ws_bytes, stream);
+}
+
+// ... with the activation gradient of the layer that PRODUCED this conv's input folded into the epilogue:
+// dx = dgrad(dy) * (act_src > 0 ? 1 : act_slope), act_src = the conv's input x [batch,Cin,IH,IW] (a ReLU / LeakyReLU output)
+SCDA_API int scda_conv2d_dgrad_act_hip(const float *dy, const float *wt, float *dx, int batch, int Cin, int IH, int IW,
+                                       int Cout, int KH, int KW, int S, int P, const float *act_src, float act_slope,
+                                       void *ws, size_t ws_bytes, void *stream) {
     if (!dy || !wt || !dx || batch <= 0) { set_error("scda_conv2d_dgrad_hip: bad arguments"); return SCDA_EINVAL; }
     const int OH = conv_out_dim(IH, KH, S, P), OW = conv_out_dim(IW, KW, S, P);
     ConvGeom g;
@@ -1347,7 +1365,7 @@ SCDA_API int scda_conv2d_dgrad_hip(const float *dy, const float *wt, float *dx, 
     g.dPHW = Div(IH * IW); g.dPW = Div(IW); g.dCB = Div(Cout);
     g.slab_aligned = (Cout % BK) == 0;
     g.zp = zero_page();
-    Epi e{dx, nullptr, nullptr, 0, (int)ACT_NONE, 0.f, 1, 0};
+    Epi e{dx, nullptr, nullptr, 0, (int)ACT_NONE, 0.f, 1, 0, act_src, act_slope};
     CONV_DISPATCH(launch_conv, , true > (wt, dy, g, e, (float *)ws, ws_bytes, as_stream(stream)))
 }
 
@@ -1459,7 +1477,7 @@ SCDA_API int scda_gemm_hip(const float *A, const float *B, float *C, int M, int 
                xcd_swizzle_enabled()};
     if (!g.zp) { set_error("scda_gemm_hip: could not allocate the zero page"); return SCDA_ELAUNCH; }
     splits = cdiv(K, g.k_per_split);
-    Epi e{C, (float *)ws, bias, bias_on_n, act, slope, splits, accumulate};
+    Epi e{C, (float *)ws, bias, bias_on_n, act, slope, splits, accumulate, nullptr, 0.f};
     dim3 grid((unsigned)g.nx * g.ny * splits);
 #define GEMM_LAUNCH(BM_, BN_)                                                                            \
     do {                                                                                                 \

@@ -57,16 +57,20 @@ __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float *__restri
     }
 }
 
+// relu_y (may be null): the pool's OUTPUT; when given, the gradient of a ReLU that produced the pool's input is applied too --
+// the winner of a window is > 0 exactly when the pooled value is (fused "max-pool backward + ReLU backward")
 __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float *__restrict__ dy, const uint8_t *__restrict__ idx,
                                                            float *__restrict__ dx, const long long total, const int H,
-                                                           const int W, const int OH, const int OW) {
+                                                           const int W, const int OH, const int OW,
+                                                           const float *__restrict__ relu_y) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
          i += (long long)blockDim.x * gridDim.x) {
         const int ox = (int)(i % OW);
         const long long r = i / OW;
         const int oy = (int)(r % OH);
         const long long pc = r / OH;
-        const float g = dy[i];
+        float g = dy[i];
+        if (relu_y && !(relu_y[i] > 0.f)) g = 0.f;
         const int k = idx[i];
         float *p = dx + (pc * H + 2 * oy) * W + 2 * ox;
         if (W & 1) {
@@ -143,6 +147,60 @@ __global__ __launch_bounds__(256) void dropout_apply_kernel(const float *__restr
                                                             const float scale) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)blockDim.x * gridDim.x)
         y[i] = mask[i] ? x[i] * scale : 0.f;
+}
+
+// nn.Dropout without a mask tensor: keep(i) is recomputed from (seed, i) in the forward AND the backward pass (the same
+// generator as dropout_mask_kernel, so a seeded run and a mask-replay run agree).  relu_src (backward only, may be null): the
+// dropout's INPUT when that is a ReLU output -- the ReLU's gradient is applied in the same pass.
+__global__ __launch_bounds__(256) void dropout_seeded_kernel(const float *__restrict__ x, float *__restrict__ y, const long long n,
+                                                             const float p, const uint64_t seed, const float scale,
+                                                             const float *__restrict__ relu_src) {
+    const uint32_t thr = (uint32_t)((double)p * 4294967296.0 > 4294967295.0 ? 4294967295.0 : (double)p * 4294967296.0);
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)blockDim.x * gridDim.x) {
+        bool keep = mix_hash(seed, (uint64_t)i) >= thr;
+        if (relu_src) keep = keep && relu_src[i] > 0.f;
+        y[i] = keep ? x[i] * scale : 0.f;
+    }
+}
+
+// sum_c w[c] * mean_i BCE(sigmoid(x[c][i]), t[c or 0][i]) * scale -- the per-cluster adversarial terms of
+// tools/faster_rcnn_train_val.py:584-600,675-687,723-732 (F.binary_cross_entropy on torch.sigmoid outputs, log clamp -100,
+// one mean per cluster row, rows weighted by the patch discriminator) as ONE launch; prob_out keeps sigmoid(x) for the backward.
+// accumulate: out[0] += (several groups of one loss).  Single workgroup: C x n is a few thousand elements.
+__global__ __launch_bounds__(1024) void sigmoid_bce_rows_fwd_kernel(const float *__restrict__ x, const float *__restrict__ t,
+                                                                    const int t_rows, const float *__restrict__ w,
+                                                                    const int C, const int n, const float scale,
+                                                                    const int accumulate, float *__restrict__ prob_out,
+                                                                    float *__restrict__ out) {
+    __shared__ float red[16];
+    float total = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float *tr = t + (t_rows == 1 ? 0 : (size_t)c * n);
+        float s = 0.f;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const float pi = 1.f / (1.f + expf(-x[(size_t)c * n + i])), ti = tr[i];
+            if (prob_out) prob_out[(size_t)c * n + i] = pi;
+            const float lp = fmaxf(logf(pi), -100.f), l1p = fmaxf(logf(1.f - pi), -100.f);
+            s += -(ti * lp + (1.f - ti) * l1p);
+        }
+        s = block_sum(s, red);
+        total += (w ? w[c] : 1.f) * (s / (float)n);
+    }
+    if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.f) + total * scale;
+}
+
+// d/dx of the above: chain of BCE'(p) = (p - t) / max(p (1 - p), 1e-12) (torch's clamp) and sigmoid'(p) = p (1 - p)
+__global__ __launch_bounds__(256) void sigmoid_bce_rows_bwd_kernel(const float *__restrict__ prob, const float *__restrict__ t,
+                                                                   const int t_rows, const float *__restrict__ w,
+                                                                   const int C, const int n, const float scale,
+                                                                   const float *__restrict__ g, float *__restrict__ dx) {
+    const long long total = (long long)C * n;
+    for (long long j = blockIdx.x * (long long)blockDim.x + threadIdx.x; j < total; j += (long long)blockDim.x * gridDim.x) {
+        const int c = (int)(j / n), i = (int)(j - (long long)c * n);
+        const float pi = prob[j], ti = t[t_rows == 1 ? i : j];
+        const float gs = g[0] * scale * (w ? w[c] : 1.f) / (float)n;
+        dx[j] = (pi - ti) / fmaxf((1.f - pi) * pi, 1e-12f) * gs * (pi * (1.f - pi));
+    }
 }
 
 // ------------------------------------------------------- bias gradients -----
@@ -724,7 +782,18 @@ SCDA_API int scda_maxpool2x2_bwd_hip(const float *dy, const uint8_t *idx, float 
     NN_CHECK(dy && dx && idx && planes > 0 && H >= 2 && W >= 2, "scda_maxpool2x2_bwd_hip")
     const int OH = H / 2, OW = W / 2;
     const long long total = (long long)planes * OH * OW;
-    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(ew_grid(total) * 4), dim3(256), 0, as_stream(stream), dy, idx, dx, total, H, W, OH, OW);
+    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(ew_grid(total) * 4), dim3(256), 0, as_stream(stream), dy, idx, dx, total, H, W, OH, OW,
+                       (const float *)nullptr);
+    return launch_status("maxpool2_bwd_kernel");
+}
+
+SCDA_API int scda_maxpool2x2_bwd_relu_hip(const float *dy, const uint8_t *idx, const float *y_pooled, float *dx, int planes, int H,
+                                          int W, void *stream) {
+    NN_CHECK(dy && dx && idx && y_pooled && planes > 0 && H >= 2 && W >= 2, "scda_maxpool2x2_bwd_relu_hip")
+    const int OH = H / 2, OW = W / 2;
+    const long long total = (long long)planes * OH * OW;
+    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(ew_grid(total) * 4), dim3(256), 0, as_stream(stream), dy, idx, dx, total, H, W, OH, OW,
+                       y_pooled);
     return launch_status("maxpool2_bwd_kernel");
 }
 
@@ -765,6 +834,30 @@ SCDA_API int scda_dropout_apply_hip(const float *x, const uint8_t *mask, float *
 }
 
 #define BIAS_GRAD_MAX_SPLIT 128
+SCDA_API int scda_dropout_seeded_hip(const float *x, float *y, long long n, float p, uint64_t seed, float scale,
+                                     const float *relu_src, void *stream) {
+    NN_CHECK(x && y && n >= 0 && p >= 0.f && p < 1.f, "scda_dropout_seeded_hip")
+    if (n == 0) return SCDA_OK;
+    hipLaunchKernelGGL(dropout_seeded_kernel, dim3(ew_grid(n) * 4), dim3(256), 0, as_stream(stream), x, y, n, p, seed, scale, relu_src);
+    return launch_status("dropout_seeded_kernel");
+}
+
+SCDA_API int scda_sigmoid_bce_rows_fwd_hip(const float *x, const float *t, int t_rows, const float *w, int C, int n, float scale,
+                                           int accumulate, float *prob_out, float *out1, void *stream) {
+    NN_CHECK(x && t && out1 && C > 0 && n > 0 && (t_rows == 1 || t_rows == C), "scda_sigmoid_bce_rows_fwd_hip")
+    hipLaunchKernelGGL(sigmoid_bce_rows_fwd_kernel, dim3(1), dim3(1024), 0, as_stream(stream), x, t, t_rows, w, C, n, scale, accumulate,
+                       prob_out, out1);
+    return launch_status("sigmoid_bce_rows_fwd_kernel");
+}
+
+SCDA_API int scda_sigmoid_bce_rows_bwd_hip(const float *prob, const float *t, int t_rows, const float *w, int C, int n, float scale,
+                                           const float *grad_scalar, float *dx, void *stream) {
+    NN_CHECK(prob && t && grad_scalar && dx && C > 0 && n > 0 && (t_rows == 1 || t_rows == C), "scda_sigmoid_bce_rows_bwd_hip")
+    hipLaunchKernelGGL(sigmoid_bce_rows_bwd_kernel, dim3(ew_grid((long long)C * n)), dim3(256), 0, as_stream(stream), prob, t, t_rows, w,
+                       C, n, scale, grad_scalar, dx);
+    return launch_status("sigmoid_bce_rows_bwd_kernel");
+}
+
 SCDA_API size_t scda_bias_grad_workspace_bytes(int C) { return (size_t)C * BIAS_GRAD_MAX_SPLIT * sizeof(float); }
 
 SCDA_API int scda_bias_grad_nchw_hip(const float *dy, float *db, int B, int C, int HW, int accumulate, float *ws,

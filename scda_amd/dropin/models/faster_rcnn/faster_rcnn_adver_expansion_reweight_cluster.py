@@ -241,6 +241,7 @@ class GAN_dis_AE(nn.Module):
         self.model_A.apply(gaussian_weights_init)
         self.model_B = self._make_net(ch, cin, n_layer - 1)
         self.model_B.apply(gaussian_weights_init)
+        L.plan_act_fusion(self.model_A, self.model_B)   # LeakyReLU gradients applied by the next conv's data gradient
 
     def _make_net(self, ch, input_dim, n_layer):
         seq = [LeakyReLUConv2d(input_dim, ch, kernel_size=3, stride=2, padding=1)]

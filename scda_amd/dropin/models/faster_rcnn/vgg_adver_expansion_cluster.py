@@ -52,6 +52,9 @@ class VGG(FasterRCNN_AdEx):
             L.Linear(4096, 4096, fused_act=ACT_RELU), L.FusedAct("ReLU"), L.Dropout())
         self.fc_rcnn_cls = L.Linear(4096, cfg['num_classes'])
         self.fc_rcnn_loc = L.Linear(4096, cfg['num_classes'] * 4)
+        # pure chains: conv -> conv / pool and FC -> dropout apply the producer's ReLU gradient (conv5_3 and the RPN's 3x3 conv
+        # feed two consumers each and keep their own elementwise pass)
+        L.plan_act_fusion(self.features, self.classifier)
         self._initialize_weights()
 
     def feature_extractor(self, x):

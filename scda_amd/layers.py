@@ -24,9 +24,13 @@ class Conv2d(nn.Conv2d):
             raise NotImplementedError("scda_amd.Conv2d: anisotropic stride/padding")
         self.fused_act = fused_act
         self.slope = slope
+        # static fusion plan (plan_act_fusion): act of the layer that feeds this conv / whether our consumer applies our act'
+        self.input_act = None
+        self.defer_act_bwd = False
 
     def forward(self, x):
-        return A.conv2d(x, self.weight, self.bias, self.stride[0], self.padding[0], self.fused_act, self.slope)
+        return A.conv2d(x, self.weight, self.bias, self.stride[0], self.padding[0], self.fused_act, self.slope,
+                        (self.input_act, self.defer_act_bwd))
 
     def extra_repr(self):
         s = super().extra_repr()
@@ -63,14 +67,17 @@ class Linear(nn.Linear):
     def __init__(self, *args, fused_act=A.ACT_NONE, **kw):
         super().__init__(*args, **kw)
         self.fused_act = fused_act
+        self.defer_act_bwd = False     # fusion plan: the Dropout behind this layer applies its ReLU gradient
 
     def forward(self, x):
-        return A.linear(x, self.weight, self.bias, self.fused_act)
+        return A.linear(x, self.weight, self.bias, self.fused_act, self.defer_act_bwd)
 
 
 class MaxPool2x2(nn.Module):
+    relu_input = False             # fusion plan: this pool's backward also applies the ReLU gradient of the conv in front of it
+
     def forward(self, x):
-        return A.MaxPool2x2Fn.apply(x)
+        return A.MaxPool2x2Fn.apply(x, self.relu_input)
 
     def extra_repr(self):
         return "kernel_size=2, stride=2"
@@ -94,23 +101,52 @@ class Dropout(nn.Module):
     Tests inject masks through `mask_source` so that the CPU oracle and the device see the same Bernoulli draws."""
 
     mask_source = None  # callable(shape, p, device) -> uint8 mask, or None
+    relu_input = False  # fusion plan: the backward also applies the ReLU gradient of the Linear in front (eval mode: see forward)
 
     def __init__(self, p=0.5):
         super().__init__()
         self.p = float(p)
 
     def forward(self, x):
+        fused = self.relu_input and A.replay is None
         if not self.training or self.p == 0.0:
-            return x
+            # identity -- but a producer that deferred its ReLU gradient to us still needs it applied
+            return A.ActFn.apply(x, N.ACT_MODE["relu"], 0.0) if fused and torch.is_grad_enabled() and x.requires_grad else x
         if Dropout.mask_source is not None:
             mask = Dropout.mask_source(tuple(x.shape), self.p, x.device)
-        else:
-            seed = int(torch.randint(0, 1 << 62, (1,), dtype=torch.int64))
-            mask = N.dropout_mask(tuple(x.shape), self.p, seed, x.device)
-        return A.DropoutFn.apply(x, mask, 1.0 / (1.0 - self.p))
+            if fused:   # replayed masks (parity tests of the FUSED path): explicit mask, ReLU gradient through a no-op ReLU
+                x = A.ActFn.apply(x, N.ACT_MODE["relu"], 0.0)
+            return A.DropoutFn.apply(x, mask, 1.0 / (1.0 - self.p))
+        seed = int(torch.randint(0, 1 << 62, (1,), dtype=torch.int64))
+        return A.DropoutSeededFn.apply(x, self.p, seed, fused)
 
     def extra_repr(self):
         return f"p={self.p}"
+
+
+def plan_act_fusion(*sequentials):
+    """Static fusion plan for PURE CHAINS (nn.Sequential whose intermediate tensors have exactly one consumer -- the VGG
+    feature extractor, the FC6/FC7 classifier, each image-discriminator branch): the gradient of a fused ReLU / LeakyReLU is
+    applied by the layer that CONSUMES the activation instead of by an elementwise pass of its own:
+        Conv(act) -> Conv            the second conv's data-gradient epilogue multiplies by act'(its input)
+        Conv(ReLU) -> MaxPool2x2     the pool's backward zeroes windows whose maximum is not positive
+        Linear(ReLU) -> Dropout      the dropout's backward also tests its input > 0
+    Both ends get a flag, so a producer never skips its act' unless its consumer applies it.  Removes 30 of the 44
+    elementwise act' launches of an iteration.  Parity tests that replay activation masks run the un-fused backward."""
+    n = 0
+    for seq in sequentials:
+        leaves = [m for m in seq.modules() if not list(m.children()) and not isinstance(m, FusedAct)]
+        for a, b in zip(leaves, leaves[1:]):
+            if isinstance(a, Conv2d) and a.fused_act != A.ACT_NONE and isinstance(b, Conv2d):
+                a.defer_act_bwd, b.input_act = True, (a.fused_act, a.slope)
+            elif isinstance(a, Conv2d) and a.fused_act == A.ACT_RELU and isinstance(b, MaxPool2x2):
+                a.defer_act_bwd, b.relu_input = True, True
+            elif isinstance(a, Linear) and a.fused_act == A.ACT_RELU and isinstance(b, Dropout):
+                a.defer_act_bwd, b.relu_input = True, True
+            else:
+                continue
+            n += 1
+    return n
 
 
 class InstanceNorm2d(nn.Module):

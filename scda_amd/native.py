@@ -311,12 +311,18 @@ def conv2d_fwd(x, w, bias, stride, pad, act=ACT_NONE, slope=0.01):
     return y
 
 
-def conv2d_dgrad(dy, w, x_shape, stride, pad):
+def conv2d_dgrad(dy, w, x_shape, stride, pad, act_src=None, act_slope=0.0):
+    """act_src (the conv's input x, a ReLU / LeakyReLU output): dx is additionally multiplied by x > 0 ? 1 : act_slope -- the
+    activation gradient of the layer that produced x, folded into this kernel's epilogue"""
     _req(dy, "dy"); _req(w, "w")
     B, Cin, IH, IW = x_shape
     Cout, _, KH, KW = w.shape
     dx = torch.empty(B, Cin, IH, IW, dtype=torch.float32, device=dy.device)
-    if Cin <= 4 and Cout * KH * KW * 16 <= 65536 and (KH, KW) in ((3, 3), (1, 1)):
+    if act_src is not None:
+        _req(act_src, "act_src")
+        if tuple(act_src.shape) != tuple(x_shape):
+            raise ValueError("act_src must have the shape of the conv input")
+    if act_src is None and Cin <= 4 and Cout * KH * KW * 16 <= 65536 and (KH, KW) in ((3, 3), (1, 1)):
         # image-side layer: 3 rows of a 64-row MFMA tile would be 95 % padding -- direct kernel, unpacked weights
         _check(lib().scda_conv2d_dgrad_small_cin_hip(_p(dy), _p(w.contiguous()), _p(dx), i32(B), i32(Cin), i32(IH), i32(IW), i32(Cout),
                                                      i32(KH), i32(KW), i32(stride), i32(pad), _stream()),
@@ -324,8 +330,9 @@ def conv2d_dgrad(dy, w, x_shape, stride, pad):
         return dx
     wt = conv2d_pack_weight(w, True)
     ws, n = _conv_ws(B, Cin, IH, IW, Cout, KH, KW, stride, pad, dy.device)
-    _check(lib().scda_conv2d_dgrad_hip(_p(dy), _p(wt), _p(dx), i32(B), i32(Cin), i32(IH), i32(IW), i32(Cout), i32(KH),
-                                       i32(KW), i32(stride), i32(pad), _p(ws), _sz(n), _stream()), "scda_conv2d_dgrad_hip")
+    _check(lib().scda_conv2d_dgrad_act_hip(_p(dy), _p(wt), _p(dx), i32(B), i32(Cin), i32(IH), i32(IW), i32(Cout), i32(KH),
+                                           i32(KW), i32(stride), i32(pad), _p(act_src), f32(act_slope), _p(ws), _sz(n), _stream()),
+           "scda_conv2d_dgrad_act_hip")
     return dx
 
 
@@ -427,11 +434,17 @@ def maxpool2x2_fwd(x):
     return y, idx
 
 
-def maxpool2x2_bwd(dy, idx, x_shape):
+def maxpool2x2_bwd(dy, idx, x_shape, relu_y=None):
+    """relu_y = the pool's output: additionally applies the gradient of a ReLU that produced the pool's input"""
     _req(dy, "dy"); _req(idx, "idx", torch.uint8)
     B, C, H, W = x_shape
     dx = torch.empty(B, C, H, W, dtype=torch.float32, device=dy.device)
-    _check(lib().scda_maxpool2x2_bwd_hip(_p(dy), _p(idx), _p(dx), i32(B * C), i32(H), i32(W), _stream()), "scda_maxpool2x2_bwd_hip")
+    if relu_y is None:
+        _check(lib().scda_maxpool2x2_bwd_hip(_p(dy), _p(idx), _p(dx), i32(B * C), i32(H), i32(W), _stream()), "scda_maxpool2x2_bwd_hip")
+    else:
+        _req(relu_y, "relu_y")
+        _check(lib().scda_maxpool2x2_bwd_relu_hip(_p(dy), _p(idx), _p(relu_y), _p(dx), i32(B * C), i32(H), i32(W), _stream()),
+               "scda_maxpool2x2_bwd_relu_hip")
     return dx
 
 
@@ -473,6 +486,43 @@ def dropout_apply(x, mask, scale):
     y = torch.empty_like(x)
     _check(lib().scda_dropout_apply_hip(_p(x), _p(mask), _p(y), i64(x.numel()), f32(scale), _stream()), "scda_dropout_apply_hip")
     return y
+
+
+def dropout_seeded(x, p, seed, scale, relu_src=None):
+    """y = keep(seed, i) ? x * scale : 0 (no mask tensor; the backward calls this again with dy); relu_src: see scda_ops.h"""
+    _req(x, "x")
+    if relu_src is not None:
+        _req(relu_src, "relu_src")
+    y = torch.empty_like(x)
+    _check(lib().scda_dropout_seeded_hip(_p(x), _p(y), i64(x.numel()), f32(p), u64(seed & 0xFFFFFFFFFFFFFFFF), f32(scale),
+                                         _p(relu_src), _stream()), "scda_dropout_seeded_hip")
+    return y
+
+
+def sigmoid_bce_rows_fwd(x, t, w, scale, out=None, want_prob=True):
+    """out[0] (+)= scale * sum_c w[c] * mean_i BCE(sigmoid(x[c,i]), t[c or 0, i]); -> (out [1], prob [C,n] | None)"""
+    _req(x, "x"); _req(t, "t")
+    C, n = x.shape
+    t_rows = t.numel() // n
+    if t.numel() != t_rows * n or t_rows not in (1, C):
+        raise ValueError("labels must be [1,n] or [C,n]")
+    if w is not None:
+        _req(w, "w")
+    acc = out is not None
+    if out is None:
+        out = torch.empty(1, dtype=torch.float32, device=x.device)
+    prob = torch.empty_like(x) if want_prob else None
+    _check(lib().scda_sigmoid_bce_rows_fwd_hip(_p(x), _p(t), i32(t_rows), _p(w), i32(C), i32(n), f32(scale), i32(int(acc)), _p(prob),
+                                               _p(out), _stream()), "scda_sigmoid_bce_rows_fwd_hip")
+    return out, prob
+
+
+def sigmoid_bce_rows_bwd(prob, t, w, scale, g):
+    C, n = prob.shape
+    dx = torch.empty_like(prob)
+    _check(lib().scda_sigmoid_bce_rows_bwd_hip(_p(prob), _p(t), i32(t.numel() // n), _p(w), i32(C), i32(n), f32(scale), _p(g), _p(dx),
+                                               _stream()), "scda_sigmoid_bce_rows_bwd_hip")
+    return dx
 
 
 def bias_grad_nchw(dy, out=None):

@@ -222,27 +222,24 @@ class ScdaTrainer:
         src_patch, tgt_patch = outputs['cluster_features']          # [C, threshold, 4096] leaves
         src_recon, tgt_recon = self.dec(src_patch, tgt_patch)        # [C, 3, recon, recon]
 
-        bce, sig = A.binary_cross_entropy, A.sigmoid
+        bce, adv = A.binary_cross_entropy, A.adversarial_loss
         mark('crops+dec_fwd_enqueued')
 
+        # The adversarial terms below are the reference's sums over clusters of F.binary_cross_entropy(torch.sigmoid(d)[c], label)
+        # (one mean per cluster row), each group evaluated by ONE fused kernel (A.adversarial_loss) on the logits.
         # ---------------- (1) image discriminators ----------------
         self.opt['dis'].zero_grad()
         d_src_fake, d_tgt_fake = self.dis(src_recon.detach(), tgt_recon.detach())
         d_src_real, d_tgt_real = self.dis(x_small, t_small)
-        p_src_fake, p_tgt_fake, p_src_real, p_tgt_real = sig(d_src_fake), sig(d_tgt_fake), sig(d_src_real), sig(d_tgt_real)
-        row = (1, p_src_real.shape[1])
+        row = (1, d_src_real.shape[1])
         score1 = _soft(1, row, dev)
         score0 = _soft(0, row, dev)
-        ad_src = 0.0
-        for c in range(C):
-            ad_src = ad_src + (bce(p_src_fake[c:c + 1], score1) + bce(p_src_real[c:c + 1], score0))
         tgt_pro = self.dis_patch(tgt_patch)                          # [C, 512] in (0,1); also updates BN statistics
         w_tgt = N.row_mean(tgt_pro.detach().contiguous())            # per-cluster weight (its gradient is dead here)
         src_pro = self.dis_patch(src_patch)
-        ad_tgt = 0.0
-        for c in range(C):
-            ad_tgt = ad_tgt + (w_tgt[c] * bce(p_tgt_fake[c:c + 1], score0) + bce(p_tgt_real[c:c + 1], score1))
-        adloss = (ad_src + ad_tgt) / ws
+        adloss = adv([(d_src_fake, score1, None), (d_src_real, score0, None),          # ad_src  (:584-588)
+                      (d_tgt_fake, score0, w_tgt), (d_tgt_real, score1, None)],         # ad_tgt  (:596-600)
+                     scale=1.0 / ws)
         adloss.backward()
         w1 = self._reduce(self.dis, async_op=True)
         mark('phase1')
@@ -268,22 +265,15 @@ class ScdaTrainer:
         self.opt['dec'].zero_grad()
         with _Frozen(self.dis):
             d_src_fake, d_tgt_fake = self.dis(src_recon, tgt_recon)   # gradient flows to the decoders only
-            p_src_fake = sig(d_src_fake)
             with torch.no_grad():
                 d_src_real, d_tgt_real = self.dis(x_small, t_small)
-                p_src_real, p_tgt_real = sig(d_src_real), sig(d_tgt_real)
                 w_tgt2 = N.row_mean(self.dis_patch(tgt_patch).contiguous())
-            p_tgt_fake = sig(d_tgt_fake)
             one_t = _hard(1, row, dev)
             zero_t = _hard(0, row, dev)
-            fake1_tgt = 0.0
-            for c in range(C):
-                fake1_tgt = fake1_tgt + w_tgt2[c] * (bce(p_tgt_fake[c:c + 1], one_t) + bce(p_tgt_real[c:c + 1], zero_t))
+            fake1_tgt = adv([(d_tgt_fake, one_t, w_tgt2), (d_tgt_real, zero_t, w_tgt2)])       # :675-681
             one_s = _hard(1, row, dev)
             zero_s = _hard(0, row, dev)
-            fake1_src = 0.0
-            for c in range(C):
-                fake1_src = fake1_src + (bce(p_src_fake[c:c + 1], one_s) + bce(p_src_real[c:c + 1], zero_s))
+            fake1_src = adv([(d_src_fake, one_s, None), (d_src_real, zero_s, None)])           # :683-687
             recon_loss = (fake1_src + fake1_tgt) / ws
             recon_loss.backward()
         w3 = self._reduce(self.dec, async_op=True)
@@ -306,14 +296,10 @@ class ScdaTrainer:
         with torch.no_grad():
             swap_src, swap_tgt = self.dec(tgt_patch, src_patch)
             q_src, q_tgt = self.dis(swap_src, swap_tgt)
-            q_tgt_p = sig(q_tgt)
-            ones_all = _hard(1, q_tgt_p.shape, dev)
-            fake_loss_source = bce(q_tgt_p, ones_all)
-            q_src_p = sig(q_src)
+            ones_all = _hard(1, q_tgt.shape, dev)
+            fake_loss_source = adv([(q_tgt, ones_all, None)], scale=1.0 / q_tgt.shape[0])      # mean over all elements (:723)
             ones_row = torch.ones(row, dtype=torch.float32, device=dev)
-            fake_loss_target = 0.0
-            for c in range(C):
-                fake_loss_target = fake_loss_target + w_tgt2[c] * bce(q_src_p[c:c + 1], ones_row)
+            fake_loss_target = adv([(q_src, ones_row, w_tgt2)])                                 # :725-732
         loss = det_loss + 0.1 * (fake_loss_source + fake_loss_target) / ws
         if w4 is not None:
             w4.wait()

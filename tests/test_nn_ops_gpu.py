@@ -270,3 +270,83 @@ def test_decoder_32_forward_backward(cuda):
     (ya.mean() + yb.mean()).backward()
     g = m.decode_A[0].model[0].weight.grad
     assert g is not None and torch.isfinite(g).all() and float(g.abs().max()) > 0
+
+
+def test_adversarial_loss_matches_per_cluster_bce(cuda):
+    """A.adversarial_loss == the reference's sum over clusters of F.binary_cross_entropy(torch.sigmoid(d)[c], label) terms
+    (tools/faster_rcnn_train_val.py:584-600), forward and gradient, incl. row weights, full-size labels and a saturated logit"""
+    from scda_amd import autograd_ops as A
+    C, n = 4, 1024
+    d1 = torch.randn(C, n, generator=gen(51)) * 2; d2 = torch.randn(C, n, generator=gen(52)) * 2
+    d1[0, 0] = 40.0; d1[1, 1] = -40.0                    # sigmoid saturates: the -100 log clamp / 1e-12 clamp paths
+    t1 = torch.rand(1, n, generator=gen(53)) * 0.2 + 0.8; t0 = torch.rand(1, n, generator=gen(54)) * 0.3
+    tf = torch.rand(C, n, generator=gen(55))
+    w = torch.rand(C, generator=gen(56))
+    r1, r2 = d1.clone().requires_grad_(), d2.clone().requires_grad_()
+    p1, p2 = torch.sigmoid(r1), torch.sigmoid(r2)
+    ref = 0.0
+    for c in range(C):
+        ref = ref + (F.binary_cross_entropy(p1[c:c + 1], t1) + w[c] * F.binary_cross_entropy(p2[c:c + 1], t0))
+    ref = (ref + F.binary_cross_entropy(p1, tf)) * 0.5
+    ref.backward()
+    g1, g2 = d1.to(cuda).requires_grad_(), d2.to(cuda).requires_grad_()
+    out = A.adversarial_loss([(g1, t1.to(cuda), None), (g2, t0.to(cuda), w.to(cuda))], scale=0.5) + \
+        A.adversarial_loss([(g1, tf.to(cuda), None)], scale=0.5 / C)
+    out.backward()
+    assert abs(float(out) - float(ref)) <= 2e-6 * abs(float(ref))
+    close(g1.grad, r1.grad, 2e-6); close(g2.grad, r2.grad, 2e-6)
+
+
+def test_seeded_dropout_equals_mask_path(cuda):
+    """DropoutSeededFn (keep decisions recomputed from the seed in both passes) == dropout_mask + dropout_apply with that seed;
+    with relu_input the backward additionally applies x > 0"""
+    from scda_amd import autograd_ops as A, native as N
+    x = torch.randn(512, 300, generator=gen(61)).to(cuda)
+    dy = torch.randn(512, 300, generator=gen(62)).to(cuda)
+    seed, p = 0x1234ABCD5678, 0.5
+    mask = N.dropout_mask(tuple(x.shape), p, seed, cuda)
+    for relu_input in (False, True):
+        xa = (x.relu() if relu_input else x).clone().requires_grad_()
+        ya = A.DropoutSeededFn.apply(xa, p, seed, relu_input); ya.backward(dy)
+        assert torch.equal(ya, N.dropout_apply(xa.detach(), mask, 2.0))
+        want = N.dropout_apply(dy, mask, 2.0)
+        if relu_input:
+            want = want * (xa.detach() > 0)
+        assert torch.equal(xa.grad, want)
+    assert 0.45 < float(mask.float().mean()) < 0.55
+
+
+def test_act_fusion_plan_gives_identical_gradients(cuda):
+    """layers.plan_act_fusion moves each fused ReLU / LeakyReLU gradient into its consumer (next conv's data gradient, pool
+    backward, dropout backward): parameter and input gradients must be BIT-identical to the un-fused backward"""
+    from scda_amd import layers as L
+    from scda_amd.autograd_ops import ACT_LEAKY, ACT_RELU
+
+    def conv_chain():
+        return torch.nn.Sequential(
+            L.Conv2d(3, 16, 3, padding=1, fused_act=ACT_RELU), L.FusedAct(), L.Conv2d(16, 32, 3, padding=1, fused_act=ACT_RELU), L.FusedAct(),
+            L.MaxPool2x2(), L.Conv2d(32, 32, 3, stride=2, padding=1, fused_act=ACT_LEAKY), L.FusedAct("LeakyReLU"),
+            L.Conv2d(32, 48, 3, padding=1, fused_act=ACT_LEAKY), L.FusedAct("LeakyReLU"), L.Conv2d(48, 1, 1))
+
+    def fc_chain():
+        return torch.nn.Sequential(L.Linear(64, 96, fused_act=ACT_RELU), L.FusedAct(), L.Dropout(),
+                                   L.Linear(96, 80, fused_act=ACT_RELU), L.FusedAct(), L.Dropout(), L.Linear(80, 7))
+
+    for make, shape in ((conv_chain, (2, 3, 24, 40)), (fc_chain, (33, 64))):
+        torch.manual_seed(7)
+        plain = make().to(cuda)
+        fused = make().to(cuda)
+        fused.load_state_dict(plain.state_dict())
+        n = L.plan_act_fusion(fused)
+        assert n == (4 if make is conv_chain else 2)
+        x = torch.randn(*shape, generator=gen(70)).to(cuda)
+        outs = []
+        for net in (plain, fused):
+            torch.manual_seed(11)                         # same dropout seeds
+            xi = x.clone().requires_grad_()
+            y = net(xi)
+            y.square().sum().backward()
+            outs.append((y.detach(), xi.grad, [p.grad.clone() for p in net.parameters()]))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        for a, b in zip(outs[0][2], outs[1][2]):
+            assert torch.equal(a, b)
