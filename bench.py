@@ -5,13 +5,20 @@
   python bench.py --gpus N --steps K --warmup W
   (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`, one rank per GPU)
 
-One "step" = one iteration = 1 source + 1 target 512x1024 image per GPU; images/s = 2 * N * steps / time.
+One "step" = one iteration = 1 source + 1 target 512x1024 image per GPU; images/s = 2 * N * steps / time (as in the
+reference, the source image goes forward AND backward, the target image forward only -- it has no loss; `config.iters_per_s`
+is the iteration rate for comparisons with iteration-based numbers).
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline      dominant kernel (fp32-MFMA implicit-GEMM conv forward with direct-to-LDS staging, 3x3 stride 1, 128- or 256-row tiles): algorithmic FLOPs of its
                 launches inside the timed region / their summed duration (HIP events recorded on the launch stream by the
                 library's profiler), against the 157.3 TFLOP/s fp32-MFMA peak
+                `roofline.iteration` = the whole iteration against the same peak: F_iter (2.255 TFLOP of necessary conv / FC
+                work per iteration, SURVEY.md 8d / BASELINE.md 2) x iterations/s
   cpu_baseline  the CPU oracle of the same iteration (oracle/torch_ref.py, a faithful PyTorch-CPU restatement of the
-                reference's train() body, pinned against the reference) timed on this box's host cores: rank 0, N=1 only
+                reference's train() body, pinned against the reference) timed on this box's host cores: rank 0, N=1 only;
+                1 warm-up + 3 timed iterations
+Before timing, the detector is pre-conditioned: warm-up iterations continue (up to 40) until the RPN yields the
+full post-NMS quota on both images, so that NMS / RoI sampling see realistic proposal sets; the counts are in the JSON.
 """
 import argparse
 import json
@@ -45,7 +52,9 @@ for _k in CFG:
 
 H, W, G = 512, 1024, 12
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
-DOMINANT = "conv_igemm_glds_kernel<128+,*,3,3,1,0>"   # tile rows 128 or 256 (8 waves), any tile width
+F_ITER_TFLOP = 2.255          # necessary conv / FC / convT work of one iteration
+PMC_TRAFFIC_FILES = ("r02_pmc_traffic.json", "r01_pmc_traffic.json")
+DOMINANT = "conv_igemm_glds_kernel<128|256,*,3,3,1,fwd>"   # the instantiations with 128 or 256 tile rows (256 = 8 waves), any tile width, 3x3 stride 1, forward
 
 
 def synth_batch(rank):
@@ -66,13 +75,14 @@ def pmc_traffic():
     run; they come from the committed rocprofv3 passes of this same command (scripts/collect_profiles.sh ->
     profiles/r01_pmc_traffic.json: `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` in separate passes, FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for gfx950).  None when that file is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            d = json.load(f)
-        return int(d["dominant"]["traffic_bytes_per_launch"]), "profiles/r01_pmc_traffic.json"
-    except Exception:
-        return None, None
+    for name in PMC_TRAFFIC_FILES:     # newest committed counter pass first
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                d = json.load(f)
+            return int(d["dominant"]["traffic_bytes_per_launch"]), "profiles/" + name
+        except Exception:
+            continue
+    return None, None
 
 
 def cpu_baseline():
@@ -95,14 +105,18 @@ def cpu_baseline():
         models = R.build_models(CFG)
         tr = R.RefTrainer(CFG, models, lr=1.25e-5, new_w=W, new_h=H)
         src, tgt, gts, info = synth_batch(0)
-        t0 = time.time()
-        tr.step(src, gts, info, tgt)
-        dt = time.time() - t0
+        tr.step(src, gts, info, tgt)            # warm-up (allocator, oneDNN primitive caches)
+        times = []
+        for _ in range(3):
+            t0 = time.time()
+            tr.step(src, gts, info, tgt)
+            times.append(time.time() - t0)
+        dt = sum(times) / len(times)
     finally:
         R.reset_backend()
     return {"value": round(2.0 / dt, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "1 full iteration (1 source + 1 target 512x1024 image, all 4 phases incl. Adam) of oracle/torch_ref.py "
-                      "RefTrainer, %.1f s, no warm-up" % dt,
+            "sample": "3 timed full iterations after 1 warm-up (each: 1 source + 1 target 512x1024 image, all 4 phases incl. "
+                      "Adam) of oracle/torch_ref.py RefTrainer: %s s" % ", ".join("%.2f" % t for t in times),
             "s_per_iter": round(dt, 3)}
 
 
@@ -147,8 +161,13 @@ def main():
     src, tgt, gts, info = synth_batch(rank)
     src, tgt = src.to(dev), tgt.to(dev)
 
+    quota = CFG["train_rpn_proposal_cfg"]["post_nms_top_n"]
+    precond = 0
     for _ in range(a.warmup):
         tr.step(src, gts, info, tgt)
+    while min(tr.last_num_proposals) < quota and precond < 40:   # realistic proposal sets before timing
+        tr.step(src, gts, info, tgt)
+        precond += 1
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -177,11 +196,15 @@ def main():
             n, tms, fl, by = prof[DOMINANT]
             ach = fl / (tms * 1e-3) / 1e12
             traffic, src = pmc_traffic()
+            it_ach = F_ITER_TFLOP * world * a.steps / dt
             roof = {"bound": "mfma", "kernel": DOMINANT, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                     "traffic_unit": "bytes/launch (HBM+Infinity-Cache side of L2: 2*FETCH_SIZE + WRITE_SIZE)", "traffic_source": src,
                     "algorithmic_bytes_per_launch": round(by / n), "launches": n, "avg_launch_ms": round(tms / n, 4),
-                    "gflop_per_launch": round(fl / n / 1e9, 2)}
+                    "gflop_per_launch": round(fl / n / 1e9, 2),
+                    "iteration": {"achieved": round(it_ach / world, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s per GPU",
+                                  "frac": round(it_ach / world / PEAK_F32_MFMA_TFLOPS, 4),
+                                  "definition": "F_iter (%.3f TFLOP of necessary conv/FC work per iteration) x iterations/s" % F_ITER_TFLOP}}
         res = {
             "metric": "images/sec (fwd+bwd) VGG16 Faster-RCNN+SCDA 512x1024", "value": round(value, 3), "unit": "images/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
@@ -189,7 +212,10 @@ def main():
             "config": {"workload": "vgg16_FasterRCNN + 4-cluster SCDA, synthetic Cityscapes->Foggy 512x1024, batch=1/GPU "
                                    "(BASELINE.json configs[1]); 1 step = 1 source + 1 target image, 4 optimiser phases",
                        "image": [H, W], "gt_boxes": G, "rois": 512, "clusters": 4, "recon": 256, "parallelism": "dp%d" % world,
-                       "iters_per_s": round(world * a.steps / dt, 3), "final_loss": round(float(out["loss"]), 4)},
+                       "iters_per_s": round(world * a.steps / dt, 3), "final_loss": round(float(out["loss"]), 4),
+                       "images_per_step": "1 source (forward + backward) + 1 target (forward only: it carries no loss), per GPU",
+                       "proposals_post_nms": {"source": tr.last_num_proposals[0], "target": tr.last_num_proposals[1], "quota": quota},
+                       "preconditioning_iterations": a.warmup + precond},
             "roofline": roof,
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -46,7 +46,7 @@ const float *zero_page();
 // When enabled, a hipEvent pair is recorded on the launch stream around the tagged kernel;
 // scda_prof_collect() (after a device sync) turns them into per-kernel count / time / flops.
 // kernel classes mirror the template instantiations rocprofv3 lists:
-//   conv_igemm_glds_kernel<BM,BN,KH,KW,S,DGRAD> (tile chosen per shape; '128+' = 128- and 256-row tiles): id = ((DGRAD*2 + (BM==64)) * 3 + shape), shape 0: 3x3 s1, 1: 3x3 s2, 2: 1x1
+//   conv_igemm_glds_kernel<BM,BN,KH,KW,S,DGRAD> (classes follow the INSTANTIATION that ran: tile rows 64, or 128|256): id = ((DGRAD*2 + (BM==64)) * 3 + shape), shape 0: 3x3 s1, 1: 3x3 s2, 2: 1x1
 //   conv_wgrad_kernel<*,*,KH,KW,S>:          id = 12 + shape ;   gemm_kernel<*>: id = 15
 //   conv_igemm_kernel<*> (the gather kernel of the layers whose channel count is not a multiple of 16): id = 16
 enum { PK_CONV = 0, PK_CONV_WGRAD = 12, PK_GEMM = 15, PK_CONV_GATHER = 16, PK_COUNT = 17 };

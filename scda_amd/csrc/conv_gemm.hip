@@ -1150,6 +1150,9 @@ static LaunchPlan plan_launch(int M, int N, int K, int bm, bool allow64, bool al
     for (const Entry &e : cache)
         if (e.k.M == key.M && e.k.N == key.N && e.k.K == key.K && e.k.flags == key.flags && e.k.ws == key.ws) return e.p;
     const LaunchPlan p = plan_search(M, N, K, bm, allow64, allow128, must_split, ws_bytes, k_granule, allow256, allow_bm256);
+    if (getenv("SCDA_PLAN_LOG"))
+        fprintf(stderr, "[scda plan] M=%d N=%d K=%d %s-> tile %dx%d splits %d (%lld workgroups)\n", M, N, K, must_split ? "wgrad " : "",
+                p.bm, p.bn, p.splits, (long long)cdiv(M, p.bm) * cdiv(N, p.bn) * p.splits);
     if (cache.size() < 512) cache.push_back(Entry{key, p});
     return p;
 }
@@ -1216,7 +1219,7 @@ static int launch_conv(const float *Wm, const float *X, const ConvGeom &g0, Epi 
     g.nx = cdiv(g.N, BNv); g.ny = cdiv(g.M, BMt); g.swz = xcd_swizzle_enabled();
     dim3 grid((unsigned)g.nx * g.ny * splits);
     note_plan(BMt, BNv, splits, g.slab_aligned);
-    prof_begin(g.slab_aligned ? PK_CONV + ((DGRAD ? 2 : 0) + (small_m ? 1 : 0)) * 3 + prof_shape(KH, S) : (int)PK_CONV_GATHER,
+    prof_begin(g.slab_aligned ? PK_CONV + ((DGRAD ? 2 : 0) + (BMt == 64 ? 1 : 0)) * 3 + prof_shape(KH, S) : (int)PK_CONV_GATHER,
                2.0 * g.M * (double)g.N * g.K, st,
                4.0 * ((double)g.batch * g.CB * g.HB * g.WB + (double)g.M * g.K + (double)g.M * g.N));
     g.mpad = conv_packed_mpad(g.M);

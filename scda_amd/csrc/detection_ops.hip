@@ -670,10 +670,10 @@ SCDA_API void scda_prof_enable(unsigned kernel_mask) { g_prof_mask = kernel_mask
 SCDA_API int scda_prof_num_kernels(void) { return PK_COUNT; }
 SCDA_API const char *scda_prof_kernel_name(int k) {
     static const char *names[PK_COUNT] = {
-        "conv_igemm_glds_kernel<128+,*,3,3,1,0>", "conv_igemm_glds_kernel<128+,*,3,3,2,0>", "conv_igemm_glds_kernel<128+,*,1,1,1,0>",
-        "conv_igemm_glds_kernel<64,*,3,3,1,0>", "conv_igemm_glds_kernel<64,*,3,3,2,0>", "conv_igemm_glds_kernel<64,*,1,1,1,0>",
-        "conv_igemm_glds_kernel<128+,*,3,3,1,1>", "conv_igemm_glds_kernel<128+,*,3,3,2,1>", "conv_igemm_glds_kernel<128+,*,1,1,1,1>",
-        "conv_igemm_glds_kernel<64,*,3,3,1,1>", "conv_igemm_glds_kernel<64,*,3,3,2,1>", "conv_igemm_glds_kernel<64,*,1,1,1,1>",
+        "conv_igemm_glds_kernel<128|256,*,3,3,1,fwd>", "conv_igemm_glds_kernel<128|256,*,3,3,2,fwd>", "conv_igemm_glds_kernel<128|256,*,1,1,1,fwd>",
+        "conv_igemm_glds_kernel<64,*,3,3,1,fwd>", "conv_igemm_glds_kernel<64,*,3,3,2,fwd>", "conv_igemm_glds_kernel<64,*,1,1,1,fwd>",
+        "conv_igemm_glds_kernel<128|256,*,3,3,1,dgrad>", "conv_igemm_glds_kernel<128|256,*,3,3,2,dgrad>", "conv_igemm_glds_kernel<128|256,*,1,1,1,dgrad>",
+        "conv_igemm_glds_kernel<64,*,3,3,1,dgrad>", "conv_igemm_glds_kernel<64,*,3,3,2,dgrad>", "conv_igemm_glds_kernel<64,*,1,1,1,dgrad>",
         "conv_wgrad_glds_kernel<*,*,3,3,1>", "conv_wgrad_glds_kernel<*,*,3,3,2>", "conv_wgrad_glds_kernel<*,*,1,1,1>", "gemm_glds_kernel<*>", "conv_igemm_kernel<*>"};
     return (k >= 0 && k < PK_COUNT) ? names[k] : "";
 }

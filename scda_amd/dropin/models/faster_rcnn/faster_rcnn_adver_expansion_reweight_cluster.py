@@ -179,6 +179,7 @@ class FasterRCNN_AdEx(nn.Module):
         def target_branch():
             with torch.no_grad():
                 proposals_t = fn['rpn_proposal_fn'](*tgt_host.get())
+                outputs['num_proposals_target'] = int(proposals_t.shape[0])
                 rois_t_host = proposals_t[0:512, :5].contiguous()
                 rois_t = N.upload(rois_t_host, dev)
                 rois_t._scda_host = rois_t_host.numpy()
@@ -202,6 +203,7 @@ class FasterRCNN_AdEx(nn.Module):
         outputs['losses'] = losses
         outputs['accuracy'] = [rpn_acc, rcnn_acc]
         outputs['predict'] = [proposals]
+        outputs['num_proposals'] = (int(proposals.shape[0]), outputs.pop('num_proposals_target', 0))   # post-NMS, source / target
         if x_fea_t.size(0) != 512:  # target image produced too few proposals: fall back to the source clusters
             logger.info("Different channels {} at target image".format(x_fea_t.size(0)))
             outputs['cluster_features'] = [clu_fea, clu_fea]

@@ -307,6 +307,7 @@ class ScdaTrainer:
         self.opt['det'].step()
         mark('phase4+det_step')
 
+        self.last_num_proposals = outputs.get('num_proposals')     # post-NMS proposal counts (source, target) of this iteration
         return {'loss': loss.detach() * ws, 'rpn_cls': rpn_cls.detach(), 'rpn_loc': rpn_loc.detach(),
                 'rcnn_cls': rcnn_cls.detach(), 'rcnn_loc': rcnn_loc.detach(), 'rpn_acc': outputs['accuracy'][0],
                 'rcnn_acc': outputs['accuracy'][1], 'fake_loss_target': fake_loss_target, 'fake_loss_source': fake_loss_source,

@@ -53,13 +53,13 @@ def main(d, out_md, out_json, algo_json=None):
                           ("dropout_apply_kernel", "reads 4 B + 1 B mask, writes 4 B -> read/write = 1.25")):
             if k in cal and cal[k][3] > 0:
                 f.write("* `%s`: %s; measured (2 x FETCH)/WRITE = %.3f\n" % (k, expect, cal[k][2] / cal[k][3]))
-        f.write("\nDominant kernel class `conv_igemm_glds_kernel<128+,*,3,3,1,0>` (%d launches): read %.1f MB + write %.1f MB = %.1f MB per launch\n\n"
+        f.write("\nDominant kernel class `conv_igemm_glds_kernel<128|256,*,3,3,1,fwd>` (%d launches): read %.1f MB + write %.1f MB = %.1f MB per launch\n\n"
                 % (n, dom_fetch / 1e6, dom_write / 1e6, (dom_fetch + dom_write) / 1e6))
         f.write("| kernel | launches | read MB/launch | write MB/launch |\n|---|---:|---:|---:|\n")
         for r in rows[:45]:
             f.write("| `%s` | %d | %.2f | %.2f |\n" % (r[0][:110], r[1], r[2] / 1e6, r[3] / 1e6))
     with open(out_json, "w") as f:
-        json.dump({"dominant": {"kernel": "conv_igemm_glds_kernel<128+,*,3,3,1,0>", "launches": n,
+        json.dump({"dominant": {"kernel": "conv_igemm_glds_kernel<128|256,*,3,3,1,fwd>", "launches": n,
                                 "read_bytes_per_launch": round(dom_fetch), "write_bytes_per_launch": round(dom_write),
                                 "traffic_bytes_per_launch": round(dom_fetch + dom_write)},
                    "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; read = 2*FETCH_SIZE KB*1024, write = WRITE_SIZE KB*1024"},
