@@ -68,6 +68,10 @@ void scda_debug_last_plan(int *out4);
 size_t scda_nms_workspace_bytes(int n);
 int scda_nms_hip(const float *boxes, int n, float thresh, void *mask_ws, int64_t *keep, int64_t *num_out,
                  int max_keep, void *stream);
+/* the same with per-box validity flags (uint8 [n], may be NULL): boxes flagged 0 are treated as absent -- never kept, never
+ * suppressing -- and `keep` indexes the ORIGINAL list: the min-size filter of functions/rpn_proposal.py:57-59 without compaction */
+int scda_nms_valid_hip(const float *boxes, const unsigned char *valid, int n, float thresh, void *mask_ws, int64_t *keep,
+                       int64_t *num_out, int max_keep, void *stream);
 /* the pairwise suppression bit-mask alone (upper triangle of col-blocks only):
  * mask uint64 [n, ceil(n/64)]                                                */
 int scda_nms_mask_hip(const float *boxes, int n, float thresh, uint64_t *mask, void *stream);
@@ -121,6 +125,32 @@ int scda_iou_overlaps_hip(const float *b1, const float *b2, int size_bbox, int n
 /* replaces  cython_bbox.bbox_overlaps(boxes f32[N,4], query f32[K,4]) -> f32[N,K]
  *           extensions/_cython_bbox/cython_bbox.pyx:32-73   (no +1, 0 unless iw>0 and ih>0) */
 int scda_bbox_overlaps_hip(const float *boxes, int N, const float *query, int K, float *out, void *stream);
+
+/* ------------------------------------------ box logic on the device ---- */
+/* What the reference computes in numpy on the host between the RPN and the RCNN head.  The host keeps
+ * the two jobs whose results are observable behaviour of the reference: drawing from numpy's global RNG (it gets two counts
+ * back) and ranking scores with numpy's argpartition / argsort.
+ *
+ * functions/anchor_target.py:38-64 -- labels of one image before sub-sampling (-1 ignore, 0 bg, 1 fg), ascending index lists
+ * of the positives / negatives, counts = {#pos, #neg}.  anchors [KA,4] fp32, gts [G,gt_stride>=4] fp32; all buffers are the
+ * caller's (best_iou f32 [KA], best_gt i32 [KA], gt_best u32 [G], labels i8 [KA], pos_list / neg_list i32 [KA], counts i32 [2]) */
+int scda_anchor_label_hip(const float *anchors, int KA, const float *gts, int G, int gt_stride, float neg_thresh, float pos_thresh,
+                          float min_gt_best, float *best_iou, int *best_gt, unsigned *gt_best, signed char *labels, int *pos_list,
+                          int *neg_list, int *counts, void *stream);
+/* :66-107 -- drop the surplus the host drew (drop_* index INTO pos_list / neg_list, as np.random.choice returns them) and emit
+ * cls_targets int64 [A,fh,fw], loc_targets / loc_masks fp32 [4A,fh,fw]; anchors64 = the float64 anchor grid [KA,4] */
+int scda_anchor_finalize_hip(signed char *labels, const int *best_gt, const int *pos_list, const int *drop_pos, int n_drop_pos,
+                             const int *neg_list, const int *drop_neg, int n_drop_neg, const double *anchors64, const float *gts,
+                             int gt_stride, int A, int fh, int fw, long long *cls_targets, float *loc_targets, float *loc_masks,
+                             void *stream);
+/* functions/rpn_proposal.py:36-60 for the n candidates the host ranked (order i32 [n], anchor indices): decode + clip in float64,
+ * props5 fp32 [n,5] = (x1,y1,x2,y2,score), ok u8 [n] = the roi_min_size test.  loc [4A,fh,fw] / prob [2A,fh,fw] are the RPN's
+ * NCHW outputs of that image.  Then scda_nms_valid_hip(props5, ok, ...) and scda_proposal_gather_hip. */
+int scda_proposal_decode_hip(const int *order, int n, const double *anchors64, const float *loc, const float *prob, int A, int fh,
+                             int fw, double img_h, double img_w, double min_size, float *props5, unsigned char *ok, void *stream);
+/* out6 [max_rows,6] rows i < min(max_rows, *num_keep) = (image_index, props5[keep[i]]) */
+int scda_proposal_gather_hip(const float *props5, const long long *keep, const long long *num_keep, float image_index, int max_rows,
+                             float *out6, void *stream);
 
 /* ------------------------------------------------- convolution / GEMM ---- */
 /* The reference reaches these through torch.nn (cuDNN / cuBLAS): nn.Conv2d in

@@ -115,15 +115,26 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const int n, const float t
 // Per chunk, wave 0 resolves the 64 in-chunk decisions from the diagonal word
 // (a scalar recurrence over v_readlane, one step per kept box), then all waves OR the kept
 // boxes' mask rows into the LDS-resident "removed" bit vector.
+// valid (may be null): boxes with valid[i] == 0 start out removed -- they are never kept and, never being kept, never suppress
+// anything: the result equals the sweep over the list with those boxes deleted, with indices into the ORIGINAL list (the
+// min-size filter of functions/rpn_proposal.py:57-59 without a compaction pass or a host round trip for the new length)
 __global__ __launch_bounds__(1024) void nms_sweep_kernel(const uint64_t *__restrict__ mask, const int n,
                                                         const int col_blocks, int64_t *__restrict__ keep,
-                                                        int64_t *__restrict__ num_out, const int max_keep) {
+                                                        int64_t *__restrict__ num_out, const int max_keep,
+                                                        const unsigned char *__restrict__ valid) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint64_t *remv = reinterpret_cast<uint64_t *>(smem_raw);  // [col_blocks]
     uint64_t *bcast = remv + col_blocks;                       // [2]: kept mask, stop flag
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    for (int i = tid; i < col_blocks; i += 1024) remv[i] = 0;
+    for (int i = tid; i < col_blocks; i += 1024) {
+        uint64_t w = 0;
+        if (valid) {
+            const int lim = min(64, n - i * 64);
+            for (int j = 0; j < lim; ++j) w |= (uint64_t)(valid[i * 64 + j] == 0) << j;
+        }
+        remv[i] = w;
+    }
     if (tid == 0) { bcast[0] = 0; bcast[1] = 0; }
     __syncthreads();
 
@@ -709,6 +720,11 @@ SCDA_API int scda_nms_mask_hip(const float *boxes, int n, float thresh, uint64_t
 
 SCDA_API int scda_nms_hip(const float *boxes, int n, float thresh, void *mask_ws, int64_t *keep, int64_t *num_out,
                           int max_keep, void *stream) {
+    return scda_nms_valid_hip(boxes, nullptr, n, thresh, mask_ws, keep, num_out, max_keep, stream);
+}
+
+SCDA_API int scda_nms_valid_hip(const float *boxes, const unsigned char *valid, int n, float thresh, void *mask_ws, int64_t *keep,
+                                int64_t *num_out, int max_keep, void *stream) {
     if (n < 0 || !num_out || (n > 0 && (!boxes || !mask_ws || !keep))) {
         set_error("scda_nms_hip: bad arguments");
         return SCDA_EINVAL;
@@ -723,7 +739,7 @@ SCDA_API int scda_nms_hip(const float *boxes, int n, float thresh, void *mask_ws
     const size_t lds = (size_t)(cb + 2) * sizeof(uint64_t);
     if (lds > 64 * 1024) { set_error("scda_nms_hip: n=%d too large for the LDS-resident sweep", n); return SCDA_EINVAL; }
     hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(1024), lds, as_stream(stream), (const uint64_t *)mask_ws, n, cb,
-                       keep, num_out, max_keep);
+                       keep, num_out, max_keep, valid);
     return launch_status("nms_sweep_kernel");
 }
 

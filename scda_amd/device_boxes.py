@@ -1,0 +1,148 @@
+"""Device-resident box logic of the detector: anchor labelling and RPN proposal generation on the
+MI355X (scda_amd/csrc/box_ops.hip), replacing the numpy passes of functions/anchor_target.py:38-107 and
+functions/rpn_proposal.py:36-66 for batch-1 device inputs.
+
+What stays on the host, because it IS the reference's observable behaviour:
+  * random draws from numpy's global generator (np.random.choice for the surplus positives / negatives): the device sends
+    back two counts, the host draws exactly what the reference would and uploads the indices to drop;
+  * the ranking of RPN scores (np.argpartition + np.argsort -- the order of tied scores is numpy's): the host receives the
+    objectness map only (not the deltas), ranks, and uploads the candidate order.
+What no longer crosses PCIe: the 30720 x G IoU matrix, the 30720 x 9 target maps, the RPN deltas, the 12000 candidate boxes.
+All kernels here run on the box logic's high-priority side stream (their inputs do not depend on the compute stream's
+backlog), so the host's waits stay short.
+
+`enabled()` is the switch (SCDA_DEVICE_BOXES=0 restores the numpy passes, e.g. for an A/B of host CPU time)."""
+import os
+
+import numpy as np
+import torch
+
+from scda_amd import native as N
+from scda_amd.dropin import backend
+from scda_amd.dropin.utils import anchor_helper
+
+_ANCHORS = {}
+_BUFS = {}
+
+
+def enabled():
+    return os.environ.get("SCDA_DEVICE_BOXES", "1") != "0" and torch.cuda.is_available()
+
+
+def anchors_on_device(fh, fw, cfg, dev):
+    key = (fh, fw, tuple(cfg['anchor_scales']), cfg['anchor_stride'], dev.index)
+    hit = _ANCHORS.get(key)
+    if hit is None:
+        a = anchor_helper.get_anchors_over_plane(fh, fw, cfg['anchor_ratios'], cfg['anchor_scales'], cfg['anchor_stride'])
+        a64 = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        a32 = torch.from_numpy(a.astype(np.float32)).to(dev)      # the cast the reference applies before the IoU (bbox_helper.py:9)
+        hit = _ANCHORS[key] = (a32, a64)
+    return hit
+
+
+def _bufs(KA, G, dev):
+    key = (KA, dev.index)
+    b = _BUFS.get(key)
+    if b is None or b["gt_best"].numel() < G:
+        i32 = dict(dtype=torch.int32, device=dev)
+        b = _BUFS[key] = {"best_iou": torch.empty(KA, dtype=torch.float32, device=dev), "best_gt": torch.empty(KA, **i32),
+                          "gt_best": torch.empty(max(G, 64), **i32), "labels": torch.empty(KA, dtype=torch.int8, device=dev),
+                          "pos_list": torch.empty(KA, **i32), "neg_list": torch.empty(KA, **i32), "counts": torch.zeros(2, **i32),
+                          "counts_host": torch.zeros(2, dtype=torch.int32, pin_memory=True)}
+    return b
+
+
+def _pinned_i32(a):
+    t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32))
+    p = torch.empty(t.shape, dtype=torch.int32, pin_memory=True)
+    p.copy_(t)
+    return p
+
+
+def anchor_targets(feature_size, cfg, gts_dev):
+    """functions/anchor_target.py:16-116 for ONE image whose ground truth lives on the device.
+    -> cls_targets int64 [1,A,fh,fw], loc_targets, loc_masks fp32 [1,4A,fh,fw], normaliser (int)"""
+    B, A4, fh, fw = feature_size
+    A = A4 // 4
+    assert B == 1 and A * 4 == A4
+    dev = gts_dev.device
+    a32, a64 = anchors_on_device(fh, fw, cfg, dev)
+    KA = a32.shape[0]
+    main = torch.cuda.current_stream(dev)
+    aux = backend._aux_stream(dev)
+    host_gts = getattr(gts_dev, "_scda_host", None)
+    with torch.cuda.stream(aux):
+        if host_gts is not None:      # re-upload the (tiny) boxes on the side stream: no dependence on the compute stream at all
+            pin = torch.empty(host_gts.shape[1:], dtype=torch.float32, pin_memory=True)
+            pin.copy_(torch.from_numpy(np.ascontiguousarray(host_gts[0], dtype=np.float32)))
+            gts = pin.to(dev, non_blocking=True)
+        else:
+            aux.wait_stream(main)
+            gts = gts_dev[0].contiguous()
+        G = gts.shape[0]
+        bufs = _bufs(KA, G, dev)
+        N.anchor_label(a32, gts, cfg['negative_iou_thresh'], cfg['positive_iou_thresh'], 0.1, bufs)
+        bufs["counts_host"].copy_(bufs["counts"], non_blocking=True)
+        aux.synchronize()
+        n_pos, n_neg = (int(v) for v in bufs["counts_host"])
+        # sub-sampling: the reference's two np.random.choice calls, on the counts the device found (:66-80)
+        budget = cfg['rpn_batch_size'] * B
+        max_pos = int(cfg['positive_percent'] * budget)
+        drop_pos = drop_neg = None
+        if n_pos > max_pos:
+            drop_pos = _pinned_i32(np.random.choice(n_pos, size=n_pos - max_pos, replace=False)).to(dev, non_blocking=True)
+            n_pos = max_pos
+        max_neg = budget - n_pos
+        if n_neg > max_neg:
+            drop_neg = _pinned_i32(np.random.choice(n_neg, size=n_neg - max_neg, replace=False)).to(dev, non_blocking=True)
+            n_neg = max_neg
+        cls_t, loc_t, loc_m = N.anchor_finalize(bufs, drop_pos, drop_neg, a64, gts, A, fh, fw)
+    main.wait_stream(aux)
+    for t in (cls_t, loc_t, loc_m):
+        t.record_stream(main)
+    return cls_t, loc_t, loc_m, max(1, n_pos + n_neg)
+
+
+def rpn_proposals(prob_dev, loc_dev, cfg, image_info, scores_host=None):
+    """functions/rpn_proposal.py:17-74 with the RPN outputs resident on the device.  prob_dev [B,2A,fh,fw] (soft-maxed),
+    loc_dev [B,4A,fh,fw]; scores_host: CPU copy of prob_dev if the caller already has one (else it is fetched here).
+    -> CPU float tensor [N,6] (b,x1,y1,x2,y2,score), as the reference returns; `._scda_dev` = the same rows on the device"""
+    B, A4, fh, fw = loc_dev.shape
+    A = A4 // 4
+    dev = loc_dev.device
+    _, a64 = anchors_on_device(fh, fw, cfg, dev)
+    KA = fh * fw * A
+    if scores_host is None:
+        scores_host = prob_dev.detach().cpu()
+    cls = scores_host.permute(0, 2, 3, 1).contiguous().view(B, KA, -1).numpy()
+    info = image_info.cpu().numpy() if torch.is_tensor(image_info) else np.asarray(image_info)
+    top_n, keep_n = cfg['pre_nms_top_n'], cfg['post_nms_top_n']
+    main = torch.cuda.current_stream(dev)
+    aux = backend._aux_stream(dev)
+    outs = []
+    with torch.cuda.stream(aux):
+        aux.wait_stream(main)    # the RPN outputs were produced there (already complete when the caller holds their host copy)
+        for b in range(B):
+            score = cls[b, :, -1]
+            if top_n <= 0 or top_n > score.shape[0]:
+                order = score.argsort()[::-1]
+            else:
+                cand = np.argpartition(-score, top_n)[:top_n]
+                order = cand[np.argsort(-score[cand])]
+            order_dev = _pinned_i32(order).to(dev, non_blocking=True)
+            out6, num = N.proposals_from_ranking(order_dev, a64, loc_dev[b].contiguous(), prob_dev[b].contiguous(), A, fh, fw,
+                                                 float(info[b][0]), float(info[b][1]), float(cfg['roi_min_size']),
+                                                 float(cfg['nms_iou_thresh']), max(keep_n, 0), float(b))
+            host = torch.empty(out6.numel() + 1, dtype=torch.float32, pin_memory=True)
+            host[:-1].copy_(out6.view(-1), non_blocking=True)
+            host[-1:].copy_(num.to(torch.float32), non_blocking=True)
+            outs.append((host, out6))
+        aux.synchronize()
+    rows, devs = [], []
+    for host, out6 in outs:
+        k = int(host[-1])
+        rows.append(host[:-1].view(-1, 6)[:k].clone())
+        devs.append(out6[:k])
+    res = torch.cat(rows, 0) if len(rows) > 1 else rows[0]
+    res._scda_dev = torch.cat(devs, 0) if len(devs) > 1 else devs[0]
+    return res

@@ -24,6 +24,11 @@ def _to_dev(a, like):
 
 def compute_anchor_targets(feature_size, cfg, ground_truth_bboxes, image_info, ignore_regions=None):
     """-> cls_targets int64 [B,A,h,w] (1 fg / 0 bg / -1 ignore), loc_targets, loc_masks fp32 [B,4A,h,w], normaliser"""
+    if (ignore_regions is None and feature_size[0] == 1 and torch.is_tensor(ground_truth_bboxes) and ground_truth_bboxes.is_cuda
+            and ground_truth_bboxes.dtype == torch.float32):
+        from scda_amd import device_boxes
+        if device_boxes.enabled():     # IoU, labels, sub-sampling and the target maps stay on the MI355X (box_ops.hip)
+            return device_boxes.anchor_targets(feature_size, cfg, ground_truth_bboxes)
     dev_like = ground_truth_bboxes
     gts, image_info, ignore_regions = _np(ground_truth_bboxes), _np(image_info), _np(ignore_regions)
     B, A4, fh, fw = feature_size

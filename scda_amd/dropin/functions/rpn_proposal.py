@@ -19,8 +19,22 @@ rpn_output_hook = None
 
 def compute_rpn_proposals(conv_cls, conv_loc, cfg, image_info):
     """conv_cls [B, A*2, h, w] (soft-maxed), conv_loc [B, A*4, h, w] -> CPU float tensor [N,6] (b,x1,y1,x2,y2,score)"""
+    scores_host = getattr(conv_cls, "_scda_host", None)    # CPU copy of conv_cls the caller already started (or None)
+    on_device = conv_loc.is_cuda
     if rpn_output_hook is not None:
+        if scores_host is not None:
+            conv_cls = scores_host() if callable(scores_host) else scores_host
+        dev = conv_loc.device
         conv_cls, conv_loc = rpn_output_hook(conv_cls, conv_loc)
+        scores_host = conv_cls if not conv_cls.is_cuda else None
+        if on_device and not conv_loc.is_cuda:      # the hook handed back host tensors: the device path continues on their upload
+            conv_cls, conv_loc = conv_cls.to(dev), conv_loc.to(dev)
+    if on_device:
+        from scda_amd import device_boxes
+        if device_boxes.enabled():     # decode / clip / size test / NMS / gather on the MI355X; the host only ranks the scores
+            if callable(scores_host):
+                scores_host = scores_host()
+            return device_boxes.rpn_proposals(conv_cls, conv_loc, cfg, image_info, scores_host)
     B, A4, fh, fw = conv_loc.shape
     A = A4 // 4
     assert A * 4 == A4

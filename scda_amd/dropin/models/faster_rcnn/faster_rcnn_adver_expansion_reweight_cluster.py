@@ -55,6 +55,18 @@ class _HostCopy:
         return self.host
 
 
+def _rpn_outputs(prob, loc):
+    """(objectness, deltas) on the device for the proposal generator, the objectness with an asynchronous host copy attached
+    (`_scda_host`: the host ranks the scores, everything else stays on the device -- scda_amd.device_boxes); with
+    SCDA_DEVICE_BOXES=0: host copies of both, for the numpy path"""
+    from scda_amd import device_boxes
+    if not device_boxes.enabled():
+        return _HostCopy(prob, loc).get
+    copy = _HostCopy(prob)
+    prob._scda_host = lambda: copy.get()[0]
+    return lambda: (prob, loc)
+
+
 def _objectness(rpn_pred_cls):
     """soft-max over (bg, fg) per anchor, returned in the conv layout [B, 2A, h, w]"""
     nhwc = rpn_pred_cls.detach().permute(0, 2, 3, 1).contiguous()
@@ -125,7 +137,7 @@ class FasterRCNN_AdEx(nn.Module):
 
         feat = self.feature_extractor(image)
         rpn_cls, rpn_loc = self.rpn(feat)
-        src_host = _HostCopy(_objectness(rpn_cls), rpn_loc.detach()) if self.training else None
+        src_host = _rpn_outputs(_objectness(rpn_cls), rpn_loc.detach()) if self.training else None
 
         if not self.training:
             proposals = fn['rpn_proposal_fn'](_objectness(rpn_cls), rpn_loc.detach())
@@ -142,7 +154,7 @@ class FasterRCNN_AdEx(nn.Module):
         with torch.no_grad():
             feat_t = self.feature_extractor(target)
             rpn_cls_t, rpn_loc_t = self.rpn(feat_t)
-            tgt_host = _HostCopy(_objectness(rpn_cls_t), rpn_loc_t)
+            tgt_host = _rpn_outputs(_objectness(rpn_cls_t), rpn_loc_t)
         ev_backbones = torch.cuda.Event()
         ev_backbones.record()
         mark('backbones_enqueued')
@@ -150,7 +162,7 @@ class FasterRCNN_AdEx(nn.Module):
         # ---- source image: RPN loss, proposals, sampled RoIs, RCNN, cluster regions
         rpn_loss_cls, rpn_loss_loc, rpn_acc = self._add_rpn_loss(fn['anchor_target_fn'], rpn_cls, rpn_loc)
         mark('anchor_targets+rpn_loss')
-        proposals = fn['rpn_proposal_fn'](*src_host.get())
+        proposals = fn['rpn_proposal_fn'](*src_host())
         mark('src_proposals')
         rois, cls_targets, loc_targets, loc_weights = fn['proposal_target_fn'](proposals)
         mark('src_proposal_targets')
@@ -178,7 +190,7 @@ class FasterRCNN_AdEx(nn.Module):
         # ---- target image: same RPN / RCNN, no labels, nothing is differentiated through it
         def target_branch():
             with torch.no_grad():
-                proposals_t = fn['rpn_proposal_fn'](*tgt_host.get())
+                proposals_t = fn['rpn_proposal_fn'](*tgt_host())
                 outputs['num_proposals_target'] = int(proposals_t.shape[0])
                 rois_t_host = proposals_t[0:512, :5].contiguous()
                 rois_t = N.upload(rois_t_host, dev)

@@ -203,6 +203,56 @@ def bbox_overlaps(boxes, query):
     return out
 
 
+# ------------------------------------------------ box logic on the device ----
+def anchor_label(anchors32, gts, neg_thresh, pos_thresh, min_gt_best, bufs):
+    """bufs: dict of caller-owned device buffers (best_iou, best_gt, gt_best, labels, pos_list, neg_list, counts)"""
+    _req(anchors32, "anchors"); _req(gts, "gts")
+    KA, G = anchors32.shape[0], gts.shape[0]
+    _check(lib().scda_anchor_label_hip(_p(anchors32), i32(KA), _p(gts), i32(G), i32(gts.shape[1]), f32(neg_thresh), f32(pos_thresh),
+                                       f32(min_gt_best), _p(bufs["best_iou"]), _p(bufs["best_gt"]), _p(bufs["gt_best"]),
+                                       _p(bufs["labels"]), _p(bufs["pos_list"]), _p(bufs["neg_list"]), _p(bufs["counts"]), _stream()),
+           "scda_anchor_label_hip")
+
+
+def anchor_finalize(bufs, drop_pos, drop_neg, anchors64, gts, A, fh, fw):
+    """-> cls_targets int64 [1,A,fh,fw], loc_targets, loc_masks fp32 [1,4A,fh,fw]"""
+    dev = gts.device
+    cls_t = torch.empty(1, A, fh, fw, dtype=torch.int64, device=dev)
+    loc_t = torch.empty(1, 4 * A, fh, fw, dtype=torch.float32, device=dev)
+    loc_m = torch.empty(1, 4 * A, fh, fw, dtype=torch.float32, device=dev)
+    _check(lib().scda_anchor_finalize_hip(_p(bufs["labels"]), _p(bufs["best_gt"]), _p(bufs["pos_list"]), _p(drop_pos),
+                                          i32(0 if drop_pos is None else drop_pos.numel()), _p(bufs["neg_list"]), _p(drop_neg),
+                                          i32(0 if drop_neg is None else drop_neg.numel()), _p(anchors64), _p(gts), i32(gts.shape[1]),
+                                          i32(A), i32(fh), i32(fw), _p(cls_t), _p(loc_t), _p(loc_m), _stream()),
+           "scda_anchor_finalize_hip")
+    return cls_t, loc_t, loc_m
+
+
+def proposals_from_ranking(order, anchors64, loc, prob, A, fh, fw, img_h, img_w, min_size, nms_thresh, max_keep, image_index):
+    """order int32 [n] (device) -> (out6 fp32 [rows,6], num int64 [1]) on the device: decode + clip + size test, NMS, gather"""
+    _req(order, "order", torch.int32); _req(loc, "loc"); _req(prob, "prob")
+    n = order.numel()
+    dev = loc.device
+    rows = max_keep if max_keep > 0 else max(n, 1)
+    out6 = torch.zeros(rows, 6, dtype=torch.float32, device=dev)
+    num = torch.zeros(1, dtype=torch.int64, device=dev)
+    if n == 0:
+        return out6, num
+    props = torch.empty(n, 5, dtype=torch.float32, device=dev)
+    ok = torch.empty(n, dtype=torch.uint8, device=dev)
+    L = lib()
+    _check(L.scda_proposal_decode_hip(_p(order), i32(n), _p(anchors64), _p(loc), _p(prob), i32(A), i32(fh), i32(fw),
+                                      ctypes.c_double(img_h), ctypes.c_double(img_w), ctypes.c_double(min_size), _p(props), _p(ok),
+                                      _stream()), "scda_proposal_decode_hip")
+    keep = torch.empty(n, dtype=torch.int64, device=dev)
+    ws = torch.empty(max(L.scda_nms_workspace_bytes(i32(n)), 8), dtype=torch.uint8, device=dev)
+    _check(L.scda_nms_valid_hip(_p(props), _p(ok), i32(n), f32(nms_thresh), _p(ws), _p(keep), _p(num), i32(max_keep), _stream()),
+           "scda_nms_valid_hip")
+    _check(L.scda_proposal_gather_hip(_p(props), _p(keep), _p(num), f32(image_index), i32(rows), _p(out6), _stream()),
+           "scda_proposal_gather_hip")
+    return out6, num
+
+
 # ------------------------------------------------- convolution / GEMM -------
 _WS = {}
 

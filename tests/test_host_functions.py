@@ -46,7 +46,9 @@ def cpu_backend():
     backend.reset()
 
 
-def check_l2(golden_dir, G):
+def check_l2(golden_dir, G, device=None):
+    """device given: ground truth and RPN outputs are handed over as device tensors, which routes anchor labelling and proposal
+    generation through the device-resident kernels (scda_amd/device_boxes.py); results are compared on the host either way"""
     from scda_amd.dropin.functions.anchor_target import compute_anchor_targets
     from scda_amd.dropin.functions.rpn_proposal import compute_rpn_proposals
     from scda_amd.dropin.functions.proposal_target import compute_proposal_targets
@@ -54,9 +56,17 @@ def check_l2(golden_dir, G):
     g = np.load(os.path.join(golden_dir, f"l2_G{G}.npz"))
     seed = int(g["seed"])
     gts = torch.from_numpy(g["gts"]); info = torch.from_numpy(g["image_info"])
+    if device is not None:
+        gts_in = gts.to(device)
+        gts_in._scda_host = g["gts"]
+    else:
+        gts_in = gts
 
     np.random.seed(seed)
-    cls_t, loc_t, loc_m, norm = compute_anchor_targets((1, 60, 32, 64), CFG["train_anchor_target_cfg"], gts, info, None)
+    cls_t, loc_t, loc_m, norm = compute_anchor_targets((1, 60, 32, 64), CFG["train_anchor_target_cfg"], gts_in, info, None)
+    if device is not None:
+        assert cls_t.is_cuda and loc_t.is_cuda
+        cls_t, loc_t, loc_m = cls_t.cpu(), loc_t.cpu(), loc_m.cpu()
     np.testing.assert_array_equal(cls_t.numpy().astype(np.int8), g["at_cls_targets"])
     assert norm == int(g["at_normalizer"])
     nz = np.nonzero(loc_m.numpy().reshape(-1))[0]
@@ -65,7 +75,10 @@ def check_l2(golden_dir, G):
     assert cls_t.dtype == torch.int64 and loc_t.dtype == torch.float32 and tuple(loc_t.shape) == (1, 60, 32, 64)
 
     cls, loc = synth_rpn_outputs(seed)
+    if device is not None:
+        cls, loc = cls.to(device), loc.to(device)
     props = compute_rpn_proposals(cls, loc, CFG["train_rpn_proposal_cfg"], g["image_info"])
+    assert not props.is_cuda and (device is None or torch.equal(props._scda_dev.cpu(), props))
     np.testing.assert_array_equal(props.numpy(), g["proposals"])
     props_test = compute_rpn_proposals(cls, loc, CFG["test_rpn_proposal_cfg"], g["image_info"])
     np.testing.assert_array_equal(props_test.numpy(), g["proposals_test"])
