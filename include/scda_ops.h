@@ -145,8 +145,10 @@ int scda_anchor_finalize_hip(signed char *labels, const int *best_gt, const int 
                              void *stream);
 /* functions/rpn_proposal.py:36-60 for the n candidates the host ranked (order i32 [n], anchor indices): decode + clip in float64,
  * props5 fp32 [n,5] = (x1,y1,x2,y2,score), ok u8 [n] = the roi_min_size test.  loc [4A,fh,fw] / prob [2A,fh,fw] are the RPN's
- * NCHW outputs of that image.  Then scda_nms_valid_hip(props5, ok, ...) and scda_proposal_gather_hip. */
-int scda_proposal_decode_hip(const int *order, int n, const double *anchors64, const float *loc, const float *prob, int A, int fh,
+ * NCHW outputs of that image; exp_wh f32 [n,2] = np.exp of the candidates' (dw, dh) evaluated by numpy on the host (numpy's
+ * float32 exp is not correctly rounded: only numpy reproduces it).  Then scda_nms_valid_hip(props5, ok, ...) and
+ * scda_proposal_gather_hip. */
+int scda_proposal_decode_hip(const int *order, const float *exp_wh, int n, const double *anchors64, const float *loc, const float *prob, int A, int fh,
                              int fw, double img_h, double img_w, double min_size, float *props5, unsigned char *ok, void *stream);
 /* out6 [max_rows,6] rows i < min(max_rows, *num_keep) = (image_index, props5[keep[i]]) */
 int scda_proposal_gather_hip(const float *props5, const long long *keep, const long long *num_keep, float image_index, int max_rows,

@@ -148,7 +148,11 @@ __global__ __launch_bounds__(256) void anchor_finalize_kernel(const signed char 
 // ok[j] = both sides >= roi_min_size.  delta / score are read straight out of the RPN's NCHW outputs
 // (loc [4A, fh, fw], objectness [2A, fh, fw], anchor k = (y*fw + x)*A + a).  Decode in float64 as utils/bbox_helper.py:88-103
 // (numpy promotes the fp32 deltas to the float64 anchors), clip as :105-110, the `+ 1` size test of rpn_proposal.py:57-58.
-__global__ __launch_bounds__(256) void proposal_decode_kernel(const int *__restrict__ order, const int n,
+// exp_wh [n,2] = np.exp(delta_w), np.exp(delta_h) of the ranked candidates AS NUMPY COMPUTES THEM: on a float32 array np.exp
+// returns float32 from numpy's own SIMD routine, which is not correctly rounded -- no device expf reproduces it bit for bit
+// (a float64 exp here differed from the reference in the last fp32 bit of 7.6 % of the coordinates).  The host therefore
+// evaluates these 2n exponentials with numpy (microseconds) and everything else happens here.
+__global__ __launch_bounds__(256) void proposal_decode_kernel(const int *__restrict__ order, const float *__restrict__ exp_wh, const int n,
                                                               const double *__restrict__ anchors64,
                                                               const float *__restrict__ loc, const float *__restrict__ prob,
                                                               const int A, const int fh, const int fw, const double img_h,
@@ -160,9 +164,8 @@ __global__ __launch_bounds__(256) void proposal_decode_kernel(const int *__restr
     const size_t plane = (size_t)fh * fw;
     const double *r = anchors64 + (size_t)k * 4;
     const double d0 = loc[(size_t)(a * 4 + 0) * plane + cell], d1 = loc[(size_t)(a * 4 + 1) * plane + cell];
-    const double d2 = loc[(size_t)(a * 4 + 2) * plane + cell], d3 = loc[(size_t)(a * 4 + 3) * plane + cell];
     const double rcx = (r[0] + r[2]) / 2., rcy = (r[1] + r[3]) / 2., rw = r[2] - r[0], rh = r[3] - r[1];
-    const double cx = d0 * rw + rcx, cy = d1 * rh + rcy, w = exp(d2) * rw, h = exp(d3) * rh;
+    const double cx = d0 * rw + rcx, cy = d1 * rh + rcy, w = (double)exp_wh[2 * j] * rw, h = (double)exp_wh[2 * j + 1] * rh;
     double x1 = cx - w / 2., y1 = cy - h / 2., x2 = cx + w / 2., y2 = cy + h / 2.;
     x1 = fmin(fmax(x1, 0.), img_w - 1.); y1 = fmin(fmax(y1, 0.), img_h - 1.);
     x2 = fmin(fmax(x2, 0.), img_w - 1.); y2 = fmin(fmax(y2, 0.), img_h - 1.);
@@ -231,14 +234,14 @@ SCDA_API int scda_anchor_finalize_hip(signed char *labels, const int *best_gt, c
 
 // RPN proposals of one image (functions/rpn_proposal.py:36-60) for the candidates the host ranked: decode + clip + size test,
 // then the caller runs scda_nms_valid_hip on props5 / ok and scda_proposal_gather_hip on the keep list.
-SCDA_API int scda_proposal_decode_hip(const int *order, int n, const double *anchors64, const float *loc, const float *prob, int A,
-                                      int fh, int fw, double img_h, double img_w, double min_size, float *props5,
-                                      unsigned char *ok, void *stream) {
-    BOX_CHECK(n >= 0 && (n == 0 || (order && anchors64 && loc && prob && props5 && ok)) && A > 0 && fh > 0 && fw > 0,
+SCDA_API int scda_proposal_decode_hip(const int *order, const float *exp_wh, int n, const double *anchors64, const float *loc,
+                                      const float *prob, int A, int fh, int fw, double img_h, double img_w, double min_size,
+                                      float *props5, unsigned char *ok, void *stream) {
+    BOX_CHECK(n >= 0 && (n == 0 || (order && exp_wh && anchors64 && loc && prob && props5 && ok)) && A > 0 && fh > 0 && fw > 0,
               "scda_proposal_decode_hip")
     if (n == 0) return SCDA_OK;
-    hipLaunchKernelGGL(proposal_decode_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), order, n, anchors64, loc, prob, A, fh,
-                       fw, img_h, img_w, min_size, props5, ok);
+    hipLaunchKernelGGL(proposal_decode_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), order, exp_wh, n, anchors64, loc, prob, A,
+                       fh, fw, img_h, img_w, min_size, props5, ok);
     return launch_status("proposal_decode_kernel");
 }
 

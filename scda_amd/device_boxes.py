@@ -5,9 +5,11 @@ functions/rpn_proposal.py:36-66 for batch-1 device inputs.
 What stays on the host, because it IS the reference's observable behaviour:
   * random draws from numpy's global generator (np.random.choice for the surplus positives / negatives): the device sends
     back two counts, the host draws exactly what the reference would and uploads the indices to drop;
-  * the ranking of RPN scores (np.argpartition + np.argsort -- the order of tied scores is numpy's): the host receives the
-    objectness map only (not the deltas), ranks, and uploads the candidate order.
-What no longer crosses PCIe: the 30720 x G IoU matrix, the 30720 x 9 target maps, the RPN deltas, the 12000 candidate boxes.
+  * the ranking of RPN scores (np.argpartition + np.argsort -- the order of tied scores is numpy's) and np.exp of the ranked
+    candidates' size deltas (numpy's float32 exp is its own, not correctly rounded, SIMD routine): the host receives the RPN
+    outputs, ranks, exponentiates 2 x 12000 numbers and uploads order + factors.
+What no longer crosses PCIe or touches numpy: the 30720 x G IoU matrix, the 30720 x 9 target maps, the decoded / clipped / filtered
+candidate boxes, the NMS input and the gather of the kept rows.
 All kernels here run on the box logic's high-priority side stream (their inputs do not depend on the compute stream's
 backlog), so the host's waits stay short.
 
@@ -34,7 +36,7 @@ def anchors_on_device(fh, fw, cfg, dev):
     hit = _ANCHORS.get(key)
     if hit is None:
         a = anchor_helper.get_anchors_over_plane(fh, fw, cfg['anchor_ratios'], cfg['anchor_scales'], cfg['anchor_stride'])
-        a64 = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        a64 = torch.from_numpy(np.array(a, dtype=np.float64)).to(dev)
         a32 = torch.from_numpy(a.astype(np.float32)).to(dev)      # the cast the reference applies before the IoU (bbox_helper.py:9)
         hit = _ANCHORS[key] = (a32, a64)
     return hit
@@ -103,9 +105,9 @@ def anchor_targets(feature_size, cfg, gts_dev):
     return cls_t, loc_t, loc_m, max(1, n_pos + n_neg)
 
 
-def rpn_proposals(prob_dev, loc_dev, cfg, image_info, scores_host=None):
+def rpn_proposals(prob_dev, loc_dev, cfg, image_info, scores_host=None, loc_host=None):
     """functions/rpn_proposal.py:17-74 with the RPN outputs resident on the device.  prob_dev [B,2A,fh,fw] (soft-maxed),
-    loc_dev [B,4A,fh,fw]; scores_host: CPU copy of prob_dev if the caller already has one (else it is fetched here).
+    loc_dev [B,4A,fh,fw]; scores_host / loc_host: CPU copies if the caller already has them (else they are fetched here).
     -> CPU float tensor [N,6] (b,x1,y1,x2,y2,score), as the reference returns; `._scda_dev` = the same rows on the device"""
     B, A4, fh, fw = loc_dev.shape
     A = A4 // 4
@@ -114,7 +116,10 @@ def rpn_proposals(prob_dev, loc_dev, cfg, image_info, scores_host=None):
     KA = fh * fw * A
     if scores_host is None:
         scores_host = prob_dev.detach().cpu()
+    if loc_host is None:
+        loc_host = loc_dev.detach().cpu()
     cls = scores_host.permute(0, 2, 3, 1).contiguous().view(B, KA, -1).numpy()
+    loc = loc_host.permute(0, 2, 3, 1).contiguous().view(B, KA, 4).numpy()
     info = image_info.cpu().numpy() if torch.is_tensor(image_info) else np.asarray(image_info)
     top_n, keep_n = cfg['pre_nms_top_n'], cfg['post_nms_top_n']
     main = torch.cuda.current_stream(dev)
@@ -130,7 +135,10 @@ def rpn_proposals(prob_dev, loc_dev, cfg, image_info, scores_host=None):
                 cand = np.argpartition(-score, top_n)[:top_n]
                 order = cand[np.argsort(-score[cand])]
             order_dev = _pinned_i32(order).to(dev, non_blocking=True)
-            out6, num = N.proposals_from_ranking(order_dev, a64, loc_dev[b].contiguous(), prob_dev[b].contiguous(), A, fh, fw,
+            ewh = torch.from_numpy(np.exp(loc[b, order, 2:4]))           # float32 in, float32 out: numpy's own exp (bbox_helper.py:97)
+            ewh_pin = torch.empty(ewh.shape, dtype=torch.float32, pin_memory=True)
+            ewh_pin.copy_(ewh)
+            out6, num = N.proposals_from_ranking(order_dev, ewh_pin.to(dev, non_blocking=True), a64, loc_dev[b].contiguous(), prob_dev[b].contiguous(), A, fh, fw,
                                                  float(info[b][0]), float(info[b][1]), float(cfg['roi_min_size']),
                                                  float(cfg['nms_iou_thresh']), max(keep_n, 0), float(b))
             host = torch.empty(out6.numel() + 1, dtype=torch.float32, pin_memory=True)

@@ -19,22 +19,25 @@ rpn_output_hook = None
 
 def compute_rpn_proposals(conv_cls, conv_loc, cfg, image_info):
     """conv_cls [B, A*2, h, w] (soft-maxed), conv_loc [B, A*4, h, w] -> CPU float tensor [N,6] (b,x1,y1,x2,y2,score)"""
-    scores_host = getattr(conv_cls, "_scda_host", None)    # CPU copy of conv_cls the caller already started (or None)
+    host = getattr(conv_cls, "_scda_host", None)    # () -> CPU copies (cls, loc) the caller already started, or None
     on_device = conv_loc.is_cuda
+    cls_host = loc_host = None
+    if host is not None:
+        cls_host, loc_host = host()
     if rpn_output_hook is not None:
-        if scores_host is not None:
-            conv_cls = scores_host() if callable(scores_host) else scores_host
         dev = conv_loc.device
-        conv_cls, conv_loc = rpn_output_hook(conv_cls, conv_loc)
-        scores_host = conv_cls if not conv_cls.is_cuda else None
-        if on_device and not conv_loc.is_cuda:      # the hook handed back host tensors: the device path continues on their upload
-            conv_cls, conv_loc = conv_cls.to(dev), conv_loc.to(dev)
+        cls_host, loc_host = rpn_output_hook(cls_host if cls_host is not None else conv_cls,
+                                             loc_host if loc_host is not None else conv_loc)
+        if cls_host.is_cuda:
+            cls_host = loc_host = None
+        elif on_device:                              # the hook handed back host tensors: the device path continues on their upload
+            conv_cls, conv_loc = cls_host.to(dev), loc_host.to(dev)
+        else:
+            conv_cls, conv_loc = cls_host, loc_host
     if on_device:
         from scda_amd import device_boxes
-        if device_boxes.enabled():     # decode / clip / size test / NMS / gather on the MI355X; the host only ranks the scores
-            if callable(scores_host):
-                scores_host = scores_host()
-            return device_boxes.rpn_proposals(conv_cls, conv_loc, cfg, image_info, scores_host)
+        if device_boxes.enabled():     # decode / clip / size test / NMS / gather on the MI355X; the host ranks and exponentiates
+            return device_boxes.rpn_proposals(conv_cls, conv_loc, cfg, image_info, cls_host, loc_host)
     B, A4, fh, fw = conv_loc.shape
     A = A4 // 4
     assert A * 4 == A4

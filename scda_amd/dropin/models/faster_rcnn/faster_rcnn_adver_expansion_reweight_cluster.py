@@ -56,14 +56,14 @@ class _HostCopy:
 
 
 def _rpn_outputs(prob, loc):
-    """(objectness, deltas) on the device for the proposal generator, the objectness with an asynchronous host copy attached
-    (`_scda_host`: the host ranks the scores, everything else stays on the device -- scda_amd.device_boxes); with
-    SCDA_DEVICE_BOXES=0: host copies of both, for the numpy path"""
+    """(objectness, deltas) on the device for the proposal generator, with asynchronous host copies attached (`_scda_host`: the
+    host ranks the scores and exponentiates the size deltas, everything else stays on the device -- scda_amd.device_boxes);
+    with SCDA_DEVICE_BOXES=0: the host copies alone, for the numpy path"""
     from scda_amd import device_boxes
+    copy = _HostCopy(prob, loc)
     if not device_boxes.enabled():
-        return _HostCopy(prob, loc).get
-    copy = _HostCopy(prob)
-    prob._scda_host = lambda: copy.get()[0]
+        return copy.get
+    prob._scda_host = copy.get
     return lambda: (prob, loc)
 
 

@@ -228,9 +228,10 @@ def anchor_finalize(bufs, drop_pos, drop_neg, anchors64, gts, A, fh, fw):
     return cls_t, loc_t, loc_m
 
 
-def proposals_from_ranking(order, anchors64, loc, prob, A, fh, fw, img_h, img_w, min_size, nms_thresh, max_keep, image_index):
-    """order int32 [n] (device) -> (out6 fp32 [rows,6], num int64 [1]) on the device: decode + clip + size test, NMS, gather"""
-    _req(order, "order", torch.int32); _req(loc, "loc"); _req(prob, "prob")
+def proposals_from_ranking(order, exp_wh, anchors64, loc, prob, A, fh, fw, img_h, img_w, min_size, nms_thresh, max_keep, image_index):
+    """order int32 [n], exp_wh f32 [n,2] (device) -> (out6 fp32 [rows,6], num int64 [1]) on the device: decode + clip + size test,
+    NMS, gather"""
+    _req(order, "order", torch.int32); _req(exp_wh, "exp_wh"); _req(loc, "loc"); _req(prob, "prob")
     n = order.numel()
     dev = loc.device
     rows = max_keep if max_keep > 0 else max(n, 1)
@@ -241,7 +242,7 @@ def proposals_from_ranking(order, anchors64, loc, prob, A, fh, fw, img_h, img_w,
     props = torch.empty(n, 5, dtype=torch.float32, device=dev)
     ok = torch.empty(n, dtype=torch.uint8, device=dev)
     L = lib()
-    _check(L.scda_proposal_decode_hip(_p(order), i32(n), _p(anchors64), _p(loc), _p(prob), i32(A), i32(fh), i32(fw),
+    _check(L.scda_proposal_decode_hip(_p(order), _p(exp_wh), i32(n), _p(anchors64), _p(loc), _p(prob), i32(A), i32(fh), i32(fw),
                                       ctypes.c_double(img_h), ctypes.c_double(img_w), ctypes.c_double(min_size), _p(props), _p(ok),
                                       _stream()), "scda_proposal_decode_hip")
     keep = torch.empty(n, dtype=torch.int64, device=dev)
