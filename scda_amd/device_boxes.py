@@ -125,8 +125,10 @@ def rpn_proposals(prob_dev, loc_dev, cfg, image_info, scores_host=None, loc_host
     main = torch.cuda.current_stream(dev)
     aux = backend._aux_stream(dev)
     outs = []
+    # No stream dependency is needed: the host holds a copy of the RPN outputs (its own .cpu() above, or the caller's event-
+    # synchronised pinned copy), so the kernels that produced prob_dev / loc_dev have completed.  (Waiting for the compute
+    # stream here would put the proposals behind everything queued since -- e.g. the whole target-image backbone.)
     with torch.cuda.stream(aux):
-        aux.wait_stream(main)    # the RPN outputs were produced there (already complete when the caller holds their host copy)
         for b in range(B):
             score = cls[b, :, -1]
             if top_n <= 0 or top_n > score.shape[0]:
