@@ -223,6 +223,11 @@ int scda_gemm_hip(const float *A, const float *B, float *C, int M, int N, int K,
 /* nn.MaxPool2d(2,2): vgg_adver_expansion_cluster.py:106.  idx uint8 = winner 0..3 */
 int scda_maxpool2x2_fwd_hip(const float *x, float *y, uint8_t *idx, int planes, int H, int W, void *stream);
 int scda_maxpool2x2_bwd_hip(const float *dy, const uint8_t *idx, float *dx, int planes, int H, int W, void *stream);
+/* nn.MaxPool2d(3, stride 2, padding 1), forward (ResNet stem, models/mask_rcnn/resnet.py:120; frozen there, so no backward);
+ * y [planes, (H-1)/2+1, (W-1)/2+1] */
+int scda_maxpool3x3s2_fwd_hip(const float *x, float *y, int planes, int H, int W, void *stream);
+/* y = relu(a + b): residual join of a ResNet block (resnet.py:104-105) */
+int scda_add_relu_hip(const float *a, const float *b, float *y, long long n, void *stream);
 /* max-pool backward + backward of the ReLU in front of the pool (a window's winner is > 0 iff the pooled value y_pooled is) */
 int scda_maxpool2x2_bwd_relu_hip(const float *dy, const uint8_t *idx, const float *y_pooled, float *dx, int planes, int H, int W,
                                  void *stream);

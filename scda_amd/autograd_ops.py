@@ -235,6 +235,34 @@ class AddFn(Function):
         return dy, dy
 
 
+class AddReluFn(Function):
+    """relu(a + b) -- the residual join of a ResNet block; both inputs receive dy * (y > 0)"""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        y = N.add_relu(_c(a), _c(b))
+        ctx.save_for_backward(_mask_src(ctx, y))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        g = N.act_bwd(_c(dy), y, 0, 0.0)
+        return (g if ctx.needs_input_grad[0] else None), (g if ctx.needs_input_grad[1] else None)
+
+
+class MaxPool3x3s2Fn(Function):
+    """nn.MaxPool2d(3, 2, 1), forward only (the ResNet stem in front of it is frozen: nothing is differentiated through it)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return N.maxpool3x3s2_fwd(_c(x))
+
+    @staticmethod
+    def backward(ctx, dy):
+        raise NotImplementedError("MaxPool3x3s2 has no backward: the reference freezes the stem (models/mask_rcnn/resnet.py:230-238)")
+
+
 class RoIPoolFn(Function):
     """extensions/_roi_pooling/functions/roi_pool.py:6-42 (differentiable w.r.t. features only)"""
 

@@ -1312,7 +1312,8 @@ using namespace scda;
     if (KH == 3 && KW == 3 && S == 1) return FN<3, 3, 1 __VA_ARGS__;                              \
     if (KH == 3 && KW == 3 && S == 2) return FN<3, 3, 2 __VA_ARGS__;                              \
     if (KH == 1 && KW == 1 && S == 1) return FN<1, 1, 1 __VA_ARGS__;                              \
-    set_error("conv: unsupported kernel %dx%d stride %d (supported: 3x3 s1, 3x3 s2, 1x1 s1)", KH, KW, S); \
+    if (KH == 1 && KW == 1 && S == 2) return FN<1, 1, 2 __VA_ARGS__;   /* ResNet down-sampling shortcuts */ \
+    set_error("conv: unsupported kernel %dx%d stride %d (supported: 3x3 s1, 3x3 s2, 1x1 s1, 1x1 s2; forward also 7x7 s2)", KH, KW, S); \
     return SCDA_EINVAL;
 
 static int conv_out_dim(int in, int k, int s, int p) { return (in + 2 * p - k) / s + 1; }
@@ -1346,6 +1347,8 @@ SCDA_API int scda_conv2d_fwd_hip(const float *x, const float *w, const float *bi
     g.slab_aligned = (Cin % BK) == 0;
     g.zp = zero_page();
     Epi e{y, nullptr, bias, 0, act, slope, 1, 0, nullptr, 0.f};
+    if (KH == 7 && KW == 7 && S == 2)   // the ResNet stem (3 -> 64, frozen in the reference: models/mask_rcnn/resnet.py:230-238): forward only
+        return launch_conv<7, 7, 2, false>(w, x, g, e, (float *)ws, ws_bytes, as_stream(stream));
     CONV_DISPATCH(launch_conv, , false > (w, x, g, e, (float *)ws, ws_bytes, as_stream(stream)))
 }
 

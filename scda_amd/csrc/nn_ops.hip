@@ -88,6 +88,42 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float *__restri
     }
 }
 
+// nn.MaxPool2d(kernel_size=3, stride=2, padding=1) -- the ResNet stem pool (models/mask_rcnn/resnet.py:120); forward only: the
+// stem and layer1 are frozen in the reference (:230-238), nothing is differentiated through it.  -inf padding semantics.
+__global__ __launch_bounds__(256) void maxpool3s2_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, const long long total,
+                                                             const int H, const int W, const int OH, const int OW) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)blockDim.x * gridDim.x) {
+        const int ox = (int)(i % OW);
+        const long long r = i / OW;
+        const int oy = (int)(r % OH);
+        const long long pc = r / OH;
+        const float *p = x + pc * H * W;
+        float m = -INFINITY;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int iy = 2 * oy - 1 + dy;
+            if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int ix = 2 * ox - 1 + dx;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                const float v = p[(size_t)iy * W + ix];
+                if (v > m || v != v) m = v;
+            }
+        }
+        y[i] = m;
+    }
+}
+
+// y = relu(a + b): the residual join of a bottleneck (resnet.py:104-105) in one pass; backward = ReLU mask on y for both inputs
+__global__ __launch_bounds__(256) void add_relu_kernel(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ y,
+                                                       const long long n) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)blockDim.x * gridDim.x) {
+        const float v = a[i] + b[i];
+        y[i] = v > 0.f ? v : 0.f;
+    }
+}
+
 // ----------------------------------------------------------- elementwise ----
 // mode 0: relu'(y) ; 1: leaky'(y, slope) ; 2: tanh'(y) = 1-y^2 ; 3: sigmoid'(y) = y(1-y)
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ y,
@@ -502,29 +538,23 @@ __global__ __launch_bounds__(256) void batchnorm_fwd_kernel(const float *__restr
     __shared__ float red[16];
     const int c = blockIdx.x;
     const float n = (float)B * (float)HW;
+    // the (image, pixel) pairs of this channel as ONE index space: RoI-sized maps (HW = 49, B = 512) keep all threads busy
+    const int BHW = B * HW;
+    auto at = [&](const int j) -> size_t { const int b = j / HW; return ((size_t)b * C + c) * HW + (j - b * HW); };
     float s = 0.f;
-    for (int b = 0; b < B; ++b) {
-        const float *p = x + ((size_t)b * C + c) * HW;
-        for (int i = threadIdx.x; i < HW; i += blockDim.x) s += p[i];
-    }
+    for (int j = threadIdx.x; j < BHW; j += blockDim.x) s += x[at(j)];
     const float mean = block_sum(s, red) / n;
     float v = 0.f;
-    for (int b = 0; b < B; ++b) {
-        const float *p = x + ((size_t)b * C + c) * HW;
-        for (int i = threadIdx.x; i < HW; i += blockDim.x) { const float d = p[i] - mean; v += d * d; }
-    }
+    for (int j = threadIdx.x; j < BHW; j += blockDim.x) { const float d = x[at(j)] - mean; v += d * d; }
     const float var = block_sum(v, red) / n;
     const float rstd = 1.f / sqrtf(var + eps);
     const float ga = gamma[c], be = beta[c];
-    for (int b = 0; b < B; ++b) {
-        const float *p = x + ((size_t)b * C + c) * HW;
-        float *q = y + ((size_t)b * C + c) * HW;
-        for (int i = threadIdx.x; i < HW; i += blockDim.x) {
-            float o = (p[i] - mean) * rstd * ga + be;
-            if (act == 2) o = o > 0.f ? o : o * slope;
-            else if (act == 1) o = o > 0.f ? o : 0.f;
-            q[i] = o;
-        }
+    for (int j = threadIdx.x; j < BHW; j += blockDim.x) {
+        const size_t o_ = at(j);
+        float o = (x[o_] - mean) * rstd * ga + be;
+        if (act == 2) o = o > 0.f ? o : o * slope;
+        else if (act == 1) o = o > 0.f ? o : 0.f;
+        y[o_] = o;
     }
     if (threadIdx.x == 0) {
         mean_out[c] = mean; rstd_out[c] = rstd;
@@ -546,31 +576,29 @@ __global__ __launch_bounds__(256) void batchnorm_bwd_kernel(const float *__restr
     const int c = blockIdx.x;
     const float n = (float)B * (float)HW;
     const float mean = mean_in[c], rstd = rstd_in[c], ga = gamma[c], be = beta[c];
+    const int BHW = B * HW;
+    auto at = [&](const int j) -> size_t { const int b = j / HW; return ((size_t)b * C + c) * HW + (j - b * HW); };
     float s1 = 0.f, s2 = 0.f;
-    for (int b = 0; b < B; ++b) {
-        const size_t off = ((size_t)b * C + c) * HW;
-        for (int i = threadIdx.x; i < HW; i += blockDim.x) {
-            const float xh = (x[off + i] - mean) * rstd;
-            const float pre = xh * ga + be;
-            float g = dy[off + i];
-            if (act == 2) g = pre > 0.f ? g : g * slope;
-            else if (act == 1) g = pre > 0.f ? g : 0.f;
-            s1 += g; s2 += g * xh;
-        }
+    for (int j = threadIdx.x; j < BHW; j += blockDim.x) {
+        const size_t o_ = at(j);
+        const float xh = (x[o_] - mean) * rstd;
+        const float pre = xh * ga + be;
+        float g = dy[o_];
+        if (act == 2) g = pre > 0.f ? g : g * slope;
+        else if (act == 1) g = pre > 0.f ? g : 0.f;
+        s1 += g; s2 += g * xh;
     }
     const float sum1 = block_sum(s1, red), sum2 = block_sum(s2, red);
     const float m1 = sum1 / n, m2 = sum2 / n;
     if (dx) {
-        for (int b = 0; b < B; ++b) {
-            const size_t off = ((size_t)b * C + c) * HW;
-            for (int i = threadIdx.x; i < HW; i += blockDim.x) {
-                const float xh = (x[off + i] - mean) * rstd;
-                const float pre = xh * ga + be;
-                float g = dy[off + i];
-                if (act == 2) g = pre > 0.f ? g : g * slope;
-                else if (act == 1) g = pre > 0.f ? g : 0.f;
-                dx[off + i] = ga * rstd * (g - m1 - xh * m2);
-            }
+        for (int j = threadIdx.x; j < BHW; j += blockDim.x) {
+            const size_t o_ = at(j);
+            const float xh = (x[o_] - mean) * rstd;
+            const float pre = xh * ga + be;
+            float g = dy[o_];
+            if (act == 2) g = pre > 0.f ? g : g * slope;
+            else if (act == 1) g = pre > 0.f ? g : 0.f;
+            dx[o_] = ga * rstd * (g - m1 - xh * m2);
         }
     }
     if (threadIdx.x == 0) {
@@ -795,6 +823,21 @@ SCDA_API int scda_maxpool2x2_bwd_relu_hip(const float *dy, const uint8_t *idx, c
     hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(ew_grid(total) * 4), dim3(256), 0, as_stream(stream), dy, idx, dx, total, H, W, OH, OW,
                        y_pooled);
     return launch_status("maxpool2_bwd_kernel");
+}
+
+SCDA_API int scda_maxpool3x3s2_fwd_hip(const float *x, float *y, int planes, int H, int W, void *stream) {
+    NN_CHECK(x && y && planes > 0 && H >= 1 && W >= 1, "scda_maxpool3x3s2_fwd_hip")
+    const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    const long long total = (long long)planes * OH * OW;
+    hipLaunchKernelGGL(maxpool3s2_fwd_kernel, dim3(ew_grid(total) * 4), dim3(256), 0, as_stream(stream), x, y, total, H, W, OH, OW);
+    return launch_status("maxpool3s2_fwd_kernel");
+}
+
+SCDA_API int scda_add_relu_hip(const float *a, const float *b, float *y, long long n, void *stream) {
+    NN_CHECK(a && b && y && n >= 0, "scda_add_relu_hip")
+    if (n == 0) return SCDA_OK;
+    hipLaunchKernelGGL(add_relu_kernel, dim3(ew_grid(n) * 4), dim3(256), 0, as_stream(stream), a, b, y, n);
+    return launch_status("add_relu_kernel");
 }
 
 SCDA_API int scda_act_fwd_hip(const float *x, float *y, long long n, int mode, float slope, void *stream) {

@@ -279,8 +279,10 @@ class GAN_dis_AE_patch(nn.Module):
             self.n_in, self.n_out, clusters = params['n_in'], params['n_out'], params['cluster_num']
         else:
             self.n_in, self.n_out, clusters = 128, 256, 4
+        # the reference hard-codes the 64 x 64 unfolding of VGG's 4096-d RoI feature (:326); other detectors pass 'w' / 'h'
+        w, h = (params or {}).get('w', 64), (params or {}).get('h', 64)
         self.model_A_patch = nn.Sequential(ResDis_cluster(n_in=self.n_in, n_out=self.n_out, kernel_size=3, stride=2,
-                                                          padding=1, w=64, h=64, cluster_num=clusters))
+                                                          padding=1, w=w, h=h, cluster_num=clusters))
 
     def forward(self, rois_features):
         return A.sigmoid(self.model_A_patch(rois_features))

@@ -1,0 +1,135 @@
+"""ResNet C4 Faster R-CNN body -- module API of models/mask_rcnn/resnet.py:69-259 (Bottleneck :69-106, ResNet :111-259,
+resnet50 :300-310), as a detector of the SCDA family: BASELINE.json configs[3] ("resnet50_FasterRCNN + SCDA, 800x1333").
+
+The reference has NO runnable model for this configuration: `models/mask_rcnn/mask_rcnn.py` (its base class) is missing from the
+repository and `tools/faster_rcnn_train_val.py:83` admits VGG only.  What exists is the body specification
+followed here layer for layer: 7x7/2 stem + BN + ReLU + 3x3/2 max-pool, layer1..layer3 of bottlenecks (stride 16, 1024 channels;
+torchvision's `resnet50-19c8e357.pth` key layout), `NaiveRpnHead(1024)`, `RoIAlignAvg(7, 7, 1/16)`, layer4 at stride 1 on the
+RoI features, 7x7 average pool, `fc_rcnn_cls / fc_rcnn_loc` on 2048 features; stem and layer1 frozen and in eval mode
+(:213-238).  To serve the SCDA step it derives from FasterRCNN_AdEx and `rcnn()` also returns the pooled 2048-d RoI feature
+(the cluster-region generator's input, like VGG's FC7 output).  PERFORMANCE configuration: parity is unpinned by construction."""
+import math
+
+import torch.nn as nn
+
+from scda_amd import autograd_ops as A
+from scda_amd import layers as L
+from scda_amd.autograd_ops import ACT_NONE, ACT_RELU
+from scda_amd.dropin.extensions._roi_align.modules.roi_align import RoIAlignAvg
+from scda_amd.dropin.extensions import RoIPool
+from scda_amd.dropin.models.faster_rcnn.faster_rcnn_adver_expansion_reweight_cluster import FasterRCNN_AdEx
+from scda_amd.dropin.models.head import NaiveRpnHead
+
+__all__ = ['ResNet', 'Bottleneck', 'resnet50', 'resnet101']
+
+
+class Bottleneck(nn.Module):
+    """1x1 - 3x3(stride) - 1x1(x4), each followed by BN (ReLU fused into the first two BN kernels), residual join = one kernel"""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = L.Conv2d(inplanes, planes, kernel_size=1, bias=False)
+        self.bn1 = L.BatchNorm2d(planes, fused_act=ACT_RELU)
+        self.conv2 = L.Conv2d(planes, planes, kernel_size=3, stride=stride, padding=1, bias=False)
+        self.bn2 = L.BatchNorm2d(planes, fused_act=ACT_RELU)
+        self.conv3 = L.Conv2d(planes, planes * 4, kernel_size=1, bias=False)
+        self.bn3 = L.BatchNorm2d(planes * 4)
+        self.relu = L.FusedAct("ReLU")
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        out = self.bn1(self.conv1(x))
+        out = self.bn2(self.conv2(out))
+        out = self.bn3(self.conv3(out))
+        residual = x if self.downsample is None else self.downsample(x)
+        return A.AddReluFn.apply(out, residual)
+
+
+class ResNet(FasterRCNN_AdEx):
+    def __init__(self, block, layers, cfg):
+        super().__init__(cfg.get('gan_model_flag', 2))
+        self.inplanes = 64
+        self.conv1 = L.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = L.BatchNorm2d(64, fused_act=ACT_RELU)
+        self.relu = L.FusedAct("ReLU")
+        self.maxpool = L.MaxPool3x3s2()
+        self.layer1 = self._make_layer(block, 64, layers[0])
+        self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
+        self.layer3 = self._make_layer(block, 256, layers[2], stride=2)
+        num_anchors = len(cfg['anchor_scales']) * len(cfg['anchor_ratios'])
+        self.rpn_head = NaiveRpnHead(1024, num_classes=2, num_anchors=num_anchors)
+        if cfg.get('roi_align', True):
+            self.roipooling = RoIAlignAvg(7, 7, 1.0 / cfg['anchor_stride'])
+        else:
+            self.roipooling = RoIPool(7, 7, 1.0 / cfg['anchor_stride'])
+        self.layer4 = self._make_layer(block, 512, layers[3], stride=1)     # "change stride to 1" (:140)
+        self.avgpool = L.GlobalAvgPool()                                     # AvgPool2d(7) on 7x7 maps
+        self.fc_rcnn_cls = L.Linear(512 * block.expansion, cfg['num_classes'])
+        self.fc_rcnn_loc = L.Linear(512 * block.expansion, cfg['num_classes'] * 4)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                n = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
+                m.weight.data.normal_(0, math.sqrt(2. / n))
+            elif isinstance(m, nn.BatchNorm2d):
+                m.weight.data.fill_(1)
+                m.bias.data.zero_()
+        for head, std in ((self.rpn_head, 0.01), (self.fc_rcnn_cls, 0.001), (self.fc_rcnn_loc, 0.001)):
+            for m in head.modules():
+                if isinstance(m, (nn.Conv2d, nn.Linear)):
+                    m.weight.data.normal_(0, std)
+        self.fix_layer_num = 1
+        self._fix_layer(self.fix_layer_num)
+
+    def _make_layer(self, block, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = nn.Sequential(L.Conv2d(self.inplanes, planes * block.expansion, kernel_size=1, stride=stride, bias=False),
+                                       L.BatchNorm2d(planes * block.expansion))
+        seq = [block(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes * block.expansion
+        seq += [block(self.inplanes, planes) for _ in range(1, blocks)]
+        return nn.Sequential(*seq)
+
+    def train(self, mode=True):
+        """the stem and the fixed layers stay in eval mode (their BN uses running statistics), :213-228"""
+        self.training = mode
+        for module in self.children():
+            module.train(mode)
+        self.conv1.eval()
+        self.bn1.eval()
+        for layer in [self.layer1, self.layer2, self.layer3, self.layer4][:self.fix_layer_num]:
+            layer.eval()
+        return self
+
+    def _fix_layer(self, layer_num):
+        for mod in [self.conv1, self.bn1] + [self.layer1, self.layer2, self.layer3, self.layer4][:layer_num]:
+            for p in mod.parameters():
+                p.requires_grad = False
+
+    def feature_extractor(self, x):
+        x = self.maxpool(self.bn1(self.conv1(x)))
+        return self.layer3(self.layer2(self.layer1(x)))
+
+    def rpn(self, x):
+        return self.rpn_head(x)
+
+    def rcnn(self, x, rois):
+        assert rois.shape[1] == 5
+        x = self.layer4(self.roipooling(x, rois))
+        x_fea = self.avgpool(x).view(x.size(0), -1)           # [R, 2048]
+        return x_fea, self.fc_rcnn_cls(x_fea), self.fc_rcnn_loc(x_fea)
+
+
+def resnet50(pretrained=False, **kwargs):
+    """kwargs: cfg=<the 'shared' section of the experiment json>"""
+    if pretrained:
+        raise RuntimeError("no network access: load weights with scda_amd.checkpoint.load_pretrain(model, path)")
+    return ResNet(Bottleneck, [3, 4, 6, 3], **kwargs)
+
+
+def resnet101(pretrained=False, **kwargs):
+    if pretrained:
+        raise RuntimeError("no network access: load weights with scda_amd.checkpoint.load_pretrain(model, path)")
+    return ResNet(Bottleneck, [3, 4, 23, 3], **kwargs)

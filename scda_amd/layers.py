@@ -83,6 +83,16 @@ class MaxPool2x2(nn.Module):
         return "kernel_size=2, stride=2"
 
 
+class MaxPool3x3s2(nn.Module):
+    """nn.MaxPool2d(kernel_size=3, stride=2, padding=1), forward only"""
+
+    def forward(self, x):
+        return A.MaxPool3x3s2Fn.apply(x.detach())
+
+    def extra_repr(self):
+        return "kernel_size=3, stride=2, padding=1"
+
+
 class Activation(nn.Module):
     def __init__(self, mode, slope=0.01):
         super().__init__()

@@ -499,6 +499,23 @@ def maxpool2x2_bwd(dy, idx, x_shape, relu_y=None):
     return dx
 
 
+def maxpool3x3s2_fwd(x):
+    _req(x, "x")
+    B, C, H, W = x.shape
+    y = torch.empty(B, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1, dtype=torch.float32, device=x.device)
+    _check(lib().scda_maxpool3x3s2_fwd_hip(_p(x), _p(y), i32(B * C), i32(H), i32(W), _stream()), "scda_maxpool3x3s2_fwd_hip")
+    return y
+
+
+def add_relu(a, b):
+    _req(a, "a"); _req(b, "b")
+    if a.shape != b.shape:
+        raise ValueError("add_relu: shape mismatch")
+    y = torch.empty_like(a)
+    _check(lib().scda_add_relu_hip(_p(a), _p(b), _p(y), i64(a.numel()), _stream()), "scda_add_relu_hip")
+    return y
+
+
 ACT_MODE = {"relu": 0, "leaky": 1, "tanh": 2, "sigmoid": 3}
 
 

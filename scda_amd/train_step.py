@@ -32,24 +32,27 @@ from .dropin.utils.distributed_utils import average_gradients
 
 def get_corner_from_center(center, recon_size, new_w, new_h):
     """recon_size x recon_size crop window around each cluster centre, pushed inside the new_w x new_h image;
-    int() truncation as in tools/faster_rcnn_train_val.py:411-438 -> list of [x1, y1, x2, y2]"""
-    half = recon_size // 2
+    int() truncation as in tools/faster_rcnn_train_val.py:411-438 -> list of [x1, y1, x2, y2].
+    recon_size may be (height, width) for a rectangular window (the ResNet configuration's 2048-d RoI features unfold to a
+    32 x 64 map, reconstructed as 128 x 256); the reference only has the square case."""
+    rh, rw = (recon_size, recon_size) if np.isscalar(recon_size) else recon_size
+    half_w, half_h = rw // 2, rh // 2
     boxes = []
     for cx, cy in np.asarray(center)[:, :2]:
-        x1 = max(int(cx) - half, 0)
-        y1 = max(int(cy) - half, 0)
+        x1 = max(int(cx) - half_w, 0)
+        y1 = max(int(cy) - half_h, 0)
         if x1 == 0:
-            x2 = recon_size
+            x2 = rw
         else:
-            x2 = min(int(cx) + half, new_w)
+            x2 = min(int(cx) + half_w, new_w)
             if x2 == new_w:
-                x1 = new_w - recon_size
+                x1 = new_w - rw
         if y1 == 0:
-            y2 = recon_size
+            y2 = rh
         else:
-            y2 = min(int(cy) + half, new_h)
+            y2 = min(int(cy) + half_h, new_h)
             if y2 == new_h:
-                y1 = new_h - recon_size
+                y1 = new_h - rh
         boxes.append([x1, y1, x2, y2])
     return boxes
 
@@ -62,7 +65,7 @@ def builder_gan(cluster_num=4, threshold=128, recon_size=256, neww=64, newh=64):
                   'n_gen_front_blk': size2layers[recon_size], 'res_dropout_ratio': 0.5, 'neww': neww, 'newh': newh,
                   'cluster_num': cluster_num, 'threshold': threshold}
     params_dis = {'input_dim_a': 3, 'input_dim_b': 3, 'ch': 32, 'n_gen_res_blk': 3, 'n_layer': size2layers[recon_size]}
-    params_patch = {'n_in': threshold, 'n_out': threshold * 2, 'cluster_num': cluster_num}
+    params_patch = {'n_in': threshold, 'n_out': threshold * 2, 'cluster_num': cluster_num, 'w': neww, 'h': newh}
     return GAN_dis_AE(params_dis), GAN_decoder_AE(params_dec), GAN_dis_AE_patch(params_patch)
 
 
@@ -79,9 +82,10 @@ def _hard(flag, shape, device):
 
 
 def _crops(img, corners, recon):
+    rh, rw = (recon, recon) if np.isscalar(recon) else recon
     out = []
     for x1, y1, x2, y2 in corners:
-        assert x2 - x1 == recon and y2 - y1 == recon, "crop window does not match recon_size"
+        assert x2 - x1 == rw and y2 - y1 == rh, "crop window does not match recon_size"
         out.append(img[:, :, y1:y2, x1:x2])
     return torch.cat(out, 0).contiguous()
 
@@ -103,11 +107,13 @@ class _Frozen:
 
 class ScdaTrainer:
     def __init__(self, cfg, device, lr=1.25e-5, cluster_num=4, threshold=128, recon_size=256, new_w=1024, new_h=512,
-                 weight_decay=1e-4, world_size=1, models=None):
+                 weight_decay=1e-4, world_size=1, models=None, recon_hw=None):
+        """recon_hw: (height, width) of the reconstructions / image crops when they are not recon_size x recon_size (a
+        detector whose RoI feature does not unfold to a square map: see scda_amd/resnet_config.py)"""
         self.cfg, self.device = cfg, device
         from .hostenv import configure_host_threads
         configure_host_threads()
-        self.cluster_num, self.threshold, self.recon = cluster_num, threshold, recon_size
+        self.cluster_num, self.threshold, self.recon = cluster_num, threshold, (recon_hw or recon_size)
         self.new_w, self.new_h, self.world_size = new_w, new_h, world_size
         if models is None:
             model = vgg16(pretrained=False, cfg=cfg['shared'])

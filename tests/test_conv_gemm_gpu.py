@@ -30,6 +30,8 @@ CONV_CASES = [
     (4, 128, 16, 16, 1, 1, 1, 0),     # 1x1 -> 1 channel
     (1, 512, 8, 16, 30, 1, 1, 0),     # RPN cls head
     (4, 32, 32, 32, 3, 1, 1, 0),      # decoder's final 1x1
+    (1, 64, 20, 28, 128, 1, 2, 0),    # ResNet down-sampling shortcut: 1x1 stride 2
+    (2, 256, 15, 21, 512, 1, 2, 0),   # ... odd extents, batch 2
 ]
 
 
@@ -82,6 +84,16 @@ def test_conv2d_wgrad_with_fused_bias_grad(cuda, case):
     close(dw, w.grad); close(db, b.grad, 2e-5)
     dw2, db2 = native.conv2d_wgrad_bias(dy.to(cuda), x.to(cuda), w.shape, s, p, out=dw.clone(), db_out=db.clone())
     close(dw2, 2 * w.grad); close(db2, 2 * b.grad, 2e-5)
+
+
+@pytest.mark.parametrize("shape", [(1, 3, 64, 96), (2, 3, 37, 53)])
+def test_conv7x7_stride2_stem_forward(cuda, shape):
+    """the ResNet stem (7x7, stride 2, padding 3, 3 -> 64): forward only, as the reference freezes it"""
+    from scda_amd import native
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(*shape, generator=g)
+    w = torch.randn(64, 3, 7, 7, generator=g) / 147 ** 0.5
+    close(native.conv2d_fwd(x.to(cuda), w.to(cuda), None, 2, 3), F.conv2d(x, w, None, stride=2, padding=3))
 
 
 def test_conv_identity_asymmetric(cuda):
