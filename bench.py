@@ -207,7 +207,7 @@ def main():
         if dominant in prof:
             n, tms, fl, by = prof[dominant]
             ach = fl / (tms * 1e-3) / 1e12
-            traffic, src = pmc_traffic()
+            traffic, src = pmc_traffic() if a.config == "vgg16" else (None, None)   # counter passes exist for the VGG configuration
             it_ach = f_iter * world * a.steps / dt
             roof = {"bound": "mfma", "kernel": dominant, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
@@ -228,7 +228,7 @@ def main():
                        if a.config == "vgg16" else
                        ("resnet50_FasterRCNN (C4, RoIAlignAvg, layer4 head) + 4-cluster SCDA, synthetic 800x1344, batch=1/GPU "
                         "(BASELINE.json configs[3]'s detector; no reference implementation exists: performance only)"),
-                       "image": [bh, bw], "gt_boxes": G, "rois": 512, "clusters": 4, "recon": 256, "parallelism": "dp%d" % world,
+                       "image": [bh, bw], "gt_boxes": G, "rois": 512, "clusters": 4, "recon": tr.recon, "parallelism": "dp%d" % world,
                        "iters_per_s": round(world * a.steps / dt, 3), "final_loss": round(float(out["loss"]), 4),
                        "images_per_step": "1 source (forward + backward) + 1 target (forward only: it carries no loss), per GPU",
                        "proposals_post_nms": {"source": tr.last_num_proposals[0], "target": tr.last_num_proposals[1], "quota": quota},
