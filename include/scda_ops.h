@@ -275,12 +275,13 @@ int scda_instnorm_fwd_hip(const float *x, float *y, float *mean, float *rstd, in
 int scda_instnorm_bwd_hip(const float *dy, const float *x, const float *mean, const float *rstd, float *dx, int planes,
                           int HW, int act, float slope, void *stream);
 /* nn.BatchNorm2d, training mode, with optional fused activation : common_net.py:214-223 */
+size_t scda_batchnorm_workspace_bytes(int B, int C, int HW);   /* 0: the one-workgroup-per-channel form needs none (ws may be NULL) */
 int scda_batchnorm_fwd_hip(const float *x, float *y, const float *gamma, const float *beta, float *running_mean,
                            float *running_var, float *save_mean, float *save_rstd, int B, int C, int HW, float eps,
-                           float momentum, int act, float slope, void *stream);
-int scda_batchnorm_bwd_hip(const float *dy, const float *x, const float *gamma, const float *beta,
-                           const float *save_mean, const float *save_rstd, float *dx /*may be NULL*/, float *dgamma,
-                           float *dbeta, int B, int C, int HW, int act, float slope, int accumulate, void *stream);
+                           float momentum, int act, float slope, float *ws, void *stream);
+int scda_batchnorm_bwd_hip(const float *dy, const float *x, const float *gamma, const float *beta, const float *save_mean,
+                           const float *save_rstd, float *dx, float *dgamma, float *dbeta, int B, int C, int HW, int act,
+                           float slope, int accumulate, float *ws, void *stream);
 /* nn.BatchNorm2d in eval mode (running statistics): out = act((x - mean) * rsqrt(var + eps) * gamma + beta); with dy given,
  * out = the gradient w.r.t. x instead (dy * act'(y) * gamma * rsqrt(var + eps); statistics and affine parameters are constants) */
 int scda_batchnorm_eval_hip(const float *x, const float *dy_or_null, float *out, const float *gamma, const float *beta,

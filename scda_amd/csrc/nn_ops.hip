@@ -607,6 +607,132 @@ __global__ __launch_bounds__(256) void batchnorm_bwd_kernel(const float *__restr
     }
 }
 
+// ---- the same, for maps large enough that one workgroup per channel leaves the chip idle (ResNet layer2/3 at 800 x 1344: 64-256
+// channels x 16800-67200 pixels): S slices per channel, statistics through per-slice partials (fixed summation order).
+//   fwd: bn_slice_sum -> bn_slice_sq (centred, as the one-kernel form) -> bn_slice_apply     bwd: bn_slice_grad_sums -> bn_slice_dx
+__device__ __forceinline__ size_t bn_at(const int j, const int c, const int C, const int HW) {
+    const int b = j / HW;
+    return ((size_t)b * C + c) * HW + (j - b * HW);
+}
+
+__global__ __launch_bounds__(256) void bn_slice_sum_kernel(const float *__restrict__ x, float *__restrict__ part, const int C,
+                                                           const int HW, const int BHW, const int S, const int per) {
+    __shared__ float red[16];
+    const int c = blockIdx.x / S, sl = blockIdx.x % S;
+    const int lo = sl * per, hi = min(BHW, lo + per);
+    float s = 0.f;
+    for (int j = lo + threadIdx.x; j < hi; j += blockDim.x) s += x[bn_at(j, c, C, HW)];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) part[(size_t)c * S + sl] = s;
+}
+
+__device__ __forceinline__ float bn_sum_parts(const float *__restrict__ part, const int c, const int S) {
+    float t = 0.f;
+    for (int i = 0; i < S; ++i) t += part[(size_t)c * S + i];
+    return t;
+}
+
+__global__ __launch_bounds__(256) void bn_slice_sq_kernel(const float *__restrict__ x, const float *__restrict__ part_sum,
+                                                          float *__restrict__ part_sq, const int C, const int HW, const int BHW,
+                                                          const int S, const int per) {
+    __shared__ float red[16];
+    const int c = blockIdx.x / S, sl = blockIdx.x % S;
+    const float mean = bn_sum_parts(part_sum, c, S) / (float)BHW;
+    const int lo = sl * per, hi = min(BHW, lo + per);
+    float v = 0.f;
+    for (int j = lo + threadIdx.x; j < hi; j += blockDim.x) { const float d = x[bn_at(j, c, C, HW)] - mean; v += d * d; }
+    v = block_sum(v, red);
+    if (threadIdx.x == 0) part_sq[(size_t)c * S + sl] = v;
+}
+
+__global__ __launch_bounds__(256) void bn_slice_apply_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                             const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                             float *__restrict__ run_mean, float *__restrict__ run_var,
+                                                             float *__restrict__ mean_out, float *__restrict__ rstd_out,
+                                                             const float *__restrict__ part_sum, const float *__restrict__ part_sq,
+                                                             const int C, const int HW, const int BHW, const int S, const int per,
+                                                             const float eps, const float momentum, const int act, const float slope) {
+    const int c = blockIdx.x / S, sl = blockIdx.x % S;
+    const float n = (float)BHW;
+    const float mean = bn_sum_parts(part_sum, c, S) / n, var = bn_sum_parts(part_sq, c, S) / n;
+    const float rstd = 1.f / sqrtf(var + eps), ga = gamma[c], be = beta[c];
+    const int lo = sl * per, hi = min(BHW, lo + per);
+    for (int j = lo + threadIdx.x; j < hi; j += blockDim.x) {
+        const size_t o_ = bn_at(j, c, C, HW);
+        float o = (x[o_] - mean) * rstd * ga + be;
+        if (act == 2) o = o > 0.f ? o : o * slope;
+        else if (act == 1) o = o > 0.f ? o : 0.f;
+        y[o_] = o;
+    }
+    if (sl == 0 && threadIdx.x == 0) {
+        mean_out[c] = mean; rstd_out[c] = rstd;
+        if (run_mean) {
+            run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean;
+            run_var[c] = (1.f - momentum) * run_var[c] + momentum * var * (n / (n - 1.f));
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_slice_grad_sums_kernel(const float *__restrict__ dy, const float *__restrict__ x,
+                                                                 const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                                 const float *__restrict__ mean_in, const float *__restrict__ rstd_in,
+                                                                 float *__restrict__ part, const int C, const int HW, const int BHW,
+                                                                 const int S, const int per, const int act, const float slope) {
+    __shared__ float red[16];
+    const int c = blockIdx.x / S, sl = blockIdx.x % S;
+    const float mean = mean_in[c], rstd = rstd_in[c], ga = gamma[c], be = beta[c];
+    const int lo = sl * per, hi = min(BHW, lo + per);
+    float s1 = 0.f, s2 = 0.f;
+    for (int j = lo + threadIdx.x; j < hi; j += blockDim.x) {
+        const size_t o_ = bn_at(j, c, C, HW);
+        const float xh = (x[o_] - mean) * rstd, pre = xh * ga + be;
+        float g = dy[o_];
+        if (act == 2) g = pre > 0.f ? g : g * slope;
+        else if (act == 1) g = pre > 0.f ? g : 0.f;
+        s1 += g; s2 += g * xh;
+    }
+    s1 = block_sum(s1, red); s2 = block_sum(s2, red);
+    if (threadIdx.x == 0) { part[(size_t)c * S + sl] = s1; part[(size_t)(C + c) * S + sl] = s2; }
+}
+
+__global__ __launch_bounds__(256) void bn_slice_dx_kernel(const float *__restrict__ dy, const float *__restrict__ x,
+                                                          const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                          const float *__restrict__ mean_in, const float *__restrict__ rstd_in,
+                                                          const float *__restrict__ part, float *__restrict__ dx,
+                                                          float *__restrict__ dgamma, float *__restrict__ dbeta, const int C,
+                                                          const int HW, const int BHW, const int S, const int per, const int act,
+                                                          const float slope, const int accumulate) {
+    const int c = blockIdx.x / S, sl = blockIdx.x % S;
+    const float n = (float)BHW;
+    const float mean = mean_in[c], rstd = rstd_in[c], ga = gamma[c], be = beta[c];
+    const float sum1 = bn_sum_parts(part, c, S), sum2 = bn_sum_parts(part, C + c, S);
+    const float m1 = sum1 / n, m2 = sum2 / n;
+    if (dx) {
+        const int lo = sl * per, hi = min(BHW, lo + per);
+        for (int j = lo + threadIdx.x; j < hi; j += blockDim.x) {
+            const size_t o_ = bn_at(j, c, C, HW);
+            const float xh = (x[o_] - mean) * rstd, pre = xh * ga + be;
+            float g = dy[o_];
+            if (act == 2) g = pre > 0.f ? g : g * slope;
+            else if (act == 1) g = pre > 0.f ? g : 0.f;
+            dx[o_] = ga * rstd * (g - m1 - xh * m2);
+        }
+    }
+    if (sl == 0 && threadIdx.x == 0) {
+        dgamma[c] = accumulate ? dgamma[c] + sum2 : sum2;
+        dbeta[c] = accumulate ? dbeta[c] + sum1 : sum1;
+    }
+}
+
+// slices per channel: enough workgroups for ~4 per CU, at least 4096 elements each
+static int bn_slices(int B, int C, int HW) {
+    const long long bhw = (long long)B * HW;
+    long long s = 1024 / (C > 0 ? C : 1);
+    if (s * 4096 > bhw) s = bhw / 4096;
+    if (s > 64) s = 64;
+    return s < 2 ? 1 : (int)s;
+}
+
 // nn.BatchNorm2d in EVAL mode (running statistics; validation of the vgg16_bn detector, dis_patch.eval()): a per-channel
 // affine map, HBM-bound (8 B / element).  One float4 per thread where the plane size allows.  The backward (w.r.t. x only:
 // statistics and affine parameters are constants in eval mode) is dx = dy * act'(y) * gamma * rstd.
@@ -737,6 +863,17 @@ __global__ __launch_bounds__(256) void gap_fwd_kernel(const float *__restrict__ 
     for (int i = threadIdx.x; i < HW; i += blockDim.x) s += x[(size_t)blockIdx.x * HW + i];
     s = block_sum(s, red);
     if (threadIdx.x == 0) y[blockIdx.x] = s / (float)HW;
+}
+
+// small planes (7 x 7 RoI maps x 2048 channels x 512 RoIs = 1 M planes): one THREAD per plane instead of one workgroup
+__global__ __launch_bounds__(256) void gap_fwd_small_kernel(const float *__restrict__ x, float *__restrict__ y, const long long planes,
+                                                            const int HW) {
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < planes; p += (long long)blockDim.x * gridDim.x) {
+        const float *src = x + p * HW;
+        float s = 0.f;
+        for (int i = 0; i < HW; ++i) s += src[i];
+        y[p] = s / (float)HW;
+    }
 }
 
 __global__ __launch_bounds__(256) void gap_bwd_kernel(const float *__restrict__ dy, float *__restrict__ dx,
@@ -1004,10 +1141,27 @@ SCDA_API int scda_instnorm_bwd_hip(const float *dy, const float *x, const float 
     return launch_status("instnorm_bwd_kernel");
 }
 
+SCDA_API size_t scda_batchnorm_workspace_bytes(int B, int C, int HW) {
+    const int S = bn_slices(B, C, HW);
+    return S > 1 ? (size_t)2 * C * S * sizeof(float) : 0;
+}
+
 SCDA_API int scda_batchnorm_fwd_hip(const float *x, float *y, const float *gamma, const float *beta, float *running_mean,
                                     float *running_var, float *save_mean, float *save_rstd, int B, int C, int HW,
-                                    float eps, float momentum, int act, float slope, void *stream) {
+                                    float eps, float momentum, int act, float slope, float *ws, void *stream) {
     NN_CHECK(x && y && gamma && beta && save_mean && save_rstd && B > 0 && C > 0 && HW > 0, "scda_batchnorm_fwd_hip")
+    const int S = bn_slices(B, C, HW);
+    if (S > 1) {
+        NN_CHECK(ws, "scda_batchnorm_fwd_hip (workspace)")
+        const int BHW = B * HW, per = (BHW + S - 1) / S;
+        hipStream_t st = as_stream(stream);
+        float *psum = ws, *psq = ws + (size_t)C * S;
+        hipLaunchKernelGGL(bn_slice_sum_kernel, dim3(C * S), dim3(256), 0, st, x, psum, C, HW, BHW, S, per);
+        hipLaunchKernelGGL(bn_slice_sq_kernel, dim3(C * S), dim3(256), 0, st, x, psum, psq, C, HW, BHW, S, per);
+        hipLaunchKernelGGL(bn_slice_apply_kernel, dim3(C * S), dim3(256), 0, st, x, y, gamma, beta, running_mean, running_var, save_mean,
+                           save_rstd, psum, psq, C, HW, BHW, S, per, eps, momentum, act, slope);
+        return launch_status("bn_slice kernels");
+    }
     hipLaunchKernelGGL(batchnorm_fwd_kernel, dim3(C), dim3(256), 0, as_stream(stream), x, y, gamma, beta, running_mean, running_var,
                        save_mean, save_rstd, B, C, HW, eps, momentum, act, slope);
     return launch_status("batchnorm_fwd_kernel");
@@ -1016,8 +1170,19 @@ SCDA_API int scda_batchnorm_fwd_hip(const float *x, float *y, const float *gamma
 SCDA_API int scda_batchnorm_bwd_hip(const float *dy, const float *x, const float *gamma, const float *beta,
                                     const float *save_mean, const float *save_rstd, float *dx, float *dgamma,
                                     float *dbeta, int B, int C, int HW, int act, float slope, int accumulate,
-                                    void *stream) {
+                                    float *ws, void *stream) {
     NN_CHECK(dy && x && gamma && beta && save_mean && save_rstd && dgamma && dbeta && B > 0 && C > 0 && HW > 0, "scda_batchnorm_bwd_hip")
+    const int S = bn_slices(B, C, HW);
+    if (S > 1) {
+        NN_CHECK(ws, "scda_batchnorm_bwd_hip (workspace)")
+        const int BHW = B * HW, per = (BHW + S - 1) / S;
+        hipStream_t st = as_stream(stream);
+        hipLaunchKernelGGL(bn_slice_grad_sums_kernel, dim3(C * S), dim3(256), 0, st, dy, x, gamma, beta, save_mean, save_rstd, ws, C, HW, BHW,
+                           S, per, act, slope);
+        hipLaunchKernelGGL(bn_slice_dx_kernel, dim3(C * S), dim3(256), 0, st, dy, x, gamma, beta, save_mean, save_rstd, ws, dx, dgamma, dbeta,
+                           C, HW, BHW, S, per, act, slope, accumulate);
+        return launch_status("bn_slice backward kernels");
+    }
     hipLaunchKernelGGL(batchnorm_bwd_kernel, dim3(C), dim3(256), 0, as_stream(stream), dy, x, gamma, beta, save_mean, save_rstd, dx,
                        dgamma, dbeta, B, C, HW, act, slope, accumulate);
     return launch_status("batchnorm_bwd_kernel");
@@ -1066,7 +1231,10 @@ SCDA_API int scda_bce_bwd_hip(const float *p, const float *t, int n, const float
 
 SCDA_API int scda_gap_fwd_hip(const float *x, float *y, int planes, int HW, void *stream) {
     NN_CHECK(x && y && planes > 0 && HW > 0, "scda_gap_fwd_hip")
-    hipLaunchKernelGGL(gap_fwd_kernel, dim3(planes), dim3(256), 0, as_stream(stream), x, y, HW);
+    if (HW <= 64 && planes >= 4096)
+        hipLaunchKernelGGL(gap_fwd_small_kernel, dim3(ew_grid(planes)), dim3(256), 0, as_stream(stream), x, y, (long long)planes, HW);
+    else
+        hipLaunchKernelGGL(gap_fwd_kernel, dim3(planes), dim3(256), 0, as_stream(stream), x, y, HW);
     return launch_status("gap_fwd_kernel");
 }
 

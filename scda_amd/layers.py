@@ -191,13 +191,34 @@ class BatchNorm2d(nn.BatchNorm2d):
             return A.BatchNormEvalFn.apply(x, self.weight.detach(), self.bias.detach(), self.running_mean, self.running_var,
                                            self.eps, self.fused_act, self.slope)
         if self.num_batches_tracked is not None:
-            self.num_batches_tracked.add_(1)
+            self._nbt_pending = getattr(self, "_nbt_pending", 0) + 1    # counted on the host, written into the buffer when it is read
         if A.replay is not None and self.fused_act != A.ACT_NONE:   # parity tests: see InstanceNorm2d
             y = A.BatchNormTrainFn.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
                                          self.momentum, A.ACT_NONE, self.slope)
             return A.ActFn.apply(y, 0 if self.fused_act == A.ACT_RELU else 1, self.slope)
         return A.BatchNormTrainFn.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
                                         self.momentum, self.fused_act, self.slope)
+
+
+def _flush_nbt(module):
+    n = getattr(module, "_nbt_pending", 0)
+    if n and module.num_batches_tracked is not None:
+        module.num_batches_tracked.add_(n)
+    module._nbt_pending = 0
+
+
+def _bn_state_dict(self, *args, **kw):
+    _flush_nbt(self)
+    return nn.BatchNorm2d.state_dict(self, *args, **kw)
+
+
+def _bn_save(self, destination, prefix, keep_vars):
+    _flush_nbt(self)            # num_batches_tracked += 1 per forward would be one tiny device kernel per BN layer and call
+    return nn.BatchNorm2d._save_to_state_dict(self, destination, prefix, keep_vars)
+
+
+BatchNorm2d._save_to_state_dict = _bn_save
+BatchNorm2d.state_dict = _bn_state_dict
 
 
 class Upsample2x(nn.Module):

@@ -690,14 +690,22 @@ def instnorm_bwd(dy, x, mean, rstd, act, slope):
     return dx
 
 
+def _bn_ws(B, C, HW, device):
+    L = lib()
+    L.scda_batchnorm_workspace_bytes.restype = ctypes.c_size_t
+    n = L.scda_batchnorm_workspace_bytes(i32(B), i32(C), i32(HW))
+    return torch.empty(n // 4, dtype=torch.float32, device=device) if n else None
+
+
 def batchnorm_fwd(x, gamma, beta, run_mean, run_var, eps, momentum, act, slope):
     _req(x, "x"); _req(gamma, "gamma"); _req(beta, "beta")
     B, C, H, W = x.shape
     y = torch.empty_like(x)
     mean = torch.empty(C, dtype=torch.float32, device=x.device)
     rstd = torch.empty(C, dtype=torch.float32, device=x.device)
+    ws = _bn_ws(B, C, H * W, x.device)
     _check(lib().scda_batchnorm_fwd_hip(_p(x), _p(y), _p(gamma), _p(beta), _p(run_mean), _p(run_var), _p(mean), _p(rstd), i32(B), i32(C),
-                                        i32(H * W), f32(eps), f32(momentum), i32(act), f32(slope), _stream()), "scda_batchnorm_fwd_hip")
+                                        i32(H * W), f32(eps), f32(momentum), i32(act), f32(slope), _p(ws), _stream()), "scda_batchnorm_fwd_hip")
     return y, mean, rstd
 
 
@@ -709,8 +717,8 @@ def batchnorm_bwd(dy, x, gamma, beta, mean, rstd, act, slope, need_dx=True, out=
     dg, db = out if out is not None else (torch.empty(C, dtype=torch.float32, device=x.device),
                                           torch.empty(C, dtype=torch.float32, device=x.device))
     _check(lib().scda_batchnorm_bwd_hip(_p(dy), _p(x), _p(gamma), _p(beta), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db), i32(B), i32(C),
-                                        i32(H * W), i32(act), f32(slope), i32(0 if out is None else 1), _stream()),
-           "scda_batchnorm_bwd_hip")
+                                        i32(H * W), i32(act), f32(slope), i32(0 if out is None else 1), _p(_bn_ws(B, C, H * W, x.device)),
+                                        _stream()), "scda_batchnorm_bwd_hip")
     return dx, dg, db
 
 

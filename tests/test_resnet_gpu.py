@@ -25,7 +25,7 @@ def test_maxpool_3x3_stride2(cuda, shape):
     assert torch.equal(native.maxpool3x3s2_fwd(x.to(cuda)).cpu(), F.max_pool2d(x, 3, 2, 1))
 
 
-@pytest.mark.parametrize("shape", [(512, 32, 7, 7), (1, 16, 50, 84)])
+@pytest.mark.parametrize("shape", [(512, 32, 7, 7), (1, 16, 50, 84), (1, 64, 100, 168), (2, 8, 200, 336)])
 def test_batch_norm_train_on_roi_shaped_input(cuda, shape):
     """the (image, pixel) index space of a channel is walked as one range: 512 RoIs x 7 x 7 (layer4) and 1 x 50 x 84"""
     from scda_amd import autograd_ops as A
