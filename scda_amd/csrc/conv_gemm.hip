@@ -1371,6 +1371,7 @@ SCDA_API int scda_conv2d_dgrad_act_hip(const float *dy, const float *wt, float *
     g.dPHW = Div(IH * IW); g.dPW = Div(IW); g.dCB = Div(Cout);
     g.slab_aligned = (Cout % BK) == 0;
     g.zp = zero_page();
+    if (!g.zp) { set_error("scda_conv2d_dgrad_hip: could not allocate the zero page"); return SCDA_ELAUNCH; }
     Epi e{dx, nullptr, nullptr, 0, (int)ACT_NONE, 0.f, 1, 0, act_src, act_slope};
     CONV_DISPATCH(launch_conv, , true > (wt, dy, g, e, (float *)ws, ws_bytes, as_stream(stream)))
 }

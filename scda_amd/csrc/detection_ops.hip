@@ -8,6 +8,7 @@
 #include <float.h>
 #include <stdarg.h>
 
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -24,6 +25,7 @@ void set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
+// nullptr if the allocation fails: every caller checks and returns SCDA_ELAUNCH (the gathers would dereference it)
 const float *zero_page() {
     static const float *pages[64] = {nullptr};
     int dev = 0;
@@ -47,18 +49,25 @@ static hipEvent_t prof_event() {
     (void)hipEventCreate(&e);
     return e;
 }
-static bool g_prof_open = false;
+// Launches come from two host threads (the Python main thread and autograd's backward thread): the record list is guarded by a
+// mutex, and "which record does this thread's prof_end() close" is per thread (a begin on one thread can no longer be closed by an
+// end on the other).
+static std::mutex g_prof_mu;
+static thread_local long g_prof_open = -1;   // index of the record this thread opened, or -1
 void prof_begin(int kernel, double flops, hipStream_t st, double bytes) {
-    g_prof_open = (g_prof_mask >> kernel) & 1u;
-    if (!g_prof_open) return;
+    g_prof_open = -1;
+    if (!((g_prof_mask >> kernel) & 1u)) return;
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     ProfRec r{kernel, flops, bytes, prof_event(), prof_event()};
     (void)hipEventRecord(r.a, st);
     g_prof.push_back(r);
+    g_prof_open = (long)g_prof.size() - 1;
 }
 void prof_end(hipStream_t st) {
-    if (!g_prof_open || g_prof.empty()) return;
-    g_prof_open = false;
-    (void)hipEventRecord(g_prof.back().b, st);
+    if (g_prof_open < 0) return;
+    std::lock_guard<std::mutex> lock(g_prof_mu);
+    if ((size_t)g_prof_open < g_prof.size()) (void)hipEventRecord(g_prof[g_prof_open].b, st);
+    g_prof_open = -1;
 }
 
 // ---------------------------------------------------------------------------
@@ -690,6 +699,7 @@ SCDA_API const char *scda_prof_kernel_name(int k) {
 }
 SCDA_API int scda_prof_collect(long long *launches, double *ms, double *flops, double *bytes) {
     for (int k = 0; k < PK_COUNT; ++k) { launches[k] = 0; ms[k] = 0; flops[k] = 0; if (bytes) bytes[k] = 0; }
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     for (auto &r : g_prof) {
         float t = 0.f;
         if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) {
