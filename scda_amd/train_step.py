@@ -107,9 +107,14 @@ class _Frozen:
 
 class ScdaTrainer:
     def __init__(self, cfg, device, lr=1.25e-5, cluster_num=4, threshold=128, recon_size=256, new_w=1024, new_h=512,
-                 weight_decay=1e-4, world_size=1, models=None, recon_hw=None):
+                 weight_decay=1e-4, world_size=1, models=None, recon_hw=None, reference_style=False):
         """recon_hw: (height, width) of the reconstructions / image crops when they are not recon_size x recon_size (a
-        detector whose RoI feature does not unfold to a square map: see scda_amd/resnet_config.py)"""
+        detector whose RoI feature does not unfold to a square map: see scda_amd/resnet_config.py).
+        reference_style: run the iteration the way the reference's own driver would on top of the drop-in modules -- four
+        `torch.optim.Adam` instances over plain parameter lists (tools/faster_rcnn_train_val.py:305-316), phases strictly in
+        program order on one stream, detector backward last, `average_gradients(model)` per phase -- so that the cost of NOT
+        using this repository's step (flat buckets + fused Adam, early backward, side streams) can be measured
+        (scripts/bench_reference_style.py)."""
         self.cfg, self.device = cfg, device
         from .hostenv import configure_host_threads
         configure_host_threads()
@@ -123,21 +128,26 @@ class ScdaTrainer:
         self.model, self.dec, self.dis, self.dis_patch = (m.to(device) for m in (model, dec, dis, dis_patch))
         for m in (self.model, self.dec, self.dis, self.dis_patch):
             m.train()
-        self.flat = {k: FlatParams(m) for k, m in (("det", self.model), ("dec", self.dec), ("dis", self.dis),
-                                                   ("dis_patch", self.dis_patch))}
-        self.opt = {k: FlatAdam(f, lr, betas=(0.9, 0.999), weight_decay=weight_decay) for k, f in self.flat.items()}
+        named = (("det", self.model), ("dec", self.dec), ("dis", self.dis), ("dis_patch", self.dis_patch))
+        if reference_style:
+            self.flat = {}
+            self.opt = {k: torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr, betas=(0.9, 0.999),
+                                            weight_decay=weight_decay) for k, m in named}
+        else:
+            self.flat = {k: FlatParams(m) for k, m in named}
+            self.opt = {k: FlatAdam(f, lr, betas=(0.9, 0.999), weight_decay=weight_decay) for k, f in self.flat.items()}
         self._warmup = None          # per-iteration schedulers while warming up (begin_warmup / end_warmup)
         self._epoch_sched = None     # per-epoch MultiStepLR (set_epoch_schedule / begin_epoch)
         self.capture = False   # debugging / parity tests: keep a copy of each phase's gradients in self.trace
         self.trace = {}        # ... as computed by this rank, and in self.trace_reduced after the all-reduce (world_size > 1)
         self.trace_reduced = {}
         # scheduling: detector backward enqueued as soon as its losses exist; target branch on a high-priority side stream
-        self.early_backward = True
+        self.early_backward = not reference_style
         self.side = torch.cuda.Stream(device=device, priority=-1) if device.type == "cuda" else None
-        if os.environ.get("SCDA_SIDE_STREAM", "1") == "0":
+        if os.environ.get("SCDA_SIDE_STREAM", "1") == "0" or reference_style:
             self.side = None
         # the B halves of the decoder / image discriminator run beside their A halves (SCDA_AB_STREAMS=0: one stream)
-        if device.type == "cuda" and os.environ.get("SCDA_AB_STREAMS", "1") != "0":
+        if device.type == "cuda" and os.environ.get("SCDA_AB_STREAMS", "1") != "0" and not reference_style:
             self.branch = torch.cuda.Stream(device=device)
             self.dec.branch_stream = self.branch
             self.dis.branch_stream = self.branch
