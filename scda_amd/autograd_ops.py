@@ -117,7 +117,8 @@ class LinearFn(Function):
             dx = N.linear_dgrad(dy, w)
         if ctx.needs_input_grad[1]:
             sink = _sink(ctx.w_ref)
-            dw = N.linear_wgrad(dy, x, out=sink)
+            fresh = sink is not None and ctx.w_ref._scda_flat.take_fresh(ctx.w_ref)   # lazily-zeroed FC6 / FC7 slice: overwrite
+            dw = N.linear_wgrad(dy, x, out=sink, accumulate=not fresh)
             if sink is not None:
                 dw = None
         if ctx.has_bias and ctx.needs_input_grad[2]:

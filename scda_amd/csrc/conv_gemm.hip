@@ -1484,6 +1484,10 @@ SCDA_API int scda_gemm_hip(const float *A, const float *B, float *C, int M, int 
                xcd_swizzle_enabled()};
     if (!g.zp) { set_error("scda_gemm_hip: could not allocate the zero page"); return SCDA_ELAUNCH; }
     splits = cdiv(K, g.k_per_split);
+    static const bool no_mpart = getenv("SCDA_GEMM_NO_MPART") != nullptr;   // A/B knob
+    // the A operand does not fit one XCD's L2 but an eighth of it does: partition the M-tiles over the XCDs (see tile_coords)
+    if (!no_mpart && g.swz && splits == 1 && (g.ny % 8) == 0 && (long long)g.nx * g.ny >= 2048 && (double)M * K * sizeof(float) > 4e6)
+        g.swz |= 2;
     Epi e{C, (float *)ws, bias, bias_on_n, act, slope, splits, accumulate, nullptr, 0.f};
     dim3 grid((unsigned)g.nx * g.ny * splits);
 #define GEMM_LAUNCH(BM_, BN_)                                                                            \

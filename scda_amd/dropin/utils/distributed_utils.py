@@ -41,6 +41,7 @@ def average_gradients(model, async_op=False):
         flat = FlatParams(model, keep_grads=True)
     else:
         flat.check_aliases()
+        flat.finalize_grads()
     return dist.all_reduce(flat.grad, async_op=async_op)
 
 

@@ -36,6 +36,12 @@ class FlatParams:
             p.grad = self.grad[off:off + n].view_as(p.data)
             off += sz
         self.numel = total
+        # Large dense weights (FC6: 411 MB, FC7: 67 MB) are not zero-filled before a backward pass: their one weight-gradient GEMM
+        # per phase OVERWRITES its slice instead of zero-fill + read-modify-write (-0.9 GB of HBM traffic per detector phase).
+        # `fresh` holds those whose slice still contains last phase's values; whoever writes first takes the token
+        # (autograd_ops.LinearFn), and finalize_grads() zero-fills what nobody wrote before anything reads the bucket.
+        self.lazy = [p for p in params if p.dim() == 2 and p.numel() >= (8 << 20)]
+        self.fresh = set()
         self.epoch = 0   # bumped by the optimiser after each step: invalidates packed-weight caches of THESE parameters only
         for p in params:
             p._scda_flat = self
@@ -66,8 +72,41 @@ class FlatParams:
                     view.zero_()
                 p.grad = view
 
+    def take_fresh(self, p):
+        """True exactly once per phase for a lazily-zeroed parameter: the caller must then OVERWRITE p.grad, not accumulate"""
+        if id(p) in self.fresh:
+            self.fresh.discard(id(p))
+            return True
+        return False
+
+    def finalize_grads(self):
+        """before the bucket is read as a whole (all-reduce, optimiser step, tests): zero what no backward kernel wrote"""
+        if self.fresh:
+            for p in self.lazy:
+                if id(p) in self.fresh:
+                    p.grad.zero_()
+            self.fresh.clear()
+
     def zero_grad(self):
-        self.grad.zero_()
+        if self.lazy:
+            base, edges = self.grad.data_ptr(), [0]
+            for p in self.lazy:
+                off = (p.grad.data_ptr() - base) // 4 if self._inside(p.grad, self.grad) else None
+                if off is None:
+                    edges = None
+                    break
+                edges += [off, off + p.numel()]
+            if edges is None:
+                self.grad.zero_()
+                self.fresh = set()
+            else:
+                edges.append(self.numel)
+                for a, b in zip(edges[0::2], edges[1::2]):
+                    if b > a:
+                        self.grad[a:b].zero_()
+                self.fresh = {id(p) for p in self.lazy}
+        else:
+            self.grad.zero_()
         for p in self.params:  # re-attach views if something replaced .grad (e.g. zero_grad(set_to_none=True))
             if not self._inside(p.grad, self.grad):
                 off = (p.data.data_ptr() - self.data.data_ptr()) // 4
@@ -147,6 +186,7 @@ class FlatAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         self.flat.check_aliases()
+        self.flat.finalize_grads()
         g = self.param_groups[0]
         st = self.state[self.bucket]
         n = int(st["step"]) + 1

@@ -464,11 +464,11 @@ def linear_dgrad(dy, w):
     return gemm(dy, w, M, N, K, K, N, False, True)
 
 
-def linear_wgrad(dy, x, out=None):
-    """dw[out,in] (+)= dy[M,out]^T @ x[M,in]"""
+def linear_wgrad(dy, x, out=None, accumulate=True):
+    """dw[out,in] (+)= dy[M,out]^T @ x[M,in]; with `out`: accumulates into it unless accumulate=False (overwrite)"""
     Kb, M = dy.shape
     N = x.shape[1]
-    return gemm(dy, x, M, N, Kb, M, N, True, True, out=out, accumulate=out is not None)
+    return gemm(dy, x, M, N, Kb, M, N, True, True, out=out, accumulate=out is not None and accumulate)
 
 
 # ------------------------------------------------------ layer kernels -------

@@ -201,6 +201,9 @@ class ScdaTrainer:
 
     def _reduce(self, module, async_op):
         self._join_branch()
+        flat = getattr(module, "_scda_flat", None)
+        if flat is not None:
+            flat.finalize_grads()      # lazily-zeroed slices nobody wrote this phase (see FlatParams.lazy)
         if self.capture:
             name = {id(self.model): 'det', id(self.dec): 'dec', id(self.dis): 'dis', id(self.dis_patch): 'dis_patch'}[id(module)]
             self.trace[name] = {k: p.grad.detach().clone() for k, p in module.named_parameters()}

@@ -350,3 +350,31 @@ def test_act_fusion_plan_gives_identical_gradients(cuda):
         assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
         for a, b in zip(outs[0][2], outs[1][2]):
             assert torch.equal(a, b)
+
+
+def test_lazily_zeroed_dense_gradients(cuda):
+    """FlatParams does not zero-fill large 2-D weights (FC6 / FC7 class, >= 8 M elements) before a backward pass: the first weight-
+    gradient GEMM of the phase overwrites the slice, later ones accumulate, and finalize_grads() zeroes what nobody wrote.
+    Gradients must equal the plain zero-fill + accumulate result bit for bit, phase after phase."""
+    from scda_amd import layers as L
+    from scda_amd.flat import FlatParams
+    torch.manual_seed(5)
+    net = torch.nn.Sequential(L.Linear(4096, 2048), L.Linear(2048, 16)).to(cuda)     # 8.4 M-element weight: lazy; the rest: eager
+    flat = FlatParams(net)
+    assert [tuple(p.shape) for p in flat.lazy] == [(2048, 4096)]
+    x1 = torch.randn(64, 4096, generator=gen(81)).to(cuda); x2 = torch.randn(64, 4096, generator=gen(82)).to(cuda)
+    for phase in range(3):
+        flat.zero_grad()
+        assert flat.fresh
+        if phase == 2:                      # a phase in which the big weight gets NO gradient: finalize must clear the stale values
+            flat.finalize_grads()
+            assert float(net[0].weight.grad.abs().sum()) == 0.0
+            continue
+        net(x1).square().sum().backward()
+        net(x2).sum().backward()            # second contribution of the same phase accumulates
+        assert not flat.fresh
+        w = net[0].weight.detach().clone().requires_grad_(); b = net[0].bias.detach().clone().requires_grad_()
+        w2 = net[1].weight.detach().clone().requires_grad_(); b2 = net[1].bias.detach().clone().requires_grad_()
+        ref = lambda x: F.linear(F.linear(x, w, b), w2, b2)  # noqa: E731
+        (ref(x1).square().sum() + ref(x2).sum()).backward()
+        close(net[0].weight.grad, w.grad, 2e-5); close(net[1].weight.grad, w2.grad, 2e-5); close(net[0].bias.grad, b.grad, 2e-5)
