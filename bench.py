@@ -174,7 +174,15 @@ def main():
     precond = 0
     for _ in range(a.warmup):
         tr.step(src, gts, info, tgt)
-    while min(tr.last_num_proposals) < quota and precond < 40:   # realistic proposal sets before timing
+    def short_of_quota():
+        """any rank still below the post-NMS quota?  (decided collectively: every step contains all-reduces, so all ranks must
+        run the same number of pre-conditioning steps)"""
+        flag = torch.tensor([1 if min(tr.last_num_proposals) < quota else 0], dtype=torch.int32, device=dev)
+        if world > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        return bool(flag.item())
+
+    while precond < 40 and short_of_quota():   # SURVEY.md 8(d): realistic proposal sets before timing
         tr.step(src, gts, info, tgt)
         precond += 1
     torch.cuda.synchronize()
