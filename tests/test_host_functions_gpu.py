@@ -56,3 +56,48 @@ def test_predict_bbox_matches_reference_on_device(cuda, golden_dir):
     from scda_amd.dropin import backend
     backend.reset()
     check_predict(golden_dir)
+
+
+@pytest.mark.parametrize("case", ["one_gt", "few_candidates", "nothing_survives_min_size", "all_candidates", "tiny_gt_no_anchor"])
+def test_device_box_logic_equals_numpy_path_on_edge_cases(cuda, case, monkeypatch):
+    """the device-resident kernels against THIS repository's numpy path (itself pinned to the reference's vectors) where the
+    fixtures do not reach: a single ground-truth box, fewer candidates than the post-NMS quota, no box passing the size test
+    (empty result), pre_nms_top_n <= 0 (all 30720 anchors ranked), a gt so small that no anchor reaches IoU 0.1"""
+    import copy
+    import numpy as np
+    import torch
+    from test_host_functions import CFG, synth_rpn_outputs
+    from scda_amd.dropin.functions.anchor_target import compute_anchor_targets
+    from scda_amd.dropin.functions.rpn_proposal import compute_rpn_proposals
+    cfg_a, cfg_p = copy.deepcopy(CFG["train_anchor_target_cfg"]), copy.deepcopy(CFG["train_rpn_proposal_cfg"])
+    gts = np.array([[[100, 80, 400, 300, 3], [600, 200, 900, 480, 5], [30, 300, 200, 500, 1]]], dtype=np.float32)
+    if case == "one_gt":
+        gts = gts[:, :1]
+    elif case == "tiny_gt_no_anchor":
+        gts = np.array([[[500, 250, 503, 252, 2], [100, 80, 400, 300, 3]]], dtype=np.float32)
+    elif case == "few_candidates":
+        cfg_p["pre_nms_top_n"] = 50
+    elif case == "nothing_survives_min_size":
+        cfg_p["roi_min_size"] = 5000
+    elif case == "all_candidates":
+        cfg_p["pre_nms_top_n"] = 0
+        cfg_p["post_nms_top_n"] = 300
+    info = torch.tensor([[512, 1024, 1.0]])
+    cls, loc = synth_rpn_outputs(77)
+    out = {}
+    for dev_boxes in ("1", "0"):
+        monkeypatch.setenv("SCDA_DEVICE_BOXES", dev_boxes)
+        g = torch.from_numpy(gts).to(cuda)
+        g._scda_host = gts
+        np.random.seed(5)
+        ct, lt, lm, norm = compute_anchor_targets((1, 60, 32, 64), cfg_a, g, info, None)
+        props = compute_rpn_proposals(cls.to(cuda), loc.to(cuda), cfg_p, info)
+        out[dev_boxes] = (ct.cpu(), lt.cpu(), lm.cpu(), norm, props.cpu(), np.random.rand())
+    a, b = out["1"], out["0"]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and a[3] == b[3]
+    assert a[4].shape == b[4].shape and torch.equal(a[4], b[4])
+    assert a[5] == b[5]                       # the numpy generator ended in the same state: same draws were made
+    if case == "nothing_survives_min_size":
+        assert tuple(a[4].shape) == (0, 6)
+    if case == "few_candidates":
+        assert 0 < a[4].shape[0] <= 50
