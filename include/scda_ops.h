@@ -293,6 +293,10 @@ int scda_upsample2x_bwd_hip(const float *dy, float *dx, int planes, int IH, int 
 /* F.binary_cross_entropy(p, t), mean : tools/faster_rcnn_train_val.py:584-600,627-628,675-687,723-732 */
 int scda_bce_fwd_hip(const float *p, const float *t, int n, float *out1, void *stream);
 int scda_bce_bwd_hip(const float *p, const float *t, int n, const float *grad_scalar, float *dp, void *stream);
+/* F.avg_pool2d(kernel_size=2, stride=1) of [planes, H+1, W+1] -> [planes, H, W] and its gradient: the pooling half of RoIAlignAvg
+ * (extensions/_roi_align/modules/roi_align.py:18-30) */
+int scda_avg2x2s1_fwd_hip(const float *x, float *y, int planes, int H, int W, void *stream);
+int scda_avg2x2s1_bwd_hip(const float *dy, float *dx, int planes, int H, int W, void *stream);
 /* nn.AvgPool2d(full extent) and torch.mean(x, 1) */
 int scda_gap_fwd_hip(const float *x, float *y, int planes, int HW, void *stream);
 int scda_gap_bwd_hip(const float *dy, float *dx, int planes, int HW, void *stream);

@@ -303,6 +303,18 @@ class RoIAlignFn(Function):
         return N.roi_align_bwd(_c(dy), rois, shape, ah, aw, scale), None, None, None, None
 
 
+class Avg2x2S1Fn(Function):
+    """F.avg_pool2d(x, kernel_size=2, stride=1) -- the pooling half of RoIAlignAvg, one kernel each way"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return N.avg2x2s1_fwd(_c(x))
+
+    @staticmethod
+    def backward(ctx, dy):
+        return N.avg2x2s1_bwd(_c(dy))
+
+
 class SoftmaxCEFn(Function):
     """F.cross_entropy(logits, targets, ignore_index) -> 0-dim loss"""
 

@@ -865,14 +865,51 @@ __global__ __launch_bounds__(256) void gap_fwd_kernel(const float *__restrict__ 
     if (threadIdx.x == 0) y[blockIdx.x] = s / (float)HW;
 }
 
-// small planes (7 x 7 RoI maps x 2048 channels x 512 RoIs = 1 M planes): one THREAD per plane instead of one workgroup
+// small planes (7 x 7 RoI maps x 2048 channels x 512 RoIs = 1 M planes): a workgroup takes 256 consecutive planes, streams their
+// (contiguous) elements through LDS with coalesced loads, then one thread sums one plane (stride HW in LDS: conflict-free for odd HW)
 __global__ __launch_bounds__(256) void gap_fwd_small_kernel(const float *__restrict__ x, float *__restrict__ y, const long long planes,
                                                             const int HW) {
-    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < planes; p += (long long)blockDim.x * gridDim.x) {
-        const float *src = x + p * HW;
+    extern __shared__ float tile[];   // [256 * HW]
+    for (long long p0 = (long long)blockIdx.x * 256; p0 < planes; p0 += (long long)gridDim.x * 256) {
+        const int np = (int)min((long long)256, planes - p0), n = np * HW;
+        const float *src = x + p0 * HW;
+        for (int i = threadIdx.x; i < n; i += 256) tile[i] = src[i];
+        __syncthreads();
+        if ((int)threadIdx.x < np) {
+            float s = 0.f;
+            for (int i = 0; i < HW; ++i) s += tile[threadIdx.x * HW + i];
+            y[p0 + threadIdx.x] = s / (float)HW;
+        }
+        __syncthreads();
+    }
+}
+
+// 2x2 stride-1 average over an (H+1) x (W+1) map -> H x W: the pooling half of RoIAlignAvg
+// (extensions/_roi_align/modules/roi_align.py:18-30: align to (h+1, w+1), then F.avg_pool2d(kernel_size=2, stride=1))
+__global__ __launch_bounds__(256) void avg2x2s1_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, const long long total,
+                                                           const int H, const int W) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)blockDim.x * gridDim.x) {
+        const int w = (int)(i % W);
+        const long long r = i / W;
+        const int h = (int)(r % H);
+        const float *p = x + ((r / H) * (H + 1) + h) * (W + 1) + w;
+        y[i] = (p[0] + p[1] + p[W + 1] + p[W + 2]) * 0.25f;
+    }
+}
+
+__global__ __launch_bounds__(256) void avg2x2s1_bwd_kernel(const float *__restrict__ dy, float *__restrict__ dx, const long long total,
+                                                           const int H, const int W) {   // total counts the (H+1) x (W+1) inputs
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)blockDim.x * gridDim.x) {
+        const int w = (int)(i % (W + 1));
+        const long long r = i / (W + 1);
+        const int h = (int)(r % (H + 1));
+        const float *p = dy + (r / (H + 1)) * H * W;
         float s = 0.f;
-        for (int i = 0; i < HW; ++i) s += src[i];
-        y[p] = s / (float)HW;
+        if (h < H && w < W) s += p[h * W + w];
+        if (h < H && w > 0) s += p[h * W + w - 1];
+        if (h > 0 && w < W) s += p[(h - 1) * W + w];
+        if (h > 0 && w > 0) s += p[(h - 1) * W + w - 1];
+        dx[i] = s * 0.25f;
     }
 }
 
@@ -1232,10 +1269,25 @@ SCDA_API int scda_bce_bwd_hip(const float *p, const float *t, int n, const float
 SCDA_API int scda_gap_fwd_hip(const float *x, float *y, int planes, int HW, void *stream) {
     NN_CHECK(x && y && planes > 0 && HW > 0, "scda_gap_fwd_hip")
     if (HW <= 64 && planes >= 4096)
-        hipLaunchKernelGGL(gap_fwd_small_kernel, dim3(ew_grid(planes)), dim3(256), 0, as_stream(stream), x, y, (long long)planes, HW);
+        hipLaunchKernelGGL(gap_fwd_small_kernel, dim3(ew_grid(planes)), dim3(256), (size_t)256 * HW * sizeof(float), as_stream(stream), x, y,
+                           (long long)planes, HW);
     else
         hipLaunchKernelGGL(gap_fwd_kernel, dim3(planes), dim3(256), 0, as_stream(stream), x, y, HW);
     return launch_status("gap_fwd_kernel");
+}
+
+SCDA_API int scda_avg2x2s1_fwd_hip(const float *x, float *y, int planes, int H, int W, void *stream) {
+    NN_CHECK(x && y && planes > 0 && H > 0 && W > 0, "scda_avg2x2s1_fwd_hip")
+    const long long total = (long long)planes * H * W;
+    hipLaunchKernelGGL(avg2x2s1_fwd_kernel, dim3(ew_grid(total) * 4), dim3(256), 0, as_stream(stream), x, y, total, H, W);
+    return launch_status("avg2x2s1_fwd_kernel");
+}
+
+SCDA_API int scda_avg2x2s1_bwd_hip(const float *dy, float *dx, int planes, int H, int W, void *stream) {
+    NN_CHECK(dy && dx && planes > 0 && H > 0 && W > 0, "scda_avg2x2s1_bwd_hip")
+    const long long total = (long long)planes * (H + 1) * (W + 1);
+    hipLaunchKernelGGL(avg2x2s1_bwd_kernel, dim3(ew_grid(total) * 4), dim3(256), 0, as_stream(stream), dy, dx, total, H, W);
+    return launch_status("avg2x2s1_bwd_kernel");
 }
 
 SCDA_API int scda_gap_bwd_hip(const float *dy, float *dx, int planes, int HW, void *stream) {

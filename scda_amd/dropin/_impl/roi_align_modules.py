@@ -32,7 +32,12 @@ class RoIAlign(Module):
 
 class RoIAlignAvg(RoIAlign):
     extra = 1
-    reduce2x2 = staticmethod(lambda a, b, c, d: (a + b + c + d) * 0.25)
+
+    def forward(self, features, rois):
+        from scda_amd.autograd_ops import Avg2x2S1Fn
+        assert rois.shape[1] == 5
+        x = RoIAlignFunction(self.aligned_height + 1, self.aligned_width + 1, self.spatial_scale)(features, rois)
+        return Avg2x2S1Fn.apply(x)      # avg_pool2d(kernel_size=2, stride=1) as one kernel (forward and backward)
 
 
 class RoIAlignMax(RoIAlign):

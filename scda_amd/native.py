@@ -765,6 +765,22 @@ def bce_bwd(p, t, g):
     return dp
 
 
+def avg2x2s1_fwd(x):
+    _req(x, "x")
+    B, C, H1, W1 = x.shape
+    y = torch.empty(B, C, H1 - 1, W1 - 1, dtype=torch.float32, device=x.device)
+    _check(lib().scda_avg2x2s1_fwd_hip(_p(x), _p(y), i32(B * C), i32(H1 - 1), i32(W1 - 1), _stream()), "scda_avg2x2s1_fwd_hip")
+    return y
+
+
+def avg2x2s1_bwd(dy):
+    _req(dy, "dy")
+    B, C, H, W = dy.shape
+    dx = torch.empty(B, C, H + 1, W + 1, dtype=torch.float32, device=dy.device)
+    _check(lib().scda_avg2x2s1_bwd_hip(_p(dy), _p(dx), i32(B * C), i32(H), i32(W), _stream()), "scda_avg2x2s1_bwd_hip")
+    return dx
+
+
 def gap_fwd(x):
     _req(x, "x")
     B, C, H, W = x.shape

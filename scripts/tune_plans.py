@@ -13,7 +13,8 @@ def t(fn, it=8):
     fn(); torch.cuda.synchronize(); a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True); a.record()
     for _ in range(it): fn()
     b.record(); torch.cuda.synchronize(); return a.elapsed_time(b) / it * 1e3
-cands = [(bm, bn, sp) for bm in (64, 128, 256) for bn in (64, 128, 256) for sp in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128)]
+cands = [(bm, bn, sp) for bm in (64, 128, 256) for bn in (64, 128, 256) for sp in (1, 2, 3, 4, 6, 7, 8, 12, 14, 16, 20, 24, 28, 32, 40, 48, 56, 64, 80, 96, 102, 128, 160, 204, 256)]
+os.environ["SCDA_PLAN_ALLOW_BM64"] = "1"
 for name, B, Cin, H, W, Cout in LAYERS:
     x = torch.randn(B, Cin, H, W, device=dev); w = torch.randn(Cout, Cin, 3, 3, device=dev) * 0.05; b = torch.randn(Cout, device=dev)
     y = N.conv2d_fwd(x, w, b, 1, 1, 1); dy = torch.randn_like(y)
