@@ -237,6 +237,20 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
 #define SCDA_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
+// LDS-DMA through a buffer descriptor over [base, base + 2 GB): lane offsets with bit 31 set are out of range, and an
+// out-of-range lane writes 0.0 to its LDS slot -- the hardware's bounds check takes the place of a zero page and of the
+// 64-bit address select per lane.  (The descriptor type only exists in the device compilation.)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SCDA_BUFFER_LOAD_LDS(BYTES_)                                                                                      \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)0x80000000u, 0x00020000), \
+                                             (lds_void_t *)lds_dst, BYTES_, voffset, 0, 0, 0)
+#else
+#define SCDA_BUFFER_LOAD_LDS(BYTES_) (void)0
+#endif
+__device__ __forceinline__ void buffer_load_lds_b32(const void *base, const unsigned voffset, float *lds_dst) { SCDA_BUFFER_LOAD_LDS(4); }
+__device__ __forceinline__ void buffer_load_lds_b128(const void *base, const unsigned voffset, float *lds_dst) { SCDA_BUFFER_LOAD_LDS(16); }
+#undef SCDA_BUFFER_LOAD_LDS
+
 // ---- operand staging shared by the dense GEMM and the weight-gradient kernels ------------------------------------------
 // They use the ring / vmcnt / barrier schedule of conv_igemm_glds_kernel (below); what differs is how a tile lands in LDS:
 //   MC (stored [K][MN], MN contiguous): rows of the tile are K-rows, laid down as [16][BMN] by dwordx4 LDS-DMA; the MFMA
@@ -284,8 +298,13 @@ struct GldsOperand {
             for (int t = 0; t < 4; ++t) f[t] = stage[(8 * q + 4 * h + t) * BMN + r0 + lr];
         } else {
             const int row = r0 + lr, p = (2 * q + h) ^ ((row >> 2) & 3);
-            const float4 v = *reinterpret_cast<const float4 *>(stage + row * 16 + 4 * p);
-            f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+            // a clang vector of floats, NOT HIP's float4 struct: a struct-typed LDS read loses the float type-based alias
+            // info, and the compiler then protects it from the LDS-DMA writes in flight with an s_waitcnt vmcnt(0) right after
+            // the barrier -- draining the two prefetched slabs every iteration (the ring's own counted vmcnt already
+            // guarantees that the slab being read has landed)
+            typedef float f32x4_t __attribute__((ext_vector_type(4)));
+            const f32x4_t v = *reinterpret_cast<const f32x4_t *>(stage + row * 16 + 4 * p);
+            f[0] = v[0]; f[1] = v[1]; f[2] = v[2]; f[3] = v[3];
         }
     }
 };
@@ -602,41 +621,67 @@ __global__ __launch_bounds__(BM == 256 ? 512 : 256) void conv_wgrad_glds_kernel(
     const int s_end = min(g.K, (tz + 1) * g.k_per_split) / BK;
     const int ohw = g.dOHW.d, ihw = g.IH * g.IW;
 
-    // B gather: this lane's pixel inside a slab (after the swizzle) and the (ci, tap) constants of its 8 rows
-    const int kl = 4 * (((lane & 15) >> 2) ^ wsw) + (lane & 3);
-    int b_base[B_PW], b_tap[B_PW];
+    // Staging runs with the matrix pipe idle, so its instruction count is what separates this kernel from the forward one.
+    // Both operands come in through BUFFER loads to LDS: the descriptor's range check returns 0 for any offset >= 2^31, which
+    // replaces the zero page and every 64-bit `cond ? pointer : zero_page` select (hipcc made exec-mask branches of those:
+    // ~180 instructions and 9 branches per slab).  Per-image tensors are < 2 GB (checked by the launcher), the image and the
+    // slab's first pixel go into the descriptor's base (scalar), and a lane's 32-bit offset is
+    //   A (dY rows): a constant per instruction -- row base + 16-byte chunk after the swizzle, or OOB for rows >= M
+    //   B (gathered X): pixel offset of the slab (tracked incrementally, no division) + the row's (ci, tap) constant,
+    //      with bit 31 set from the 9-bit tap-validity mask
+    constexpr unsigned OOB = 0x80000000u;
+    unsigned a_voff[OA::PW];
+#pragma unroll
+    for (int i = 0; i < OA::PW; ++i) {
+        const int row = (wave * OA::PW + i) * 16 + (lane >> 2);
+        const int c = (lane & 3) ^ ((row >> 2) & 3);
+        a_voff[i] = m0 + row < g.M ? (unsigned)(((m0 + row) * ohw + 4 * c) * 4) : OOB;
+    }
+    const int kl = 4 * (((lane & 15) >> 2) ^ wsw) + (lane & 3);   // this lane's pixel inside a slab (after the swizzle)
+    unsigned b_off[B_PW], b_sh[B_PW];
 #pragma unroll
     for (int j = 0; j < B_PW; ++j) {
         const int n = n0 + 16 * (j * JG + wjg) + 4 * wsw + (lane >> 4);
         const int c = n / (KH * KW), rem = n - c * (KH * KW);
         const int kh = rem / KW, kw = rem - kh * KW;
-        b_base[j] = c * ihw + (kh - g.pad) * g.IW + (kw - g.pad);
-        b_tap[j] = (n < g.N) ? kh * KW + kw : 31;   // bit 31 of the mask is never set
+        b_off[j] = n < g.N ? (unsigned)((c * ihw + (kh - g.pad) * g.IW + (kw - g.pad)) * 4) : OOB;
+        b_sh[j] = 31 - (kh * KW + kw);
     }
+    // slab cursor: image and first pixel (scalar), this lane's output pixel (oy, ox); advanced by 16 pixels per issue
+    int img0, pix0, oy, ox, step_y, step_x;
+    g.dOHW.divmod(s_begin * BK, img0, pix0);
+    g.dOW.divmod(pix0 + kl, oy, ox);
+    g.dOW.divmod(BK, step_y, step_x);
+    const char *a_img = reinterpret_cast<const char *>(dY) + (size_t)img0 * g.Cout * ohw * 4;
+    const char *x_img = reinterpret_cast<const char *>(X) + (size_t)img0 * g.Cin * ihw * 4;
+    const size_t a_img_stride = (size_t)g.Cout * ohw * 4, x_img_stride = (size_t)g.Cin * ihw * 4;
 
-    auto issue = [&](int s, int buf) {
+    auto issue = [&](int buf) {
         float *st = lds + buf * STAGE;
-        const int k0 = s * BK;
-        int img0, pix0;
-        g.dOHW.divmod(k0, img0, pix0);
-        OA::issue(dY + (size_t)img0 * g.Cout * ohw, ohw, g.M, m0, pix0, st, wave, lane, g.zp);
-        int oy, ox;
-        g.dOW.divmod(pix0 + kl, oy, ox);
+        const char *a_slab = a_img + (size_t)pix0 * 4;
+#pragma unroll
+        for (int i = 0; i < OA::PW; ++i)
+            buffer_load_lds_b128(a_slab, a_voff[i], st + (wave * OA::PW + i) * 16 * 16);
+        // validity of the KH x KW taps of this lane's pixel (row bits x column bits), inverted: bit t set = tap t off the image
+        unsigned rowb = 0, colb = 0;
+#pragma unroll
+        for (int kh = 0; kh < KH; ++kh) rowb |= (unsigned)((unsigned)(oy * S + kh - g.pad) < (unsigned)g.IH) << kh;
+#pragma unroll
+        for (int kw = 0; kw < KW; ++kw) colb |= (unsigned)((unsigned)(ox * S + kw - g.pad) < (unsigned)g.IW) << kw;
         unsigned mask = 0;
 #pragma unroll
-        for (int kh = 0; kh < KH; ++kh)
-#pragma unroll
-            for (int kw = 0; kw < KW; ++kw) {
-                const int iy = oy * S + kh - g.pad, ix = ox * S + kw - g.pad;
-                if ((unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW) mask |= 1u << (kh * KW + kw);
-            }
-        const float *xb = X + (size_t)img0 * g.Cin * ihw + (oy * S) * g.IW + ox * S;
+        for (int kh = 0; kh < KH; ++kh) mask |= ((rowb >> kh) & 1u) ? colb << (kh * KW) : 0u;
+        const unsigned off_taps = ~mask;
+        const unsigned x_pix = (unsigned)((oy * S * g.IW + ox * S) * 4);
         float *Bb = st + BK * BM;
 #pragma unroll
-        for (int j = 0; j < B_PW; ++j) {
-            const float *src = ((mask >> b_tap[j]) & 1u) ? xb + b_base[j] : g.zp;
-            __builtin_amdgcn_global_load_lds((glb_void_t *)src, (lds_void_t *)(Bb + (16 * (j * JG + wjg) + 4 * wsw) * 16), 4, 0, 0);
-        }
+        for (int j = 0; j < B_PW; ++j)
+            buffer_load_lds_b32(x_img, (x_pix + b_off[j]) | ((off_taps << b_sh[j]) & OOB), Bb + (16 * (j * JG + wjg) + 4 * wsw) * 16);
+        // next slab
+        pix0 += BK;
+        ox += step_x; oy += step_y;
+        if (ox >= g.dOW.d) { ox -= g.dOW.d; ++oy; }
+        if (pix0 >= ohw) { pix0 = 0; oy -= g.OH; a_img += a_img_stride; x_img += x_img_stride; }
     };
 
     f32x16 acc[TM][TN];
@@ -652,12 +697,12 @@ __global__ __launch_bounds__(BM == 256 ? 512 : 256) void conv_wgrad_glds_kernel(
     float rs[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) rs[i] = 0.f;
-    if (s_begin < s_end) issue(s_begin, 0);
-    if (s_begin + 1 < s_end) issue(s_begin + 1, 1);
+    if (s_begin < s_end) issue(0);
+    if (s_begin + 1 < s_end) issue(1);
     int buf = 0, nbuf = 2;
     for (int s = s_begin; s < s_end; ++s) {
         if (s + 2 < s_end) {
-            issue(s + 2, nbuf);
+            issue(nbuf);
             SCDA_WAIT_VMCNT(2 * L);
         } else if (s + 1 < s_end) {
             SCDA_WAIT_VMCNT(L);
@@ -1256,7 +1301,9 @@ static int launch_wgrad(const float *dY, const float *X, WgradGeom g, float *dW,
     const bool small = g.M <= 64;
     const int BNv = (g.N <= 64) ? 64 : 128;
     static const bool no_glds = getenv("SCDA_WGRAD_NO_GLDS") != nullptr;   // A/B knob
-    const bool glds = !no_glds && g.a_vec4 && (g.dOHW.d % BK) == 0;
+    // the LDS-DMA kernel addresses one image of dY / X through a buffer descriptor with 32-bit lane offsets
+    const bool fits_2g = (long long)g.Cout * g.OH * g.OW * 4 < (1LL << 31) && (long long)g.Cin * g.IH * g.IW * 4 < (1LL << 31);
+    const bool glds = !no_glds && g.a_vec4 && (g.dOHW.d % BK) == 0 && fits_2g;
     const char *fbm = getenv("SCDA_CONV_BM");                              // 256 forces the 8-wave tile where legal
     const bool bm256_ok = glds && BNv == 128 && (g.M % 256) == 0;
     LaunchPlan plan = plan_launch(g.M, g.N, g.K, small ? 64 : 128, BNv == 64, BNv == 128, true, ws_bytes, 32, false,
