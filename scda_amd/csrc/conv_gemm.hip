@@ -243,12 +243,13 @@ typedef const __attribute__((address_space(1))) void glb_void_t;
 #if defined(__HIP_DEVICE_COMPILE__)
 #define SCDA_BUFFER_LOAD_LDS(BYTES_)                                                                                      \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)0x80000000u, 0x00020000), \
-                                             (lds_void_t *)lds_dst, BYTES_, voffset, 0, 0, 0)
+                                             (lds_void_t *)lds_dst, BYTES_, voffset, soffset, 0, 0)
 #else
 #define SCDA_BUFFER_LOAD_LDS(BYTES_) (void)0
 #endif
-__device__ __forceinline__ void buffer_load_lds_b32(const void *base, const unsigned voffset, float *lds_dst) { SCDA_BUFFER_LOAD_LDS(4); }
-__device__ __forceinline__ void buffer_load_lds_b128(const void *base, const unsigned voffset, float *lds_dst) { SCDA_BUFFER_LOAD_LDS(16); }
+// address = base + voffset (per lane) + soffset (scalar, < 2^31 - the largest in-range voffset)
+__device__ __forceinline__ void buffer_load_lds_b32(const void *base, const unsigned voffset, float *lds_dst, const int soffset = 0) { SCDA_BUFFER_LOAD_LDS(4); }
+__device__ __forceinline__ void buffer_load_lds_b128(const void *base, const unsigned voffset, float *lds_dst, const int soffset = 0) { SCDA_BUFFER_LOAD_LDS(16); }
 #undef SCDA_BUFFER_LOAD_LDS
 
 // ---- operand staging shared by the dense GEMM and the weight-gradient kernels ------------------------------------------
@@ -349,27 +350,50 @@ __global__ __launch_bounds__(BM == 256 ? 512 : 256) void conv_igemm_glds_kernel(
     g.dPHW.divmod(n_ok ? n_glob : 0, img, pix);
     g.dPW.divmod(pix, py, px);
     const int plane = g.HB * g.WB;
-    const float *xb = X + (size_t)img * g.CB * plane + (size_t)(kg * B_PW) * plane;
-    // A: this lane's 4 consecutive output channels of row (wave*A_PW + i)*A_RPI + lane/A_LPR
-    const float *wsrc = Wt + (size_t)(wave * A_PW * A_RPI + lane / A_LPR) * g.mpad + m0 + (lane % A_LPR) * 4;
+    // Staging goes through buffer descriptors (buffer_load_lds_*): a lane offset with bit 31 set is out of range and lands as
+    // 0.0 in LDS, so padding / out-of-range pixels need neither a zero page nor a 64-bit select per load, and the per-slab work
+    // of a lane is three VALU instructions.  The lane's pixel is fixed for the whole kernel: its offset inside the gathered
+    // tensor (relative to the tile's first image, so that 32 bits are enough -- checked by the launcher) and the validity of
+    // each of its KH x KW taps are computed once; a slab then adds one scalar (channel block in the descriptor base, tap
+    // offset) and picks its validity bit.
+    constexpr unsigned OOB = 0x80000000u;
+    constexpr bool FAST = KH * KW <= 32 && (S == 1 || !DGRAD);   // tap offset = lane constant + slab scalar
+    const int img_first = __builtin_amdgcn_readfirstlane(g.dPHW.div(n0));
+    const char *xbase = reinterpret_cast<const char *>(X + ((size_t)img_first * g.CB + kg * B_PW) * plane);
+    const int lane_img = (img - img_first) * g.CB * plane;
+    int lane_base = 0;
+    unsigned off_taps = 0;   // bit r set: tap r of this lane's pixel reads padding (or the pixel is beyond N)
+    if (FAST) {
+        lane_base = lane_img + (DGRAD ? (py + g.pad) * g.WB + px + g.pad : (py * S - g.pad) * g.WB + px * S - g.pad);
+#pragma unroll
+        for (int r = 0; r < KH * KW; ++r)
+            off_taps |= (unsigned)(conv_tap_offset<S, DGRAD>(g, n_ok, py, px, r / KW, r % KW) < 0) << r;
+    }
+    // A: this lane's 4 consecutive output channels of row (wave*A_PW + i)*A_RPI + lane/A_LPR of the slab
+    const unsigned a_voff = (unsigned)(((lane / A_LPR) * g.mpad + (lane % A_LPR) * 4) * 4);
+    const char *wbase = reinterpret_cast<const char *>(Wt + (size_t)(wave * A_PW * A_RPI) * g.mpad + m0);
 
     auto issue = [&](int s, int buf) {
         float *Ab = lds + buf * STAGE;
         float *Bb = Ab + BK * BM;
-        const float *wa = wsrc + (size_t)s * BK * g.mpad;
+        const char *wa = wbase + (size_t)s * BK * g.mpad * 4;
 #pragma unroll
         for (int i = 0; i < A_PW; ++i)
-            __builtin_amdgcn_global_load_lds((glb_void_t *)(wa + (size_t)i * A_RPI * g.mpad),
-                                             (lds_void_t *)(Ab + (wave * A_PW + i) * A_RPI * BM), 16, 0, 0);
+            buffer_load_lds_b128(wa, a_voff, Ab + (wave * A_PW + i) * A_RPI * BM, i * A_RPI * g.mpad * 4);
         const int cb = s / (KH * KW), r = s - cb * (KH * KW);
         const int kh = r / KW, kw = r - kh * KW;
-        const int off = conv_tap_offset<S, DGRAD>(g, n_ok, py, px, kh, kw);
-        const float *src = off >= 0 ? xb + (size_t)(cb * BK) * plane + off : g.zp;
-        const size_t stride = off >= 0 ? (size_t)plane : 0;
+        unsigned voff;
+        if (FAST) {
+            const int tap = DGRAD ? -(kh * g.WB + kw) : kh * g.WB + kw;
+            voff = ((unsigned)(lane_base + tap) << 2) | (((off_taps >> r) & 1u) << 31);
+        } else {
+            const int off = conv_tap_offset<S, DGRAD>(g, n_ok, py, px, kh, kw);
+            voff = off >= 0 ? (unsigned)(lane_img + off) << 2 : OOB;
+        }
+        const char *xs = xbase + (size_t)cb * BK * plane * 4;
 #pragma unroll
         for (int j = 0; j < B_PW; ++j)
-            __builtin_amdgcn_global_load_lds((glb_void_t *)(src + j * stride),
-                                             (lds_void_t *)(Bb + (kg * B_PW + j) * BN + half * 64), 4, 0, 0);
+            buffer_load_lds_b32(xs, voff, Bb + (kg * B_PW + j) * BN + half * 64, j * plane * 4);
     };
 
     f32x16 acc[TM][TN];
@@ -1242,6 +1266,14 @@ template <int KH, int KW, int S, bool DGRAD>
 static int launch_conv(const float *Wm, const float *X, const ConvGeom &g0, Epi e, float *ws, size_t ws_bytes,
                        hipStream_t st) {
     ConvGeom g = g0;
+    if (g.slab_aligned) {   // the LDS-DMA kernel addresses the images one tile touches with 32-bit lane offsets
+        const long long phw = (long long)g.PH * g.PW, per_image = (long long)g.CB * g.HB * g.WB * 4;
+        const long long images = std::min<long long>(g.batch, (256 + phw - 1) / phw + 1);
+        if (images * per_image >= (1LL << 31)) {
+            set_error("conv: %lld x %lld bytes of gathered tensor under one tile exceed the 2 GB a buffer descriptor addresses", images, per_image);
+            return SCDA_EINVAL;
+        }
+    }
     const bool small_m = g.M <= 64;
     const int BMv = small_m ? 64 : 128;
     static const char *force = getenv("SCDA_CONV_BN");   // experiment knob: 64 | 128
