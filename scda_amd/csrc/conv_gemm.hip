@@ -311,91 +311,136 @@ struct GldsOperand {
 };
 
 
-// Wave layout: 2 x 2 waves, except the 64 x 256 tile (layers with <= 64 output channels: conv1_x, the decoder's last
-// stages), which is 1 x 4 so that every wave still owns a 64 x 64 sub-tile = 32 MFMAs per barrier; with 64 x 128 tiles a
-// wave had 32 x 64 = 16 MFMAs per barrier and those layers ran at 75 instead of ~100 TFLOP/s.
+// Tile configuration of the direct-to-LDS conv kernel.
+// Compute waves: 2 x 2, except the 64 x 256 tile (layers with <= 64 output channels: conv1_x, the decoder's last stages),
+// which is 1 x 4 so that every wave still owns a 64 x 64 sub-tile = 32 MFMAs per barrier, and the 256 x 128 tile, which has
+// EIGHT (4 x 2, one workgroup per CU, 96 KB of LDS): the gathered pixel operand is shared by twice as many output channels.
+// Staging waves: NP extra waves per workgroup do nothing but issue the LDS-DMA of the ring (they hold no accumulators); the
+// compute waves' loop is barrier -> fragment reads -> MFMAs.  With every wave staging its own share, all waves of a
+// workgroup went through the ~55-instruction staging phase at the same time (the per-slab barrier keeps them in step) and the
+// matrix pipe sat idle for its length; now that phase runs underneath the other waves' MFMAs.  NP is chosen so that two
+// slabs of one staging wave's loads fit the 6-bit vmcnt counter (2 L <= 63).
+template <int BM, int BN>
+struct ConvGldsCfg {
+    static constexpr int NWC = BM == 256 ? 8 : 4;                    // compute waves
+    static constexpr int WGN = BN == 256 ? 4 : 2, WGM = NWC / WGN;   // ... along N / M
+    static constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
+    static constexpr int A_LPR = BM / 4;            // lanes per weight row (dwordx4 each)
+    static constexpr int A_RPI = 64 / A_LPR;        // rows per wave-instruction
+    static constexpr int A_TOTAL = BK / A_RPI;      // A instructions per slab
+    static constexpr int HALVES = BN / 64;          // 64-pixel pieces per B row
+    static constexpr int L_TOTAL = A_TOTAL + BK * HALVES;
+    static constexpr int NP = L_TOTAL <= 31 ? 1 : L_TOTAL <= 62 ? 2 : 4;   // staging waves
+    static constexpr int A_PP = A_TOTAL / NP, ROWS_PP = BK / NP;    // per staging wave: A instructions, B rows
+    static constexpr int L = A_PP + ROWS_PP * HALVES;               // LDS-DMA instructions per staging wave per slab
+    static constexpr int THREADS = (NWC + NP) * 64;
+    static_assert(A_TOTAL % NP == 0 && BK % NP == 0 && 2 * L <= 63, "staging split");
+};
+
 template <int BM, int BN, int KH, int KW, int S, bool DGRAD>
-__global__ __launch_bounds__(BM == 256 ? 512 : 256) void conv_igemm_glds_kernel(const float *__restrict__ Wt,
-                                                                                const float *__restrict__ X,
-                                                                                const ConvGeom g, const Epi e) {
+__global__ __launch_bounds__((ConvGldsCfg<BM, BN>::THREADS)) void conv_igemm_glds_kernel(const float *__restrict__ Wt,
+                                                                                     const float *__restrict__ X,
+                                                                                     const ConvGeom g, const Epi e) {
+    using C = ConvGldsCfg<BM, BN>;
     constexpr int NST = 4, STAGE = BK * (BM + BN);
-    // 256 x 128 tile: EIGHT waves (4 x 2), one workgroup per CU (96 KB of LDS): the gathered pixel operand is shared by twice
-    // as many output channels (+6.6 % on conv3_2 in scripts/ablate/conv_glds.hip); used when Cout % 256 == 0 and the grid
-    // comes out at a multiple of 256 workgroups (conv3_x, conv4_x, conv5_x all do)
-    constexpr int NW = BM == 256 ? 8 : 4;
-    constexpr int WGN = BN == 256 ? 4 : 2, WGM = NW / WGN;         // waves along N / M
-    constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
-    constexpr int A_LPR = BM / 4;             // lanes per weight row (dwordx4 each)
-    constexpr int A_RPI = 64 / A_LPR;         // rows per wave-instruction
-    constexpr int A_PW = BK / A_RPI / NW;     // A instructions per wave per slab
-    constexpr int HALVES = BN / 64;           // 64-pixel pieces per B row
-    constexpr int B_PW = BK * HALVES / NW;    // B instructions (= rows) per wave per slab (64 x 256 tile: all 16 rows)
-    constexpr int L = A_PW + B_PW;            // LDS-DMA instructions per wave per slab
+    constexpr int NWC = C::NWC, WGN = C::WGN, WM = C::WM, WN = C::WN, TM = C::TM, TN = C::TN;
+    constexpr int A_LPR = C::A_LPR, A_RPI = C::A_RPI, HALVES = C::HALVES, L = C::L;
     __shared__ __attribute__((aligned(16))) float lds[NST * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WGN, wn = wave % WGN;
     int tx, ty, tz;
     tile_coords(g.nx, g.ny, g.swz, tx, ty, tz);
     const int m0 = ty * BM, n0 = tx * BN;
     const int s_begin = tz * (g.k_per_split / BK);
     const int s_end = min(g.K, (tz + 1) * g.k_per_split) / BK;
 
-    // B: this lane's pixel
-    const int half = wave % HALVES, kg = wave / HALVES;
-    const int n_glob = n0 + half * 64 + lane;
-    const bool n_ok = n_glob < g.N;
-    int img, pix, py, px;
-    g.dPHW.divmod(n_ok ? n_glob : 0, img, pix);
-    g.dPW.divmod(pix, py, px);
-    const int plane = g.HB * g.WB;
-    // Staging goes through buffer descriptors (buffer_load_lds_*): a lane offset with bit 31 set is out of range and lands as
-    // 0.0 in LDS, so padding / out-of-range pixels need neither a zero page nor a 64-bit select per load, and the per-slab work
-    // of a lane is three VALU instructions.  The lane's pixel is fixed for the whole kernel: its offset inside the gathered
-    // tensor (relative to the tile's first image, so that 32 bits are enough -- checked by the launcher) and the validity of
-    // each of its KH x KW taps are computed once; a slab then adds one scalar (channel block in the descriptor base, tap
-    // offset) and picks its validity bit.
-    constexpr unsigned OOB = 0x80000000u;
-    constexpr bool FAST = KH * KW <= 32 && (S == 1 || !DGRAD);   // tap offset = lane constant + slab scalar
-    const int img_first = __builtin_amdgcn_readfirstlane(g.dPHW.div(n0));
-    const char *xbase = reinterpret_cast<const char *>(X + ((size_t)img_first * g.CB + kg * B_PW) * plane);
-    const int lane_img = (img - img_first) * g.CB * plane;
-    int lane_base = 0;
-    unsigned off_taps = 0;   // bit r set: tap r of this lane's pixel reads padding (or the pixel is beyond N)
-    if (FAST) {
-        lane_base = lane_img + (DGRAD ? (py + g.pad) * g.WB + px + g.pad : (py * S - g.pad) * g.WB + px * S - g.pad);
+    if (wave >= NWC) {
+        // ---- staging wave p: A instructions [p*A_PP, (p+1)*A_PP), B rows [p*ROWS_PP, (p+1)*ROWS_PP) of every slab ----------
+        // Loads go through buffer descriptors (buffer_load_lds_*): a lane offset with bit 31 set is out of range and lands as
+        // 0.0 in LDS, so padding / out-of-range pixels need neither a zero page nor a 64-bit select per load.  A lane's pixels
+        // (one per 64-pixel piece of the tile) are fixed for the whole kernel: their offsets inside the gathered tensor
+        // (relative to the tile's first image, so that 32 bits are enough -- checked by the launcher) and the validity of each
+        // of their KH x KW taps are computed once; a slab then adds one scalar (channel block in the descriptor base, tap
+        // offset) and picks its validity bit.
+        const int p = wave - NWC;
+        // above the compute waves in the SIMD's issue arbitration: at equal priority the MFMA streams of the two compute waves
+        // it shares a SIMD with starved this wave and the ring ran dry (conv3_2 forward 121 vs 128 TFLOP/s)
+        __builtin_amdgcn_s_setprio(3);
+        constexpr unsigned OOB = 0x80000000u;
+        constexpr bool FAST = KH * KW <= 32 && (S == 1 || !DGRAD);   // tap offset = lane constant + slab scalar
+        const int plane = g.HB * g.WB;
+        const int img_first = __builtin_amdgcn_readfirstlane(g.dPHW.div(n0));
+        const char *xbase = reinterpret_cast<const char *>(X + ((size_t)img_first * g.CB + p * C::ROWS_PP) * plane);
+        int lane_img[HALVES], lane_base[HALVES], py[HALVES], px[HALVES];
+        unsigned off_taps[HALVES];   // bit r set: tap r of the lane's pixel reads padding (or the pixel is beyond N)
+        bool n_ok[HALVES];
 #pragma unroll
-        for (int r = 0; r < KH * KW; ++r)
-            off_taps |= (unsigned)(conv_tap_offset<S, DGRAD>(g, n_ok, py, px, r / KW, r % KW) < 0) << r;
-    }
-    // A: this lane's 4 consecutive output channels of row (wave*A_PW + i)*A_RPI + lane/A_LPR of the slab
-    const unsigned a_voff = (unsigned)(((lane / A_LPR) * g.mpad + (lane % A_LPR) * 4) * 4);
-    const char *wbase = reinterpret_cast<const char *>(Wt + (size_t)(wave * A_PW * A_RPI) * g.mpad + m0);
-
-    auto issue = [&](int s, int buf) {
-        float *Ab = lds + buf * STAGE;
-        float *Bb = Ab + BK * BM;
-        const char *wa = wbase + (size_t)s * BK * g.mpad * 4;
+        for (int h = 0; h < HALVES; ++h) {
+            const int n_glob = n0 + h * 64 + lane;
+            n_ok[h] = n_glob < g.N;
+            int img, pix;
+            g.dPHW.divmod(n_ok[h] ? n_glob : 0, img, pix);
+            g.dPW.divmod(pix, py[h], px[h]);
+            lane_img[h] = (img - img_first) * g.CB * plane;
+            lane_base[h] = 0; off_taps[h] = 0;
+            if (FAST) {
+                lane_base[h] = lane_img[h] + (DGRAD ? (py[h] + g.pad) * g.WB + px[h] + g.pad
+                                                    : (py[h] * S - g.pad) * g.WB + px[h] * S - g.pad);
 #pragma unroll
-        for (int i = 0; i < A_PW; ++i)
-            buffer_load_lds_b128(wa, a_voff, Ab + (wave * A_PW + i) * A_RPI * BM, i * A_RPI * g.mpad * 4);
-        const int cb = s / (KH * KW), r = s - cb * (KH * KW);
-        const int kh = r / KW, kw = r - kh * KW;
-        unsigned voff;
-        if (FAST) {
-            const int tap = DGRAD ? -(kh * g.WB + kw) : kh * g.WB + kw;
-            voff = ((unsigned)(lane_base + tap) << 2) | (((off_taps >> r) & 1u) << 31);
-        } else {
-            const int off = conv_tap_offset<S, DGRAD>(g, n_ok, py, px, kh, kw);
-            voff = off >= 0 ? (unsigned)(lane_img + off) << 2 : OOB;
+                for (int r = 0; r < KH * KW; ++r)
+                    off_taps[h] |= (unsigned)(conv_tap_offset<S, DGRAD>(g, n_ok[h], py[h], px[h], r / KW, r % KW) < 0) << r;
+            }
         }
-        const char *xs = xbase + (size_t)cb * BK * plane * 4;
-#pragma unroll
-        for (int j = 0; j < B_PW; ++j)
-            buffer_load_lds_b32(xs, voff, Bb + (kg * B_PW + j) * BN + half * 64, j * plane * 4);
-    };
+        // A: a lane's 4 consecutive output channels of row i*A_RPI + lane/A_LPR of the slab
+        const unsigned a_voff = (unsigned)(((lane / A_LPR) * g.mpad + (lane % A_LPR) * 4) * 4);
+        const char *wbase = reinterpret_cast<const char *>(Wt + (size_t)(p * C::A_PP * A_RPI) * g.mpad + m0);
 
+        auto issue = [&](int s, int buf) {
+            float *Ab = lds + buf * STAGE + (p * C::A_PP * A_RPI) * BM;
+            float *Bb = lds + buf * STAGE + BK * BM + (p * C::ROWS_PP) * BN;
+            const char *wa = wbase + (size_t)s * BK * g.mpad * 4;
+#pragma unroll
+            for (int i = 0; i < C::A_PP; ++i) buffer_load_lds_b128(wa, a_voff, Ab + i * A_RPI * BM, i * A_RPI * g.mpad * 4);
+            const int cb = s / (KH * KW), r = s - cb * (KH * KW);
+            const int kh = r / KW, kw = r - kh * KW;
+            const char *xs = xbase + (size_t)cb * BK * plane * 4;
+#pragma unroll
+            for (int h = 0; h < HALVES; ++h) {
+                unsigned voff;
+                if (FAST) {
+                    const int tap = DGRAD ? -(kh * g.WB + kw) : kh * g.WB + kw;
+                    voff = ((unsigned)(lane_base[h] + tap) << 2) | (((off_taps[h] >> r) & 1u) << 31);
+                } else {
+                    const int off = conv_tap_offset<S, DGRAD>(g, n_ok[h], py[h], px[h], kh, kw);
+                    voff = off >= 0 ? (unsigned)(lane_img[h] + off) << 2 : OOB;
+                }
+#pragma unroll
+                for (int j = 0; j < C::ROWS_PP; ++j) buffer_load_lds_b32(xs, voff, Bb + j * BN + h * 64, j * plane * 4);
+            }
+        };
+        if (s_begin < s_end) issue(s_begin, 0);
+        if (s_begin + 1 < s_end) issue(s_begin + 1, 1);
+        int nbuf = 2;
+        for (int s = s_begin; s < s_end; ++s) {
+            // slab s+2 goes into the buffer last read in iteration s-2: every compute wave that reached barrier s-1 is done
+            // with it.  Then wait until slab s (two slabs back in this wave's queue) has landed, and release it.
+            if (s + 2 < s_end) {
+                issue(s + 2, nbuf);
+                SCDA_WAIT_VMCNT(2 * L);
+            } else if (s + 1 < s_end) {
+                SCDA_WAIT_VMCNT(L);
+            } else {
+                SCDA_WAIT_VMCNT(0);
+            }
+            __builtin_amdgcn_s_barrier();
+            nbuf = (nbuf + 1) & (NST - 1);
+        }
+        return;
+    }
+
+    // ---- compute waves ------------------------------------------------------------------------------------------------------
+    const int wm = wave / WGN, wn = wave % WGN;
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -404,19 +449,8 @@ __global__ __launch_bounds__(BM == 256 ? 512 : 256) void conv_igemm_glds_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const int lr = lane & 31, lk = lane >> 5;
-
-    if (s_begin < s_end) issue(s_begin, 0);
-    if (s_begin + 1 < s_end) issue(s_begin + 1, 1);
-    int buf = 0, nbuf = 2;
+    int buf = 0;
     for (int s = s_begin; s < s_end; ++s) {
-        if (s + 2 < s_end) {
-            issue(s + 2, nbuf);
-            SCDA_WAIT_VMCNT(2 * L);
-        } else if (s + 1 < s_end) {
-            SCDA_WAIT_VMCNT(L);
-        } else {
-            SCDA_WAIT_VMCNT(0);
-        }
         __builtin_amdgcn_s_barrier();
         const float *ap = lds + buf * STAGE + lk * BM + wm * WM + lr;
         const float *bp = lds + buf * STAGE + BK * BM + lk * BN + wn * WN + lr;
@@ -441,7 +475,6 @@ __global__ __launch_bounds__(BM == 256 ? 512 : 256) void conv_igemm_glds_kernel(
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
         }
         buf = (buf + 1) & (NST - 1);
-        nbuf = (nbuf + 1) & (NST - 1);
     }
     conv_epilogue<WM, WN>(acc, g, e, m0, n0, tz, wm, wn, lane);
 }
@@ -614,30 +647,46 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
 // ---- weight gradient, direct-to-LDS ------------------------------------------------------------------------------------
 // Both operands are K-contiguous (K = output pixels), i.e. the KC layout of GldsOperand: tiles land as [rows][16 pixels],
 // fragments are ds_read_b128 with the K = 8q + 4h + t assignment and the 16-byte XOR swizzle.
-//   A = dY rows (output channels): dwordx4 LDS-DMA, GldsOperand<BM, false> (needs OH*OW % 16 == 0: a slab never straddles
-//       two images and stays 16-byte aligned)
-//   B = gathered X rows n = (ci, kh, kw): dword LDS-DMA, one instruction = 4 rows x 16 pixels.  The swizzle moves a lane's
-//       pixel with (row>>2)&3, so wave w takes the row groups whose (row>>2)&3 == w: every lane then owns ONE pixel of the
-//       slab for all 8 of its instructions and decodes (oy, ox) + the 9-bit tap-validity mask once per slab.
+//   A = dY rows (output channels): dwordx4 LDS-DMA, 16 rows x 64 bytes per instruction (needs OH*OW % 16 == 0: a slab never
+//       straddles two images and stays 16-byte aligned)
+//   B = gathered X rows n = (ci, kh, kw): dword LDS-DMA, one instruction = a group of 4 rows x 16 pixels.  The swizzle moves
+//       a lane's pixel with the group's class (row>>2)&3, so all groups of one class share the lane -> pixel map: (oy, ox)
+//       and the 9-bit tap-validity mask are kept per class.
+// Staging waves (see ConvGldsCfg): NP waves issue all LDS-DMA; staging wave p takes A instructions [p*A_PP, (p+1)*A_PP)
+// and the row groups of classes [p*CLS_PP, (p+1)*CLS_PP).  Loads go through buffer descriptors (buffer_load_lds_*): the
+// range check returns 0 for any lane offset >= 2^31, which replaces the zero page and the 64-bit selects; per-image tensors
+// are < 2 GB (checked by the launcher), the image and the slab's first pixel go into the descriptor base (scalar), and a lane's
+// 32-bit offset is  A: a constant per instruction (row base + 16-byte chunk after the swizzle, or OOB for rows >= M)
+//                   B: pixel offset of the slab (cursor advanced by 16 pixels per slab, no division) + the row's (ci, tap)
+//                      constant, with bit 31 set from the tap-validity mask
+template <int BM, int BN>
+struct WgradGldsCfg {
+    static constexpr int NWC = BM == 256 ? 8 : 4;          // compute waves: WGM x 2
+    static constexpr int WGM = NWC / 2;
+    static constexpr int WM = BM / WGM, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    static constexpr int A_TOTAL = BM / 16, GROUPS = BN / 4;   // LDS-DMA instructions per slab: dY (16 rows each), X (4 rows each)
+    static constexpr int L_TOTAL = A_TOTAL + GROUPS;
+    static constexpr int NP = 4;   // one swizzle class per staging wave
+    static constexpr int A_PP = A_TOTAL / NP, CLS_PP = 4 / NP, G_PC = GROUPS / 4;   // per staging wave: A instr, classes; groups per class
+    static constexpr int L = A_PP + CLS_PP * G_PC;
+    static constexpr int THREADS = (NWC + NP) * 64;
+    static_assert(A_TOTAL % NP == 0 && 2 * L <= 63, "staging split");
+};
+
 template <int BM, int BN, int KH, int KW, int S>
-__global__ __launch_bounds__(BM == 256 ? 512 : 256) void conv_wgrad_glds_kernel(const float *__restrict__ dY,
-                                                                                const float *__restrict__ X,
-                                                                                const WgradGeom g, float *__restrict__ ws,
-                                                                                float *__restrict__ db_ws) {
-    constexpr int NW = BM == 256 ? 8 : 4;          // 256 x 128 tile: 4 x 2 waves (the gathered X rows serve 256 dY rows)
-    using OA = GldsOperand<BM, false, NW>;
-    using OB = GldsOperand<BN, false, NW>;   // fragment reader only; staging is the gather below
+__global__ __launch_bounds__((WgradGldsCfg<BM, BN>::THREADS)) void conv_wgrad_glds_kernel(const float *__restrict__ dY,
+                                                                                        const float *__restrict__ X,
+                                                                                        const WgradGeom g, float *__restrict__ ws,
+                                                                                        float *__restrict__ db_ws) {
+    using C = WgradGldsCfg<BM, BN>;
+    constexpr int NWC = C::NWC;
+    using OA = GldsOperand<BM, false, NWC>;   // fragment readers only
+    using OB = GldsOperand<BN, false, NWC>;
     constexpr int NST = 4, STAGE = BK * (BM + BN);
-    constexpr int WGM = NW / 2;
-    constexpr int WM = BM / WGM, WN = BN / 2, TM = WM / 32, TN = WN / 32;
-    constexpr int B_PW = BN / 4 / NW;    // B instructions per wave per slab (4 rows each)
-    constexpr int JG = NW / 4;           // waves sharing one swizzle class split the row groups between them
-    constexpr int L = OA::PW + B_PW;
+    constexpr int WM = C::WM, WN = C::WN, TM = C::TM, TN = C::TN, L = C::L;
     __shared__ __attribute__((aligned(16))) float lds[NST * STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int wsw = wave & 3, wjg = wave >> 2;     // swizzle class of this wave's B rows, and which share of them it loads
     int tx, ty, tz;
     tile_coords(g.nx, g.ny, g.swz, tx, ty, tz);
     const int m0 = ty * BM, n0 = tx * BN;
@@ -645,69 +694,94 @@ __global__ __launch_bounds__(BM == 256 ? 512 : 256) void conv_wgrad_glds_kernel(
     const int s_end = min(g.K, (tz + 1) * g.k_per_split) / BK;
     const int ohw = g.dOHW.d, ihw = g.IH * g.IW;
 
-    // Staging runs with the matrix pipe idle, so its instruction count is what separates this kernel from the forward one.
-    // Both operands come in through BUFFER loads to LDS: the descriptor's range check returns 0 for any offset >= 2^31, which
-    // replaces the zero page and every 64-bit `cond ? pointer : zero_page` select (hipcc made exec-mask branches of those:
-    // ~180 instructions and 9 branches per slab).  Per-image tensors are < 2 GB (checked by the launcher), the image and the
-    // slab's first pixel go into the descriptor's base (scalar), and a lane's 32-bit offset is
-    //   A (dY rows): a constant per instruction -- row base + 16-byte chunk after the swizzle, or OOB for rows >= M
-    //   B (gathered X): pixel offset of the slab (tracked incrementally, no division) + the row's (ci, tap) constant,
-    //      with bit 31 set from the 9-bit tap-validity mask
-    constexpr unsigned OOB = 0x80000000u;
-    unsigned a_voff[OA::PW];
+    if (wave >= NWC) {
+        // ---- staging wave ------------------------------------------------------------------------------------------------
+        const int p = wave - NWC;
+        __builtin_amdgcn_s_setprio(3);
+        constexpr unsigned OOB = 0x80000000u;
+        unsigned a_voff[C::A_PP];
 #pragma unroll
-    for (int i = 0; i < OA::PW; ++i) {
-        const int row = (wave * OA::PW + i) * 16 + (lane >> 2);
-        const int c = (lane & 3) ^ ((row >> 2) & 3);
-        a_voff[i] = m0 + row < g.M ? (unsigned)(((m0 + row) * ohw + 4 * c) * 4) : OOB;
-    }
-    const int kl = 4 * (((lane & 15) >> 2) ^ wsw) + (lane & 3);   // this lane's pixel inside a slab (after the swizzle)
-    unsigned b_off[B_PW], b_sh[B_PW];
+        for (int i = 0; i < C::A_PP; ++i) {
+            const int row = (p * C::A_PP + i) * 16 + (lane >> 2);
+            const int c = (lane & 3) ^ ((row >> 2) & 3);
+            a_voff[i] = m0 + row < g.M ? (unsigned)(((m0 + row) * ohw + 4 * c) * 4) : OOB;
+        }
+        unsigned b_off[C::CLS_PP][C::G_PC], b_sh[C::CLS_PP][C::G_PC];
+        int oy[C::CLS_PP], ox[C::CLS_PP];
+        // slab cursor: image and first pixel (scalar), the lane's output pixel per class; advanced by 16 pixels per issue
+        int img0, pix0, step_y, step_x;
+        g.dOHW.divmod(s_begin * BK, img0, pix0);
+        g.dOW.divmod(BK, step_y, step_x);
 #pragma unroll
-    for (int j = 0; j < B_PW; ++j) {
-        const int n = n0 + 16 * (j * JG + wjg) + 4 * wsw + (lane >> 4);
-        const int c = n / (KH * KW), rem = n - c * (KH * KW);
-        const int kh = rem / KW, kw = rem - kh * KW;
-        b_off[j] = n < g.N ? (unsigned)((c * ihw + (kh - g.pad) * g.IW + (kw - g.pad)) * 4) : OOB;
-        b_sh[j] = 31 - (kh * KW + kw);
-    }
-    // slab cursor: image and first pixel (scalar), this lane's output pixel (oy, ox); advanced by 16 pixels per issue
-    int img0, pix0, oy, ox, step_y, step_x;
-    g.dOHW.divmod(s_begin * BK, img0, pix0);
-    g.dOW.divmod(pix0 + kl, oy, ox);
-    g.dOW.divmod(BK, step_y, step_x);
-    const char *a_img = reinterpret_cast<const char *>(dY) + (size_t)img0 * g.Cout * ohw * 4;
-    const char *x_img = reinterpret_cast<const char *>(X) + (size_t)img0 * g.Cin * ihw * 4;
-    const size_t a_img_stride = (size_t)g.Cout * ohw * 4, x_img_stride = (size_t)g.Cin * ihw * 4;
+        for (int c = 0; c < C::CLS_PP; ++c) {
+            const int cls = p * C::CLS_PP + c;
+            const int kl = 4 * (((lane & 15) >> 2) ^ cls) + (lane & 3);   // the lane's pixel inside a slab (after the swizzle)
+            g.dOW.divmod(pix0 + kl, oy[c], ox[c]);
+#pragma unroll
+            for (int j = 0; j < C::G_PC; ++j) {
+                const int n = n0 + 16 * j + 4 * cls + (lane >> 4);
+                const int ci = n / (KH * KW), rem = n - ci * (KH * KW);
+                const int kh = rem / KW, kw = rem - kh * KW;
+                b_off[c][j] = n < g.N ? (unsigned)((ci * ihw + (kh - g.pad) * g.IW + (kw - g.pad)) * 4) : OOB;
+                b_sh[c][j] = 31 - (kh * KW + kw);
+            }
+        }
+        const char *a_img = reinterpret_cast<const char *>(dY) + (size_t)img0 * g.Cout * ohw * 4;
+        const char *x_img = reinterpret_cast<const char *>(X) + (size_t)img0 * g.Cin * ihw * 4;
+        const size_t a_img_stride = (size_t)g.Cout * ohw * 4, x_img_stride = (size_t)g.Cin * ihw * 4;
 
-    auto issue = [&](int buf) {
-        float *st = lds + buf * STAGE;
-        const char *a_slab = a_img + (size_t)pix0 * 4;
+        auto issue = [&](int buf) {
+            float *st = lds + buf * STAGE;
+            const char *a_slab = a_img + (size_t)pix0 * 4;
 #pragma unroll
-        for (int i = 0; i < OA::PW; ++i)
-            buffer_load_lds_b128(a_slab, a_voff[i], st + (wave * OA::PW + i) * 16 * 16);
-        // validity of the KH x KW taps of this lane's pixel (row bits x column bits), inverted: bit t set = tap t off the image
-        unsigned rowb = 0, colb = 0;
+            for (int i = 0; i < C::A_PP; ++i) buffer_load_lds_b128(a_slab, a_voff[i], st + (p * C::A_PP + i) * 16 * 16);
+            float *Bb = st + BK * BM;
+            const bool wrap = pix0 + BK >= ohw;
 #pragma unroll
-        for (int kh = 0; kh < KH; ++kh) rowb |= (unsigned)((unsigned)(oy * S + kh - g.pad) < (unsigned)g.IH) << kh;
+            for (int c = 0; c < C::CLS_PP; ++c) {
+                const int cls = p * C::CLS_PP + c;
+                // validity of the KH x KW taps of the lane's pixel (row bits x column bits), inverted: bit t set = tap t off the image
+                unsigned rowb = 0, colb = 0;
 #pragma unroll
-        for (int kw = 0; kw < KW; ++kw) colb |= (unsigned)((unsigned)(ox * S + kw - g.pad) < (unsigned)g.IW) << kw;
-        unsigned mask = 0;
+                for (int kh = 0; kh < KH; ++kh) rowb |= (unsigned)((unsigned)(oy[c] * S + kh - g.pad) < (unsigned)g.IH) << kh;
 #pragma unroll
-        for (int kh = 0; kh < KH; ++kh) mask |= ((rowb >> kh) & 1u) ? colb << (kh * KW) : 0u;
-        const unsigned off_taps = ~mask;
-        const unsigned x_pix = (unsigned)((oy * S * g.IW + ox * S) * 4);
-        float *Bb = st + BK * BM;
+                for (int kw = 0; kw < KW; ++kw) colb |= (unsigned)((unsigned)(ox[c] * S + kw - g.pad) < (unsigned)g.IW) << kw;
+                unsigned mask = 0;
 #pragma unroll
-        for (int j = 0; j < B_PW; ++j)
-            buffer_load_lds_b32(x_img, (x_pix + b_off[j]) | ((off_taps << b_sh[j]) & OOB), Bb + (16 * (j * JG + wjg) + 4 * wsw) * 16);
-        // next slab
-        pix0 += BK;
-        ox += step_x; oy += step_y;
-        if (ox >= g.dOW.d) { ox -= g.dOW.d; ++oy; }
-        if (pix0 >= ohw) { pix0 = 0; oy -= g.OH; a_img += a_img_stride; x_img += x_img_stride; }
-    };
+                for (int kh = 0; kh < KH; ++kh) mask |= ((rowb >> kh) & 1u) ? colb << (kh * KW) : 0u;
+                const unsigned off_taps = ~mask;
+                const unsigned x_pix = (unsigned)((oy[c] * S * g.IW + ox[c] * S) * 4);
+#pragma unroll
+                for (int j = 0; j < C::G_PC; ++j)
+                    buffer_load_lds_b32(x_img, (x_pix + b_off[c][j]) | ((off_taps << b_sh[c][j]) & OOB), Bb + (16 * j + 4 * cls) * 16);
+                // next slab
+                ox[c] += step_x; oy[c] += step_y;
+                if (ox[c] >= g.dOW.d) { ox[c] -= g.dOW.d; ++oy[c]; }
+                if (wrap) oy[c] -= g.OH;
+            }
+            pix0 += BK;
+            if (wrap) { pix0 = 0; a_img += a_img_stride; x_img += x_img_stride; }
+        };
+        if (s_begin < s_end) issue(0);
+        if (s_begin + 1 < s_end) issue(1);
+        int nbuf = 2;
+        for (int s = s_begin; s < s_end; ++s) {
+            if (s + 2 < s_end) {
+                issue(nbuf);
+                SCDA_WAIT_VMCNT(2 * L);
+            } else if (s + 1 < s_end) {
+                SCDA_WAIT_VMCNT(L);
+            } else {
+                SCDA_WAIT_VMCNT(0);
+            }
+            __builtin_amdgcn_s_barrier();
+            nbuf = (nbuf + 1) & (NST - 1);
+        }
+        return;
+    }
 
+    // ---- compute waves ------------------------------------------------------------------------------------------------------
+    const int wm = wave >> 1, wn = wave & 1;
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -721,18 +795,11 @@ __global__ __launch_bounds__(BM == 256 ? 512 : 256) void conv_wgrad_glds_kernel(
     float rs[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) rs[i] = 0.f;
-    if (s_begin < s_end) issue(0);
-    if (s_begin + 1 < s_end) issue(1);
-    int buf = 0, nbuf = 2;
+    int buf = 0;
+    // kernel-argument loads still pending at the loop (pointers only the epilogue uses) share lgkmcnt with the LDS reads and
+    // return out of order: with one outstanding the compiler can only ever wait for lgkmcnt(0) inside the loop
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
     for (int s = s_begin; s < s_end; ++s) {
-        if (s + 2 < s_end) {
-            issue(nbuf);
-            SCDA_WAIT_VMCNT(2 * L);
-        } else if (s + 1 < s_end) {
-            SCDA_WAIT_VMCNT(L);
-        } else {
-            SCDA_WAIT_VMCNT(0);
-        }
         __builtin_amdgcn_s_barrier();
         const float *as = lds + buf * STAGE, *bs = as + BK * BM;
         float a[2][TM][4], b[2][TN][4];
@@ -743,12 +810,7 @@ __global__ __launch_bounds__(BM == 256 ? 512 : 256) void conv_wgrad_glds_kernel(
 #pragma unroll
             for (int j = 0; j < TN; ++j) OB::frag(bs, wn * WN + j * 32, lr, lh, q, b[q][j]);
         }
-        if (bias_rows) {   // fused bias gradient: row sums of dY ride along on the fragments this lane holds anyway
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-#pragma unroll
-                for (int i = 0; i < TM; ++i) rs[i] += (a[q][i][0] + a[q][i][1]) + (a[q][i][2] + a[q][i][3]);
-        }
+        __builtin_amdgcn_sched_barrier(0);   // all fragment reads in flight before the first MFMA (the scheduler sank K-group 1)
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -758,8 +820,16 @@ __global__ __launch_bounds__(BM == 256 ? 512 : 256) void conv_wgrad_glds_kernel(
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][i][t], b[q][j][t], acc[i][j], 0, 0, 0);
+        // fused bias gradient: row sums of dY ride along on the fragments this lane holds anyway.  AFTER the MFMAs: a branch
+        // between the reads and the first MFMA made the compiler wait for all eight fragment reads (lgkmcnt(0)) before any
+        // matrix work; now the K-group 0 products start while the K-group 1 fragments are still on their way.
+        if (bias_rows) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) rs[i] += (a[q][i][0] + a[q][i][1]) + (a[q][i][2] + a[q][i][3]);
+        }
         buf = (buf + 1) & (NST - 1);
-        nbuf = (nbuf + 1) & (NST - 1);
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -1303,12 +1373,12 @@ static int launch_conv(const float *Wm, const float *X, const ConvGeom &g0, Epi 
 #define CONV_LAUNCH(BM_, BN_)                                                                                            \
     do {                                                                                                                 \
         if (g.slab_aligned)                                                                                              \
-            hipLaunchKernelGGL((conv_igemm_glds_kernel<BM_, BN_, KH, KW, S, DGRAD>), grid, dim3(256), 0, st, Wm, X, g, e);  \
+            hipLaunchKernelGGL((conv_igemm_glds_kernel<BM_, BN_, KH, KW, S, DGRAD>), grid, dim3(ConvGldsCfg<BM_, BN_>::THREADS), 0, st, Wm, X, g, e);  \
         else                                                                                                             \
             hipLaunchKernelGGL((conv_igemm_kernel<BM_, BN_, KH, KW, S, DGRAD>), grid, dim3(256), 0, st, Wm, X, g, e);        \
     } while (0)
-    if (BMt == 256) hipLaunchKernelGGL((conv_igemm_glds_kernel<256, 128, KH, KW, S, DGRAD>), grid, dim3(512), 0, st, Wm, X, g, e);
-    else if (BMt == 64 && BNv == 256) hipLaunchKernelGGL((conv_igemm_glds_kernel<64, 256, KH, KW, S, DGRAD>), grid, dim3(256), 0, st, Wm, X, g, e);
+    if (BMt == 256) hipLaunchKernelGGL((conv_igemm_glds_kernel<256, 128, KH, KW, S, DGRAD>), grid, dim3(ConvGldsCfg<256, 128>::THREADS), 0, st, Wm, X, g, e);
+    else if (BMt == 64 && BNv == 256) hipLaunchKernelGGL((conv_igemm_glds_kernel<64, 256, KH, KW, S, DGRAD>), grid, dim3(ConvGldsCfg<64, 256>::THREADS), 0, st, Wm, X, g, e);
     else if (BMt == 64 && BNv == 64) CONV_LAUNCH(64, 64);
     else if (BMt == 64) CONV_LAUNCH(64, 128);
     else if (BNv == 64) CONV_LAUNCH(128, 64);
@@ -1361,9 +1431,9 @@ static int launch_wgrad(const float *dY, const float *X, WgradGeom g, float *dW,
     } while (0)
     if (db && !glds) { set_error("conv wgrad: the fused bias gradient needs OH*OW %% 16 == 0 and 16-byte aligned dy"); return SCDA_EINVAL; }
     float *db_ws = db ? ws + (size_t)splits * g.M * g.N : nullptr;
-#define WGRAD_GLDS_LAUNCH(BM_, BN_) hipLaunchKernelGGL((conv_wgrad_glds_kernel<BM_, BN_, KH, KW, S>), grid, dim3(256), 0, st, dY, X, g, ws, db_ws)
+#define WGRAD_GLDS_LAUNCH(BM_, BN_) hipLaunchKernelGGL((conv_wgrad_glds_kernel<BM_, BN_, KH, KW, S>), grid, dim3(WgradGldsCfg<BM_, BN_>::THREADS), 0, st, dY, X, g, ws, db_ws)
     if (glds && BMv == 256) {
-        hipLaunchKernelGGL((conv_wgrad_glds_kernel<256, 128, KH, KW, S>), grid, dim3(512), 0, st, dY, X, g, ws, db_ws);
+        hipLaunchKernelGGL((conv_wgrad_glds_kernel<256, 128, KH, KW, S>), grid, dim3(WgradGldsCfg<256, 128>::THREADS), 0, st, dY, X, g, ws, db_ws);
     } else if (glds) {
         if (small && BNv == 64) WGRAD_GLDS_LAUNCH(64, 64);
         else if (small) WGRAD_GLDS_LAUNCH(64, 128);
