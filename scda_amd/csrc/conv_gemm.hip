@@ -666,7 +666,7 @@ struct WgradGldsCfg {
     static constexpr int WM = BM / WGM, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     static constexpr int A_TOTAL = BM / 16, GROUPS = BN / 4;   // LDS-DMA instructions per slab: dY (16 rows each), X (4 rows each)
     static constexpr int L_TOTAL = A_TOTAL + GROUPS;
-    static constexpr int NP = 4;   // one swizzle class per staging wave
+    static constexpr int NP = 4;   // one swizzle class per staging wave (measured: 2 waves with two classes each lose 5-15 %)
     static constexpr int A_PP = A_TOTAL / NP, CLS_PP = 4 / NP, G_PC = GROUPS / 4;   // per staging wave: A instr, classes; groups per class
     static constexpr int L = A_PP + CLS_PP * G_PC;
     static constexpr int THREADS = (NWC + NP) * 64;
@@ -707,7 +707,14 @@ __global__ __launch_bounds__((WgradGldsCfg<BM, BN>::THREADS)) void conv_wgrad_gl
             a_voff[i] = m0 + row < g.M ? (unsigned)(((m0 + row) * ohw + 4 * c) * 4) : OOB;
         }
         unsigned b_off[C::CLS_PP][C::G_PC], b_sh[C::CLS_PP][C::G_PC];
-        int oy[C::CLS_PP], ox[C::CLS_PP];
+        int oy[C::CLS_PP], ox[C::CLS_PP], klp[C::CLS_PP];
+        // Stride 1 and OW % 16 == 0 (every VGG / decoder layer of the workload): the 16 pixels of a slab lie in ONE output row.
+        // Row validity of the taps and the slab's pixel offset are then scalar (SALU work of the staging wave), a lane's
+        // offset is a per-load CONSTANT plus the validity bit, and the per-slab VALU work drops from ~57 to ~28 instructions
+        // per class -- this wave's instruction stream is what bounds the kernel (with the address work ablated away it runs at
+        // 134 instead of 119 TFLOP/s on conv3_2).
+        const bool row_slab = S == 1 && (g.dOW.d % BK) == 0;
+        const int bias = (g.pad * g.IW + g.pad) * 4;   // bytes the descriptor base is moved back by
         // slab cursor: image and first pixel (scalar), the lane's output pixel per class; advanced by 16 pixels per issue
         int img0, pix0, step_y, step_x;
         g.dOHW.divmod(s_begin * BK, img0, pix0);
@@ -724,8 +731,13 @@ __global__ __launch_bounds__((WgradGldsCfg<BM, BN>::THREADS)) void conv_wgrad_gl
                 const int kh = rem / KW, kw = rem - kh * KW;
                 b_off[c][j] = n < g.N ? (unsigned)((ci * ihw + (kh - g.pad) * g.IW + (kw - g.pad)) * 4) : OOB;
                 b_sh[c][j] = 31 - (kh * KW + kw);
+                // row-slab form: + the lane's pixel inside the slab + the bias that keeps every lane offset non-negative
+                if (row_slab && n < g.N) b_off[c][j] += (unsigned)(kl * 4 + bias);
             }
+            klp[c] = kl - g.pad;
         }
+        int oy_s, ox_s;   // row-slab form: output row and first column of the slab (scalar)
+        g.dOW.divmod(pix0, oy_s, ox_s);
         const char *a_img = reinterpret_cast<const char *>(dY) + (size_t)img0 * g.Cout * ohw * 4;
         const char *x_img = reinterpret_cast<const char *>(X) + (size_t)img0 * g.Cin * ihw * 4;
         const size_t a_img_stride = (size_t)g.Cout * ohw * 4, x_img_stride = (size_t)g.Cin * ihw * 4;
@@ -737,6 +749,31 @@ __global__ __launch_bounds__((WgradGldsCfg<BM, BN>::THREADS)) void conv_wgrad_gl
             for (int i = 0; i < C::A_PP; ++i) buffer_load_lds_b128(a_slab, a_voff[i], st + (p * C::A_PP + i) * 16 * 16);
             float *Bb = st + BK * BM;
             const bool wrap = pix0 + BK >= ohw;
+            if (row_slab) {
+                unsigned rows = 0;   // copies of the column bits go where the tap rows are inside the image
+#pragma unroll
+                for (int kh = 0; kh < KH; ++kh) rows |= (unsigned)((unsigned)(oy_s + kh - g.pad) < (unsigned)g.IH) << (kh * KW);
+                const int soff = (oy_s * g.IW + ox_s) * 4;
+                const char *xb = x_img - bias;
+#pragma unroll
+                for (int c = 0; c < C::CLS_PP; ++c) {
+                    const int cls = p * C::CLS_PP + c;
+                    const int ix0 = ox_s + klp[c];
+                    unsigned colb = 0;
+#pragma unroll
+                    for (int kw = 0; kw < KW; ++kw) colb |= (unsigned)((unsigned)(ix0 + kw) < (unsigned)g.IW) << kw;
+                    const unsigned off_taps = ~(colb * rows);
+#pragma unroll
+                    for (int j = 0; j < C::G_PC; ++j)
+                        buffer_load_lds_b32(xb, b_off[c][j] | ((off_taps << b_sh[c][j]) & OOB), Bb + (16 * j + 4 * cls) * 16, soff);
+                }
+                ox_s += BK;
+                if (ox_s >= g.dOW.d) { ox_s = 0; ++oy_s; }
+                if (wrap) oy_s = 0;
+                pix0 += BK;
+                if (wrap) { pix0 = 0; a_img += a_img_stride; x_img += x_img_stride; }
+                return;
+            }
 #pragma unroll
             for (int c = 0; c < C::CLS_PP; ++c) {
                 const int cls = p * C::CLS_PP + c;
