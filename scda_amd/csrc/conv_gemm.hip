@@ -252,8 +252,9 @@ __device__ __forceinline__ void buffer_load_lds_b32(const void *base, const unsi
 __device__ __forceinline__ void buffer_load_lds_b128(const void *base, const unsigned voffset, float *lds_dst, const int soffset = 0) { SCDA_BUFFER_LOAD_LDS(16); }
 #undef SCDA_BUFFER_LOAD_LDS
 
-// ---- operand staging shared by the dense GEMM and the weight-gradient kernels ------------------------------------------
-// They use the ring / vmcnt / barrier schedule of conv_igemm_glds_kernel (below); what differs is how a tile lands in LDS:
+// ---- operand layouts in LDS shared by the dense GEMM and the weight-gradient kernels (fragment readers) ------------------
+// They use the ring / staging-wave / barrier schedule of conv_igemm_glds_kernel (below); what differs is how a tile lands in
+// LDS (the staging side is GldsStager for the GEMM, the staging-wave branch of conv_wgrad_glds_kernel for the gradient):
 //   MC (stored [K][MN], MN contiguous): rows of the tile are K-rows, laid down as [16][BMN] by dwordx4 LDS-DMA; the MFMA
 //      operand fetch is one ds_read_b32 per K value (32 consecutive words per half-wave).
 //   KC (stored [MN][K], K contiguous -- activations and nn.Linear weights): a dwordx4 covers 4 consecutive K of one row, 4
@@ -266,31 +267,6 @@ __device__ __forceinline__ void buffer_load_lds_b128(const void *base, const uns
 //      c ^ ((r>>2)&3)) and undone by the reader.
 template <int BMN, bool MC, int NW = 4>
 struct GldsOperand {
-    static constexpr int PW = BMN / 16 / NW;   // LDS-DMA instructions per wave per 16-deep slab (both layouts), NW waves
-    // issue this wave's share of one slab: tile rows/cols start at mn0, K at k0
-    __device__ static __forceinline__ void issue(const float *__restrict__ base, const int ld, const int extent, const int mn0,
-                                                 const int k0, float *stage, const int wave, const int lane,
-                                                 const float *zp) {
-        if (MC) {
-            constexpr int LPR = BMN / 4, RPI = 64 / LPR;
-            const int col = (lane % LPR) * 4;
-            const bool ok = mn0 + col < extent;
-#pragma unroll
-            for (int i = 0; i < PW; ++i) {
-                const int row0 = (wave * PW + i) * RPI;
-                const float *src = ok ? base + (size_t)(k0 + row0 + lane / LPR) * ld + mn0 + col : zp;
-                __builtin_amdgcn_global_load_lds((glb_void_t *)src, (lds_void_t *)(stage + row0 * BMN), 16, 0, 0);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < PW; ++i) {
-                const int row0 = (wave * PW + i) * 16, row = row0 + (lane >> 2);
-                const int c = (lane & 3) ^ ((row >> 2) & 3);
-                const float *src = mn0 + row < extent ? base + (size_t)(mn0 + row) * ld + k0 + 4 * c : zp;
-                __builtin_amdgcn_global_load_lds((glb_void_t *)src, (lds_void_t *)(stage + row0 * 16), 16, 0, 0);
-            }
-        }
-    }
     // fragment for K-group q of the 32-row MFMA tile starting at tile row `r0`: f[t] = operand[r0 + lr][8q + 4h + t]
     __device__ static __forceinline__ void frag(const float *stage, const int r0, const int lr, const int h, const int q,
                                                 float (&f)[4]) {
@@ -1061,33 +1037,110 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float *__restrict__ A, 
     }
 }
 
-// ---- dense GEMM, direct-to-LDS (operand staging: GldsOperand above) -------------------------------------------------
+// ---- dense GEMM, direct-to-LDS ----------------------------------------------------------------------------------------
+// One operand's share of the ring for staging wave p of NP: LDS-DMA instructions [p*PP, (p+1)*PP) of the BMN/16 that make a
+// 16-deep slab, in the layouts GldsOperand reads.  Everything that does not depend on the slab is fixed at init: the lane
+// offset (with the out-of-range rows / columns encoded as bit 31, see buffer_load_lds_*), the scalar step between
+// instructions; a slab only moves the descriptor base.
+template <int BMN, bool MC, int NP>
+struct GldsStager {
+    static constexpr int TOTAL = BMN / 16, PP = TOTAL / NP;
+    static constexpr int LPR = BMN / 4, RPI = 64 / LPR;   // MC: lanes per K-row, K-rows per instruction
+    static_assert(TOTAL % NP == 0, "staging split");
+    unsigned voff[MC ? 1 : PP];
+    const char *base0;
+    long long kstep;   // bytes per unit of K
+    int istep;         // bytes between consecutive instructions of this wave
+    int dst0;          // first LDS float of this wave's share inside the operand's stage
+    __device__ __forceinline__ void init(const float *base, const int ld, const int extent, const int mn0, const int p, const int lane) {
+        constexpr unsigned OOB = 0x80000000u;
+        if (MC) {   // instruction gi covers K-rows [gi*RPI, +RPI), 4 consecutive MN per lane
+            const int col = (lane % LPR) * 4;
+            voff[0] = mn0 + col < extent ? (unsigned)(((lane / LPR) * ld + mn0 + col) * 4) : OOB;
+            base0 = reinterpret_cast<const char *>(base + (size_t)(p * PP * RPI) * ld);
+            kstep = (long long)ld * 4;
+            istep = RPI * ld * 4;
+            dst0 = p * PP * RPI * BMN;
+        } else {    // instruction gi covers MN-rows [gi*16, +16), 4 consecutive K per lane, 16-byte chunks XOR-swizzled
+#pragma unroll
+            for (int i = 0; i < PP; ++i) {
+                const int row = (p * PP + i) * 16 + (lane >> 2);
+                const int c = (lane & 3) ^ ((row >> 2) & 3);
+                voff[i] = mn0 + row < extent ? (unsigned)(((lane >> 2) * ld + 4 * c) * 4) : OOB;
+            }
+            base0 = reinterpret_cast<const char *>(base + ((size_t)mn0 + p * PP * 16) * ld);
+            kstep = 4;
+            istep = 16 * ld * 4;
+            dst0 = p * PP * 16 * 16;
+        }
+    }
+    __device__ __forceinline__ void issue(const int k0, float *stage) const {
+        const char *b = base0 + (long long)k0 * kstep;
+#pragma unroll
+        for (int i = 0; i < PP; ++i)
+            buffer_load_lds_b128(b, voff[MC ? 0 : i], stage + dst0 + i * (MC ? RPI * BMN : 16 * 16), i * istep);
+    }
+};
+
+template <int BM, int BN>
+struct GemmGldsCfg {
+    static constexpr int NWC = BM == 256 ? 8 : 4;          // compute waves: 256 x 128 tile: 4 x 2
+    static constexpr int NP = (BM + BN) / 16 > 16 ? 2 : 1; // staging waves (see ConvGldsCfg): at most 16 LDS-DMA instructions each
+    static constexpr int L = (BM + BN) / 16 / NP;
+    static constexpr int THREADS = (NWC + NP) * 64;
+};
+
 template <int BM, int BN, bool TA, bool TB>
-__global__ __launch_bounds__(BM == 256 ? 512 : 256) void gemm_glds_kernel(const float *__restrict__ A,
-                                                                          const float *__restrict__ B, const GemmGeom g,
-                                                                          const Epi e) {
-    constexpr int NW = BM == 256 ? 8 : 4;          // 256 x 128 tile: 4 x 2 waves
-    using OA = GldsOperand<BM, TA, NW>;
-    using OB = GldsOperand<BN, TB, NW>;
+__global__ __launch_bounds__((GemmGldsCfg<BM, BN>::THREADS)) void gemm_glds_kernel(const float *__restrict__ A,
+                                                                                 const float *__restrict__ B, const GemmGeom g,
+                                                                                 const Epi e) {
+    using C = GemmGldsCfg<BM, BN>;
+    constexpr int NWC = C::NWC, L = C::L;
+    using OA = GldsOperand<BM, TA, NWC>;   // fragment readers
+    using OB = GldsOperand<BN, TB, NWC>;
     constexpr int NST = 4, STAGE = BK * (BM + BN);
-    constexpr int WM = BM / (NW / 2), WN = BN / 2, TM = WM / 32, TN = WN / 32;
-    constexpr int L = OA::PW + OB::PW;
+    constexpr int WM = BM / (NWC / 2), WN = BN / 2, TM = WM / 32, TN = WN / 32;
     __shared__ __attribute__((aligned(16))) float lds[NST * STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
     int tx, ty, tz;
     tile_coords(g.nx, g.ny, g.swz, tx, ty, tz);
     const int m0 = ty * BM, n0 = tx * BN;
     const int s_begin = tz * (g.k_per_split / BK);
     const int s_end = min(g.K, (tz + 1) * g.k_per_split) / BK;
 
-    auto issue = [&](int s, int buf) {
-        float *st = lds + buf * STAGE;
-        OA::issue(A, g.lda, g.M, m0, s * BK, st, wave, lane, g.zp);
-        OB::issue(B, g.ldb, g.N, n0, s * BK, st + BK * BM, wave, lane, g.zp);
-    };
+    if (wave >= NWC) {   // ---- staging wave ------------------------------------------------------------------------------------
+        const int p = wave - NWC;
+        __builtin_amdgcn_s_setprio(3);
+        GldsStager<BM, TA, C::NP> sa;
+        GldsStager<BN, TB, C::NP> sb;
+        sa.init(A, g.lda, g.M, m0, p, lane);
+        sb.init(B, g.ldb, g.N, n0, p, lane);
+        auto issue = [&](int s, int buf) {
+            float *st = lds + buf * STAGE;
+            sa.issue(s * BK, st);
+            sb.issue(s * BK, st + BK * BM);
+        };
+        if (s_begin < s_end) issue(s_begin, 0);
+        if (s_begin + 1 < s_end) issue(s_begin + 1, 1);
+        int nbuf = 2;
+        for (int s = s_begin; s < s_end; ++s) {
+            if (s + 2 < s_end) {
+                issue(s + 2, nbuf);
+                SCDA_WAIT_VMCNT(2 * L);
+            } else if (s + 1 < s_end) {
+                SCDA_WAIT_VMCNT(L);
+            } else {
+                SCDA_WAIT_VMCNT(0);
+            }
+            __builtin_amdgcn_s_barrier();
+            nbuf = (nbuf + 1) & (NST - 1);
+        }
+        return;
+    }
 
+    // ---- compute waves ------------------------------------------------------------------------------------------------------
+    const int wm = wave >> 1, wn = wave & 1;
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -1096,19 +1149,9 @@ __global__ __launch_bounds__(BM == 256 ? 512 : 256) void gemm_glds_kernel(const 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
     const int lr = lane & 31, lh = lane >> 5;
-
-    if (s_begin < s_end) issue(s_begin, 0);
-    if (s_begin + 1 < s_end) issue(s_begin + 1, 1);
-    int buf = 0, nbuf = 2;
+    int buf = 0;
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): no kernel-argument load pending inside the loop (see conv_wgrad_glds_kernel)
     for (int s = s_begin; s < s_end; ++s) {
-        if (s + 2 < s_end) {
-            issue(s + 2, nbuf);
-            SCDA_WAIT_VMCNT(2 * L);
-        } else if (s + 1 < s_end) {
-            SCDA_WAIT_VMCNT(L);
-        } else {
-            SCDA_WAIT_VMCNT(0);
-        }
         __builtin_amdgcn_s_barrier();
         const float *as = lds + buf * STAGE, *bs = as + BK * BM;
         float a[2][TM][4], b[2][TN][4];
@@ -1120,6 +1163,7 @@ __global__ __launch_bounds__(BM == 256 ? 512 : 256) void gemm_glds_kernel(const 
         for (int i = 0; i < TM; ++i) OA::frag(as, wm * WM + i * 32, lr, lh, 1, a[1][i]);
 #pragma unroll
         for (int j = 0; j < TN; ++j) OB::frag(bs, wn * WN + j * 32, lr, lh, 1, b[1][j]);
+        __builtin_amdgcn_sched_barrier(0);   // all fragment reads in flight before the first MFMA
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -1130,7 +1174,6 @@ __global__ __launch_bounds__(BM == 256 ? 512 : 256) void gemm_glds_kernel(const 
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][i][t], b[q][j][t], acc[i][j], 0, 0, 0);
         buf = (buf + 1) & (NST - 1);
-        nbuf = (nbuf + 1) & (NST - 1);
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -1653,8 +1696,10 @@ SCDA_API int scda_gemm_hip(const float *A, const float *B, float *C, int M, int 
     hipStream_t st = as_stream(stream);
     // direct-to-LDS kernel: whole 16-deep slabs, 16-byte addressable rows
     static const bool no_glds = getenv("SCDA_GEMM_NO_GLDS") != nullptr;   // A/B knob
+    // (+ 32-bit lane offsets inside a descriptor: 256 rows of either operand stay below 2 GB)
     const bool glds = !no_glds && (K % BK) == 0 && (lda % 4) == 0 && (ldb % 4) == 0 && ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0 &&
-                      (!trans_a || (M % 4) == 0) && (!trans_b || (N % 4) == 0);
+                      (!trans_a || (M % 4) == 0) && (!trans_b || (N % 4) == 0) && (long long)lda * 1024 + (long long)M * 4 < (1LL << 31) &&
+                      (long long)ldb * 1024 + (long long)N * 4 < (1LL << 31);
     const char *fbm = getenv("SCDA_CONV_BM");                              // 256 forces the 8-wave tile where legal
     // (not for the [K][M] x [K][N] form -- the FC weight gradient: measured 112 vs 115 TFLOP/s)
     const bool bm256_ok = glds && (M % 256) == 0 && N > 64 && !(trans_a && trans_b);
@@ -1685,10 +1730,10 @@ SCDA_API int scda_gemm_hip(const float *A, const float *B, float *C, int M, int 
     } while (0)
 #define GEMM_GLDS_LAUNCH(BM_, BN_)                                                                       \
     do {                                                                                                 \
-        if (!trans_a && !trans_b) hipLaunchKernelGGL((gemm_glds_kernel<BM_, BN_, false, false>), grid, dim3(BM_ == 256 ? 512 : 256), 0, st, A, B, g, e); \
-        else if (!trans_a && trans_b) hipLaunchKernelGGL((gemm_glds_kernel<BM_, BN_, false, true>), grid, dim3(BM_ == 256 ? 512 : 256), 0, st, A, B, g, e); \
-        else if (trans_a && !trans_b) hipLaunchKernelGGL((gemm_glds_kernel<BM_, BN_, true, false>), grid, dim3(BM_ == 256 ? 512 : 256), 0, st, A, B, g, e); \
-        else hipLaunchKernelGGL((gemm_glds_kernel<BM_, BN_, true, true>), grid, dim3(BM_ == 256 ? 512 : 256), 0, st, A, B, g, e);  \
+        if (!trans_a && !trans_b) hipLaunchKernelGGL((gemm_glds_kernel<BM_, BN_, false, false>), grid, dim3(GemmGldsCfg<BM_, BN_>::THREADS), 0, st, A, B, g, e); \
+        else if (!trans_a && trans_b) hipLaunchKernelGGL((gemm_glds_kernel<BM_, BN_, false, true>), grid, dim3(GemmGldsCfg<BM_, BN_>::THREADS), 0, st, A, B, g, e); \
+        else if (trans_a && !trans_b) hipLaunchKernelGGL((gemm_glds_kernel<BM_, BN_, true, false>), grid, dim3(GemmGldsCfg<BM_, BN_>::THREADS), 0, st, A, B, g, e); \
+        else hipLaunchKernelGGL((gemm_glds_kernel<BM_, BN_, true, true>), grid, dim3(GemmGldsCfg<BM_, BN_>::THREADS), 0, st, A, B, g, e);  \
     } while (0)
     note_plan(BMv, BNv, splits, glds);
     prof_begin(PK_GEMM, 2.0 * M * (double)N * K, st);
