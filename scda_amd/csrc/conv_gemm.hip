@@ -905,10 +905,21 @@ __global__ __launch_bounds__(256) void dense_splitk_reduce_kernel(const float *_
         if (G > 1) __syncthreads();
     }
     if (db_ws) {   // second, tiny job of the same launch: db[m] (+)= sum over splits of the fused bias-gradient partials
-        for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < db_n; m += blockDim.x * gridDim.x) {
+        // one workgroup per row, the slabs spread over its threads and combined by a fixed-shape tree (one thread walking
+        // 256 slabs was a chain of 256 loads: 70 us for the 32-channel layers, longer than their whole weight reduce)
+        float *red = &part[0][0];   // G * (E + 1) >= 256 floats
+        for (int m = blockIdx.x; m < db_n; m += gridDim.x) {
             float v = 0.f;
-            for (int s = 0; s < splits; ++s) v += db_ws[(size_t)s * db_n + m];
-            db[m] = db_accumulate ? db[m] + v : v;
+            for (int s = threadIdx.x; s < splits; s += 256) v += db_ws[(size_t)s * db_n + m];
+            __syncthreads();
+            red[threadIdx.x] = v;
+            __syncthreads();
+#pragma unroll
+            for (int w = 128; w > 0; w >>= 1) {
+                if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) db[m] = db_accumulate ? db[m] + red[0] : red[0];
         }
     }
 }
