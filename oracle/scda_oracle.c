@@ -10,12 +10,16 @@
  *   bbox_overlaps (IoU without +1): BIT-EXACT against the reference's own Cython
  *     (extensions/_cython_bbox/cython_bbox.pyx built unmodified by
  *     oracle/build_ref.py; vectors in tests/golden/bbox_overlaps.npz).
- *   NMS, RoIPool, RoIAlign, focal loss, the "+1/clamped" IoU: PARITY UNPINNED
+ *   NMS (mask + sweep, and the ">=" CPU variant): BIT-EXACT against keep lists
+ *     produced by the reference's own extensions/_cython_bbox/cython_nms.pyx,
+ *     compiled unmodified with the image's python3.9 / numpy 1.26 / Cython 0.29
+ *     (oracle/build_ref.py; tests/golden/make_golden_nms.py -> nms_ref.npz:
+ *     300 ... 12000 boxes, RPN-like / clustered / integer, thresholds .7/.5/.3,
+ *     inputs tie-free at the threshold where ">=" and ">" part ways).
+ *   RoIPool, RoIAlign, focal loss, the "+1/clamped" IoU: PARITY UNPINNED
  *     against a build of the reference.  Their sources cannot be built or run
  *     here: the .cu files need nvcc and the TH/THC headers torch 2.x no longer
- *     ships; nms.c / roi_pooling.c use the removed TH API; cython_nms.pyx needs
- *     the compile-time ctypedef np.int_t that numpy 2.x dropped (build_ref.py
- *     keeps the attempt and prints the compiler error); roi_pool_py.py indexes
+ *     ships; roi_pooling.c uses the removed TH API; roi_pool_py.py indexes
  *     0-dim tensors and relies on torch<=0.3 `max` keeping the reduced
  *     dimension.  The reference holds no tests or vectors for them.  What they
  *     ARE checked against: independent second statements written from the

@@ -3,6 +3,8 @@ calls them (the GPU nms is used everywhere); kept for import compatibility as pl
 hundred boxes."""
 import numpy as np
 
+f32, f64 = np.float32, np.float64
+
 
 def nms(dets, thresh):
     """greedy NMS, IoU(+1) >= thresh suppresses; returns np.where(suppressed == 0)[0] like the reference"""
@@ -38,15 +40,19 @@ def soft_nms(boxes_in, sigma=0.5, Nt=0.3, threshold=0.001, method=0):
         pos = i + 1
         while pos < n:
             x1, y1, x2, y2 = boxes[pos, :4]
-            iw = min(tx2, x2) - max(tx1, x1) + 1
-            ih = min(ty2, y2) - max(ty1, y1) + 1
+            # Cython writes the source's "+ 1" next to a C float as "+ 1.0": those sums and the products around them are evaluated
+            # in double and rounded once on assignment to the `cdef float` (cython_nms.pyx:163-170)
+            iw = f32(f64(min(tx2, x2) - max(tx1, x1)) + 1.0)
+            ih = f32(f64(min(ty2, y2) - max(ty1, y1)) + 1.0)
             if iw > 0 and ih > 0:
-                ua = (tx2 - tx1 + 1) * (ty2 - ty1 + 1) + (x2 - x1 + 1) * (y2 - y1 + 1) - iw * ih
-                ov = iw * ih / ua
+                area = f32((f64(x2 - x1) + 1.0) * (f64(y2 - y1) + 1.0))
+                ua = f32((f64(tx2 - tx1) + 1.0) * (f64(ty2 - ty1) + 1.0) + f64(area) - f64(iw * ih))
+                ov = (iw * ih) / ua
                 if method == 1:
                     wgt = 1 - ov if ov > Nt else 1
                 elif method == 2:
-                    wgt = np.exp(-(ov * ov) / sigma)
+                    # float32 argument, double exp, rounded to the reference's `cdef float weight` (cython_nms.pyx:179)
+                    wgt = np.float32(np.exp(np.float64(np.float32(-(ov * ov)) / np.float32(sigma))))
                 else:
                     wgt = 0 if ov > Nt else 1
                 boxes[pos, 4] *= wgt

@@ -37,6 +37,25 @@ def test_nms_keep_bit_exact(cuda, n, thresh, integer):
     np.testing.assert_array_equal(keep[:k].cpu().numpy(), ref)
 
 
+def test_nms_keep_equals_reference_cython_nms(cuda, golden_dir):
+    """scda_nms_hip against keep lists produced by the REFERENCE's cython_nms.pyx compiled unmodified
+    (tests/golden/nms_ref.npz, make_golden_nms.py): bit-exact at 300 ... 12000 boxes, RPN-like / clustered / integer boxes.
+    Also through the operator boundary (`from extensions import nms`) and through the validity-flag sweep of the
+    device-resident proposal path with every box valid."""
+    from scda_amd import dropin, native
+    from test_oracle_golden import _nms_ref
+    dropin.install()
+    from extensions import nms as ext_nms
+    for name, dets, thresh, ref in _nms_ref(golden_dir):
+        d = dev(dets, cuda)
+        keep, num = native.nms(d, thresh)
+        k = int(num.item())
+        np.testing.assert_array_equal(keep[:k].cpu().numpy(), ref, err_msg=name)
+        np.testing.assert_array_equal(ext_nms(d, thresh).cpu().numpy(), ref, err_msg=name + " (extensions.nms)")
+        keep, num = native.nms(d, thresh, max_keep=2000)
+        np.testing.assert_array_equal(keep[:int(num.item())].cpu().numpy(), ref[:2000], err_msg=name + " (max_keep)")
+
+
 @pytest.mark.parametrize("n,max_keep", [(500, 10), (3000, 300), (12000, 2000), (700, 100000)])
 def test_nms_max_keep_equals_truncation(cuda, n, max_keep):
     from scda_amd import native
