@@ -508,6 +508,42 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(const long long tota
     }
 }
 
+// Plane-resident form of the backward: one workgroup owns one (image, channel) plane of the gradient, keeps it in LDS, walks
+// every RoI of that image (thread = one bin; 256 / (AH*AW) RoIs in flight) and adds the four bilinear corners with LDS
+// atomics (ds_add_f32), then adds the plane to the output once.  The global-atomic form above sends 4 x R x C x AH x AW float
+// atomics to the L2 (512 RoIs x 1024 channels x 8 x 8: 134 M atomics, 2.7 ms on the ResNet-50 C4 head); here the L2 sees one
+// coalesced read of the top gradient and one read-modify-write of the plane.
+__global__ __launch_bounds__(256) void roi_align_bwd_plane_kernel(const float *__restrict__ top, const int R, const float scale,
+                                                                  const int C, const int H, const int W, const int AH,
+                                                                  const int AW, float *__restrict__ bottom,
+                                                                  const float *__restrict__ rois) {
+    extern __shared__ float plane[];
+    const int c = blockIdx.x % C, b = blockIdx.x / C;
+    const int hw = H * W, bins = AH * AW;
+    for (int i = threadIdx.x; i < hw; i += 256) plane[i] = 0.f;
+    __syncthreads();
+    const int per = 256 / bins;                     // RoIs in flight (bins <= 256, checked by the launcher)
+    const int sub = threadIdx.x / bins, bin = threadIdx.x - sub * bins;
+    const int ph = bin / AW, pw = bin - ph * AW;
+    const int plane_base = (b * C + c) * hw;
+    if (sub < per) {
+        for (int n = sub; n < R; n += per) {
+            const float *roi = rois + (size_t)n * 5;
+            if ((int)roi[0] != b) continue;
+            const RaPoint p = ra_point(roi, scale, C, H, W, AH, AW, c, ph, pw);
+            if (!p.ok) continue;
+            const double hr = p.hr, wr = p.wr, d = top[((size_t)n * C + c) * bins + bin];
+            const int o = p.upleft - plane_base;
+            atomicAdd(plane + o, (float)(d * (1. - hr) * (1 - wr)));
+            atomicAdd(plane + o + 1, (float)(d * (1. - hr) * wr));
+            atomicAdd(plane + o + W, (float)(d * hr * (1 - wr)));
+            atomicAdd(plane + o + W + 1, (float)(d * hr * wr));
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < hw; i += 256) bottom[(size_t)plane_base + i] += plane[i];
+}
+
 // ---------------------------------------------------------------------------
 // Focal loss.  Reference: extensions/_focal_loss/src/cuda/focal_loss_{sigmoid,softmax}_kernel.cu
 // ---------------------------------------------------------------------------
@@ -809,6 +845,14 @@ SCDA_API int scda_roi_align_bwd_hip(const float *top_grad, const float *rois, in
     if (R == 0) return SCDA_OK;
     if (!top_grad || !rois || !bottom_grad) { set_error("scda_roi_align_bwd_hip: null pointer"); return SCDA_EINVAL; }
     const long long total = (long long)R * C * AH * AW;
+    const size_t lds = (size_t)H * W * sizeof(float);
+    // (int)roi[0] * C*H*W must equal the plane the workgroup owns: batch indices are integral in every caller (checked by the
+    // reference too, roi_align_kernel.cu:33); planes that do not fit 64 KB of LDS keep the global-atomic form
+    if (lds <= 64 * 1024 && AH * AW <= 256 && !getenv("SCDA_ROI_ALIGN_ATOMIC")) {
+        hipLaunchKernelGGL(roi_align_bwd_plane_kernel, dim3((unsigned)((long long)B * C)), dim3(256), lds, as_stream(stream), top_grad, R,
+                           spatial_scale, C, H, W, AH, AW, bottom_grad, rois);
+        return launch_status("roi_align_bwd_plane_kernel");
+    }
     hipLaunchKernelGGL(roi_align_bwd_kernel, dim3(ew_grid(total) * 8), dim3(256), 0, as_stream(stream), total, top_grad,
                        spatial_scale, C, H, W, AH, AW, bottom_grad, rois);
     return launch_status("roi_align_bwd_kernel");

@@ -107,15 +107,19 @@ class _Frozen:
 
 class ScdaTrainer:
     def __init__(self, cfg, device, lr=1.25e-5, cluster_num=4, threshold=128, recon_size=256, new_w=1024, new_h=512,
-                 weight_decay=1e-4, world_size=1, models=None, recon_hw=None, reference_style=False):
+                 weight_decay=1e-4, world_size=1, models=None, recon_hw=None, reference_style=False, collectives=None):
         """recon_hw: (height, width) of the reconstructions / image crops when they are not recon_size x recon_size (a
         detector whose RoI feature does not unfold to a square map: see scda_amd/resnet_config.py).
         reference_style: run the iteration the way the reference's own driver would on top of the drop-in modules -- four
         `torch.optim.Adam` instances over plain parameter lists (tools/faster_rcnn_train_val.py:305-316), phases strictly in
         program order on one stream, detector backward last, `average_gradients(model)` per phase -- so that the cost of NOT
         using this repository's step (flat buckets + fused Adam, early backward, side streams) can be measured
-        (scripts/bench_reference_style.py)."""
+        (scripts/bench_reference_style.py).
+        collectives: issue the four per-phase all-reduces (default: world_size > 1).  True with a one-rank process group runs
+        the whole RCCL path -- async all-reduce on the device buckets, waits, stream hand-over -- on a single GPU
+        (tests/test_distributed_gpu.py::test_rccl_one_rank_group_matches_plain_step)."""
         self.cfg, self.device = cfg, device
+        self.collectives = (world_size > 1) if collectives is None else bool(collectives)
         from .hostenv import configure_host_threads
         configure_host_threads()
         self.cluster_num, self.threshold, self.recon = cluster_num, threshold, (recon_hw or recon_size)
@@ -207,7 +211,7 @@ class ScdaTrainer:
         if self.capture:
             name = {id(self.model): 'det', id(self.dec): 'dec', id(self.dis): 'dis', id(self.dis_patch): 'dis_patch'}[id(module)]
             self.trace[name] = {k: p.grad.detach().clone() for k, p in module.named_parameters()}
-        if self.world_size > 1:
+        if self.collectives:
             return average_gradients(module, async_op=async_op)
         return None
 

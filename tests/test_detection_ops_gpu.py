@@ -146,6 +146,23 @@ def test_roi_align_fwd_bwd(cuda):
     np.testing.assert_allclose(g.cpu().numpy(), eg, rtol=1e-5, atol=1e-5)  # atomics: order differs
 
 
+@pytest.mark.parametrize("shape,R,a", [((1, 24, 50, 84), 512, 8), ((2, 5, 13, 9), 33, 7), ((1, 3, 200, 336), 40, 8)])
+def test_roi_align_bwd_plane_and_atomic_forms_agree(cuda, shape, R, a, monkeypatch):
+    """the LDS-resident plane kernel (planes <= 64 KB) and the global-atomic kernel (larger planes, SCDA_ROI_ALIGN_ATOMIC=1)
+    against the oracle and against each other, at the ResNet-50 C4 head's geometry (512 RoIs on a 50 x 84 map)"""
+    from scda_amd import native
+    rs = np.random.RandomState(R)
+    rois = rand_rois(rs, R, B=shape[0], W=shape[3] * 16, H=shape[2] * 16)
+    top = rs.randn(R, shape[1], a, a).astype(np.float32)
+    want = orc.roi_align_bwd(top, rois, shape, a, a, 1 / 16.)
+    got = native.roi_align_bwd(dev(top, cuda), dev(rois, cuda), shape, a, a, 1 / 16.).cpu().numpy()
+    monkeypatch.setenv("SCDA_ROI_ALIGN_ATOMIC", "1")
+    got_atomic = native.roi_align_bwd(dev(top, cuda), dev(rois, cuda), shape, a, a, 1 / 16.).cpu().numpy()
+    scale = np.abs(want).max()
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5 * scale)
+    np.testing.assert_allclose(got_atomic, want, rtol=1e-5, atol=1e-5 * scale)
+
+
 def test_focal_sigmoid(cuda):
     from scda_amd import native
     rs = np.random.RandomState(22)

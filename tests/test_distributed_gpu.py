@@ -149,3 +149,58 @@ def test_reduced_gradient_equals_oracle_sum_of_samples(cuda, tmp_path):
             errs.append(float((got[0]['reduced'][n][k].double() - w.double()).norm() / w.double().norm()))
         errs.sort()
         assert errs[len(errs) // 2] < 5e-3 and errs[-1] < 5e-2, (n, errs[len(errs) // 2], errs[-1])
+
+
+def _rccl_worker(rank, port, out_dir):
+    """ONE rank, backend 'nccl' (= RCCL): everything the N-GPU run does except moving bytes over xGMI"""
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.pop("SLURM_PROCID", None)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import model_common as mc
+    from scda_amd.dropin.utils.distributed_utils import average_gradients, broadcast_params, dist_init
+    from scda_amd.train_step import ScdaTrainer
+    from test_train_step_gpu import build_product
+    r, w = dist_init(port, backend='nccl')                 # utils/distributed_utils.py:21-53, the 'nccl' branch
+    assert (r, w) == (0, 1) and dist.get_backend() == "nccl"
+    dev = torch.device("cuda", 0)
+    H, W = 256, 512
+    res = {}
+    for name, coll in (("rccl", True), ("plain", False)):
+        torch.manual_seed(1)
+        tr = ScdaTrainer(mc.CFG, dev, lr=1e-3, new_w=W, new_h=H, world_size=1, models=mc.seeded_models(build_product),
+                         collectives=coll)
+        if coll:
+            for m in (tr.model, tr.dec, tr.dis, tr.dis_patch):
+                broadcast_params(m)                        # one RCCL broadcast per flat bucket + buffers
+        np.random.seed(7)
+        torch.manual_seed(11)
+        losses = []
+        for it in range(3):
+            src, tgt, gts, info = mc.seeded_inputs(H, W, sample=it % 2)
+            losses.append(float(tr.step(src.to(dev), gts, info, tgt.to(dev))['loss']))
+        torch.cuda.synchronize()
+        res[name] = {'losses': losses,
+                     'sums': {k: [float(f.data.double().sum()), float(f.data.double().abs().sum())] for k, f in tr.flat.items()}}
+        if coll:     # the reference driver's call shape on an un-flattened module: flattened on first use, then ONE all-reduce
+            lin = torch.nn.Linear(8, 4).to(dev)
+            lin(torch.ones(2, 8, device=dev)).sum().backward()
+            g0 = lin.weight.grad.clone()
+            wk = average_gradients(lin, async_op=True)
+            wk.wait()
+            assert torch.equal(lin.weight.grad, g0) and getattr(lin, "_scda_flat", None) is not None
+    torch.save(res, os.path.join(out_dir, "rccl.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_one_rank_group_matches_plain_step(cuda, tmp_path):
+    """The RCCL code path -- dist_init(..., 'nccl'), broadcast_params on the flat buckets, the four asynchronous
+    dist.all_reduce(flat.grad, async_op=True) launches of a step, their waits and the hand-over between RCCL's stream and the
+    compute / side streams -- executed on real RCCL with a one-rank group (the test box has one GPU; RCCL wants one device per
+    rank).  A sum over one rank is the identity, so three steps must leave every parameter bucket BIT-identical to the same
+    three steps without collectives; a missing wait or a wrong stream dependency shows up as a difference or a hang."""
+    mp.spawn(_rccl_worker, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    res = torch.load(str(tmp_path / "rccl.pt"))
+    assert res['rccl']['losses'] == res['plain']['losses'], res
+    assert res['rccl']['sums'] == res['plain']['sums'], res
+    assert all(np.isfinite(v) for v in res['rccl']['losses'])
