@@ -101,6 +101,14 @@ int scda_roi_align_fwd_hip(const float *features, const float *rois, int R, int 
                            float spatial_scale, float *out, void *stream);
 int scda_roi_align_bwd_hip(const float *top_grad, const float *rois, int R, int B, int C, int H, int W, int AH,
                            int AW, float spatial_scale, float *bottom_grad, void *stream);
+/* the same operator with the pooled maps stored CHANNEL-MAJOR: out / top_grad are [C,R,AH,AW].  No reference counterpart: it is
+ * the layout the ResNet-C4 RoI head (models/mask_rcnn/resnet.py:140-146, layer4 on R x 7 x 7 maps) runs in here -- viewed as
+ * [1, C, R*AH', AW'] every 1x1 convolution and every batch-norm of the head sees one long contiguous row per channel instead of
+ * R pieces of 49 floats (see scda_conv2d_next_row_period for the 3x3 convolutions). */
+int scda_roi_align_cmajor_fwd_hip(const float *features, const float *rois, int R, int B, int C, int H, int W, int AH, int AW,
+                                  float spatial_scale, float *out, void *stream);
+int scda_roi_align_cmajor_bwd_hip(const float *top_grad, const float *rois, int R, int B, int C, int H, int W, int AH,
+                                  int AW, float spatial_scale, float *bottom_grad, void *stream);
 
 /* --------------------------------------------------------- focal loss ---- */
 /* replaces the four functions of extensions/_focal_loss/src/focal_loss_cuda.h:2-43
@@ -203,6 +211,11 @@ int scda_conv2d_wgrad_hip(const float *dy, const float *x, float *dw, int batch,
  * of dy).  Only when scda_conv2d_wgrad_bias_fusable(...) != 0 (OH*OW % 16 == 0, 16-byte aligned dy); otherwise call
  * scda_conv2d_wgrad_hip + scda_bias_grad_nchw_hip. */
 int scda_conv2d_wgrad_bias_fusable(int batch, int Cout, int OH, int OW, const float *dy);
+/* One-shot modifier of the calling thread's NEXT scda_conv2d_{fwd,dgrad,dgrad_act,wgrad,wgrad_bias}_hip call: the image
+ * [batch, C, IH, IW] is a vertical STACK of independent maps of `period` rows each (IH % period == 0; stride 1, 2*P == K-1) and
+ * filter taps must not reach from one map into the next -- what a batch of R maps [R, C, period, IW] computes, on the
+ * channel-major layout [1, C, R*period, IW].  0 clears it.  A call it cannot honour fails with SCDA_EINVAL. */
+void scda_conv2d_next_row_period(int period);
 int scda_conv2d_wgrad_bias_hip(const float *dy, const float *x, float *dw, float *db, int batch, int Cin, int IH, int IW,
                                int Cout, int KH, int KW, int S, int P, int accumulate, int db_accumulate, void *ws,
                                size_t ws_bytes, void *stream);

@@ -45,7 +45,7 @@ class Conv2dFn(Function):
     """conv (+bias) (+ReLU/LeakyReLU) in one MFMA kernel; backward = act' -> dgrad, wgrad, bias-grad."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, pad, act, slope, fuse=(None, False)):
+    def forward(ctx, x, w, b, stride, pad, act, slope, fuse=(None, False), row_period=0):
         """fuse = (input_act, defer): static fusion plan of the owning model (scda_amd.layers.plan_act_fusion).
         input_act = (mode, slope) of the activation that produced x: THIS conv's data gradient applies that activation's
         gradient in its epilogue.  defer = True: the consumer of y does the same for this conv's own activation, so the
@@ -53,9 +53,11 @@ class Conv2dFn(Function):
         x = _c(x)
         if not w.is_contiguous():
             w = w.contiguous()
-        y = N.conv2d_fwd(x, w, b, stride, pad, act, slope)
+        # row_period: x is a vertical stack of independent maps of that many rows (channel-major RoI head, scda_ops.h)
+        y = N.conv2d_fwd(x, w, b, stride, pad, act, slope, row_period=row_period)
         in_act, defer = fuse if replay is None else (None, False)   # parity tests replay act masks: plain un-fused backward
         ctx.cfg = (stride, pad, act, slope, in_act, defer)
+        ctx.row_period = row_period
         ctx.has_bias = b is not None
         ctx.bias_ref, ctx.w_ref = b, w   # the Parameter objects themselves (they carry the flat-bucket gradient views)
         ctx.save_for_backward(x, w, _mask_src(ctx, y) if act != ACT_NONE and not defer else None)
@@ -65,24 +67,26 @@ class Conv2dFn(Function):
     def backward(ctx, dy):
         x, w, y = ctx.saved_tensors
         stride, pad, act, slope, in_act, defer = ctx.cfg
+        rp = ctx.row_period
         dy = _c(dy)
         if act != ACT_NONE and not defer:
             dy = N.act_bwd(dy, y, 0 if act == ACT_RELU else 1, slope)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             if in_act is not None:
-                dx = N.conv2d_dgrad(dy, w, x.shape, stride, pad, act_src=x, act_slope=0.0 if in_act[0] == ACT_RELU else in_act[1])
+                dx = N.conv2d_dgrad(dy, w, x.shape, stride, pad, act_src=x, act_slope=0.0 if in_act[0] == ACT_RELU else in_act[1],
+                                    row_period=rp)
             else:
-                dx = N.conv2d_dgrad(dy, w, x.shape, stride, pad)
+                dx = N.conv2d_dgrad(dy, w, x.shape, stride, pad, row_period=rp)
         want_w, want_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         if want_w and want_b:   # one pass: the bias gradient is fused into the weight-gradient kernel where the shape allows
             sw, sb = _sink(ctx.w_ref), _sink(ctx.bias_ref)
-            dw, db = N.conv2d_wgrad_bias(dy, x, w.shape, stride, pad, out=sw, db_out=sb)
+            dw, db = N.conv2d_wgrad_bias(dy, x, w.shape, stride, pad, out=sw, db_out=sb, row_period=rp)
             dw = None if sw is not None else dw
             db = None if sb is not None else db
         elif want_w:
             sink = _sink(ctx.w_ref)
-            dw = N.conv2d_wgrad(dy, x, w.shape, stride, pad, out=sink)
+            dw = N.conv2d_wgrad(dy, x, w.shape, stride, pad, out=sink, row_period=rp)
             if sink is not None:
                 dw = None
         elif want_b:
@@ -90,7 +94,7 @@ class Conv2dFn(Function):
             db = N.bias_grad_nchw(dy, out=sink)
             if sink is not None:
                 db = None
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
 class LinearFn(Function):
@@ -289,18 +293,19 @@ class RoIAlignFn(Function):
     """extensions/_roi_align/functions/roi_align.py:7-51"""
 
     @staticmethod
-    def forward(ctx, features, rois, ah, aw, scale):
+    def forward(ctx, features, rois, ah, aw, scale, channel_major=False):
+        """channel_major: the pooled maps come out as [C,R,ah,aw] (RoI-head layout of the ResNet-C4 detector)"""
         if not features.is_contiguous() or not rois.is_contiguous():
             raise AssertionError("RoIAlign needs contiguous features and rois")
         ctx.save_for_backward(rois)
-        ctx.cfg = (tuple(features.shape), ah, aw, scale)
-        return N.roi_align_fwd(features, rois, ah, aw, scale)
+        ctx.cfg = (tuple(features.shape), ah, aw, scale, channel_major)
+        return N.roi_align_fwd(features, rois, ah, aw, scale, channel_major)
 
     @staticmethod
     def backward(ctx, dy):
         (rois,) = ctx.saved_tensors
-        shape, ah, aw, scale = ctx.cfg
-        return N.roi_align_bwd(_c(dy), rois, shape, ah, aw, scale), None, None, None, None
+        shape, ah, aw, scale, channel_major = ctx.cfg
+        return N.roi_align_bwd(_c(dy), rois, shape, ah, aw, scale, channel_major), None, None, None, None, None
 
 
 class Avg2x2S1Fn(Function):
@@ -441,8 +446,8 @@ class GlobalAvgPoolFn(Function):
 
 
 # functional front-ends -------------------------------------------------------
-def conv2d(x, w, b=None, stride=1, padding=0, act=ACT_NONE, slope=0.01, fuse=(None, False)):
-    return Conv2dFn.apply(x, w, b, stride, padding, act, slope, fuse)
+def conv2d(x, w, b=None, stride=1, padding=0, act=ACT_NONE, slope=0.01, fuse=(None, False), row_period=0):
+    return Conv2dFn.apply(x, w, b, stride, padding, act, slope, fuse, row_period)
 
 
 def linear(x, w, b=None, act=ACT_NONE, defer_act_bwd=False):

@@ -67,6 +67,9 @@ struct ConvGeom {
     int slab_aligned; // CB % BK == 0: a K-slab is one filter tap, K is channel-block major, weights are packed [K][mpad]
                       // and the direct-to-LDS kernel runs; otherwise tap-major [M][K] weights and the gather kernel
     int mpad;         // M rounded up to the M-tile (leading dimension of the [K][mpad] packed weights)
+    int row_period;   // > 0 (stride 1 only): the image is a STACK of independent maps of row_period rows each (the channel-major
+                      // RoI-head layout [1, C, R*7, 7]): a tap is valid when it stays inside its own map -- vertical validity is
+                      // tested on py % row_period against row_period instead of py against the image height.  0: plain image.
     const float *zp;  // zero page: source of every out-of-range gather lane
     Div dPHW, dPW, dCB;
 };
@@ -96,6 +99,11 @@ template <int S, bool DGRAD>
 __device__ __forceinline__ int conv_tap_offset(const ConvGeom &g, const bool n_ok, const int py, const int px, const int kh,
                                                const int kw) {
     if (!n_ok) return -1;
+    if (S == 1 && g.row_period) {   // stacked maps (see ConvGeom::row_period): same-size convolution, both directions alike
+        const int dy = DGRAD ? g.pad - kh : kh - g.pad, dx = DGRAD ? g.pad - kw : kw - g.pad;
+        const int my = py % g.row_period + dy, ix = px + dx;
+        return ((unsigned)my < (unsigned)g.row_period && (unsigned)ix < (unsigned)g.WB) ? (py + dy) * g.WB + ix : -1;
+    }
     if (!DGRAD) {
         const int iy = py * S + kh - g.pad, ix = px * S + kw - g.pad;
         return ((unsigned)iy < (unsigned)g.HB && (unsigned)ix < (unsigned)g.WB) ? iy * g.WB + ix : -1;
@@ -486,6 +494,7 @@ struct WgradGeom {
     int k_per_split;
     int nx, ny, swz;  // see tile_coords
     int a_vec4;   // OH*OW % 4 == 0 and dY 16-byte aligned: float4 loads of dY
+    int row_period;   // see ConvGeom::row_period (stride 1, same-size convolution)
     const float *zp;
     Div dOHW, dOW;
 };
@@ -566,8 +575,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
             for (int kh = 0; kh < KH; ++kh)
 #pragma unroll
                 for (int kw = 0; kw < KW; ++kw) {
-                    const int iy = oy * S + kh - g.pad, ix = ox * S + kw - g.pad;
-                    if ((unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW) mask |= 1u << (kh * KW + kw);
+                    const int iy = (g.row_period ? oy % g.row_period : oy * S) + kh - g.pad, ix = ox * S + kw - g.pad;
+                    if ((unsigned)iy < (unsigned)(g.row_period ? g.row_period : g.IH) && (unsigned)ix < (unsigned)g.IW) mask |= 1u << (kh * KW + kw);
                 }
         }
         const float *xb = X + (size_t)img * g.Cin * ihw + (oy * S) * g.IW + ox * S;
@@ -684,12 +693,14 @@ __global__ __launch_bounds__((WgradGldsCfg<BM, BN>::THREADS)) void conv_wgrad_gl
         }
         unsigned b_off[C::CLS_PP][C::G_PC], b_sh[C::CLS_PP][C::G_PC];
         int oy[C::CLS_PP], ox[C::CLS_PP], klp[C::CLS_PP];
+        int oyv[C::CLS_PP];   // the row the tap-validity test sees: oy, or oy % row_period for stacked maps (ConvGeom::row_period)
+        const int vrows = g.row_period ? g.row_period : g.IH;
         // Stride 1 and OW % 16 == 0 (every VGG / decoder layer of the workload): the 16 pixels of a slab lie in ONE output row.
         // Row validity of the taps and the slab's pixel offset are then scalar (SALU work of the staging wave), a lane's
         // offset is a per-load CONSTANT plus the validity bit, and the per-slab VALU work drops from ~57 to ~28 instructions
         // per class -- this wave's instruction stream is what bounds the kernel (with the address work ablated away it runs at
         // 134 instead of 119 TFLOP/s on conv3_2).
-        const bool row_slab = S == 1 && (g.dOW.d % BK) == 0;
+        const bool row_slab = S == 1 && (g.dOW.d % BK) == 0 && !g.row_period;
         const int bias = (g.pad * g.IW + g.pad) * 4;   // bytes the descriptor base is moved back by
         // slab cursor: image and first pixel (scalar), the lane's output pixel per class; advanced by 16 pixels per issue
         int img0, pix0, step_y, step_x;
@@ -700,6 +711,7 @@ __global__ __launch_bounds__((WgradGldsCfg<BM, BN>::THREADS)) void conv_wgrad_gl
             const int cls = p * C::CLS_PP + c;
             const int kl = 4 * (((lane & 15) >> 2) ^ cls) + (lane & 3);   // the lane's pixel inside a slab (after the swizzle)
             g.dOW.divmod(pix0 + kl, oy[c], ox[c]);
+            oyv[c] = g.row_period ? oy[c] % g.row_period : oy[c];
 #pragma unroll
             for (int j = 0; j < C::G_PC; ++j) {
                 const int n = n0 + 16 * j + 4 * cls + (lane >> 4);
@@ -756,7 +768,7 @@ __global__ __launch_bounds__((WgradGldsCfg<BM, BN>::THREADS)) void conv_wgrad_gl
                 // validity of the KH x KW taps of the lane's pixel (row bits x column bits), inverted: bit t set = tap t off the image
                 unsigned rowb = 0, colb = 0;
 #pragma unroll
-                for (int kh = 0; kh < KH; ++kh) rowb |= (unsigned)((unsigned)(oy[c] * S + kh - g.pad) < (unsigned)g.IH) << kh;
+                for (int kh = 0; kh < KH; ++kh) rowb |= (unsigned)((unsigned)(oyv[c] * S + kh - g.pad) < (unsigned)vrows) << kh;
 #pragma unroll
                 for (int kw = 0; kw < KW; ++kw) colb |= (unsigned)((unsigned)(ox[c] * S + kw - g.pad) < (unsigned)g.IW) << kw;
                 unsigned mask = 0;
@@ -768,9 +780,10 @@ __global__ __launch_bounds__((WgradGldsCfg<BM, BN>::THREADS)) void conv_wgrad_gl
                 for (int j = 0; j < C::G_PC; ++j)
                     buffer_load_lds_b32(x_img, (x_pix + b_off[c][j]) | ((off_taps << b_sh[c][j]) & OOB), Bb + (16 * j + 4 * cls) * 16);
                 // next slab
-                ox[c] += step_x; oy[c] += step_y;
-                if (ox[c] >= g.dOW.d) { ox[c] -= g.dOW.d; ++oy[c]; }
-                if (wrap) oy[c] -= g.OH;
+                ox[c] += step_x; oy[c] += step_y; oyv[c] += step_y;
+                if (ox[c] >= g.dOW.d) { ox[c] -= g.dOW.d; ++oy[c]; ++oyv[c]; }
+                if (wrap) { oy[c] -= g.OH; if (!g.row_period) oyv[c] -= g.OH; }
+                if (g.row_period) while (oyv[c] >= g.row_period) oyv[c] -= g.row_period;   // OH is a multiple of the period
             }
             pix0 += BK;
             if (wrap) { pix0 = 0; a_img += a_img_stride; x_img += x_img_stride; }
@@ -1558,6 +1571,23 @@ using namespace scda;
 
 static int conv_out_dim(int in, int k, int s, int p) { return (in + 2 * p - k) / s + 1; }
 
+// scda_conv2d_next_row_period: one-shot, per-thread modifier of the NEXT conv entry point called on this thread (forward, data
+// gradient or weight gradient): the image is a stack of independent maps of `period` rows (ConvGeom::row_period).
+static thread_local int g_next_row_period = 0;
+SCDA_API void scda_conv2d_next_row_period(int period) { g_next_row_period = period > 0 ? period : 0; }
+
+// consumes the modifier; -1 = set but illegal for this convolution
+static int take_row_period(const char *who, int IH, int KH, int KW, int S, int P) {
+    const int period = g_next_row_period;
+    g_next_row_period = 0;
+    if (!period) return 0;
+    if (S != 1 || KH != KW || 2 * P != KH - 1 || (IH % period) != 0) {
+        set_error("%s: row period %d needs a stride-1 same-size convolution on an image whose height (%d) is a multiple of it", who, period, IH);
+        return -1;
+    }
+    return KH == 1 ? 0 : period;   // a 1x1 convolution has no neighbours to protect
+}
+
 SCDA_API size_t scda_conv2d_workspace_bytes(int batch, int Cin, int IH, int IW, int Cout, int KH, int KW, int S, int P) {
     // enough for: fwd/dgrad split-K slabs and wgrad slabs (<= 64 splits of the weight matrix,
     // bounded by 8 output-sized slabs)
@@ -1586,6 +1616,7 @@ SCDA_API int scda_conv2d_fwd_hip(const float *x, const float *w, const float *bi
     g.dPHW = Div(OH * OW); g.dPW = Div(OW); g.dCB = Div(Cin);
     g.slab_aligned = (Cin % BK) == 0;
     g.zp = zero_page();
+    if ((g.row_period = take_row_period("scda_conv2d_fwd_hip", IH, KH, KW, S, P)) < 0) return SCDA_EINVAL;
     Epi e{y, nullptr, bias, 0, act, slope, 1, 0, nullptr, 0.f};
     if (KH == 7 && KW == 7 && S == 2)   // the ResNet stem (3 -> 64, frozen in the reference: models/mask_rcnn/resnet.py:230-238): forward only
         return launch_conv<7, 7, 2, false>(w, x, g, e, (float *)ws, ws_bytes, as_stream(stream));
@@ -1611,6 +1642,7 @@ SCDA_API int scda_conv2d_dgrad_act_hip(const float *dy, const float *wt, float *
     g.dPHW = Div(IH * IW); g.dPW = Div(IW); g.dCB = Div(Cout);
     g.slab_aligned = (Cout % BK) == 0;
     g.zp = zero_page();
+    if ((g.row_period = take_row_period("scda_conv2d_dgrad_hip", IH, KH, KW, S, P)) < 0) return SCDA_EINVAL;
     if (!g.zp) { set_error("scda_conv2d_dgrad_hip: could not allocate the zero page"); return SCDA_ELAUNCH; }
     Epi e{dx, nullptr, nullptr, 0, (int)ACT_NONE, 0.f, 1, 0, act_src, act_slope};
     CONV_DISPATCH(launch_conv, , true > (wt, dy, g, e, (float *)ws, ws_bytes, as_stream(stream)))
@@ -1666,6 +1698,7 @@ SCDA_API int scda_conv2d_wgrad_hip(const float *dy, const float *x, float *dw, i
     g.dOHW = Div(OH * OW); g.dOW = Div(OW);
     g.a_vec4 = ((OH * OW) % 4) == 0 && (((uintptr_t)dy) & 15) == 0;
     g.zp = zero_page();
+    if ((g.row_period = take_row_period("scda_conv2d_wgrad_hip", IH, KH, KW, S, P)) < 0) return SCDA_EINVAL;
     if (!g.zp) { set_error("scda_conv2d_wgrad_hip: could not allocate the zero page"); return SCDA_ELAUNCH; }
     CONV_DISPATCH(launch_wgrad, > (dy, x, g, dw, accumulate, (float *)ws, ws_bytes, as_stream(stream)))
 }
@@ -1686,6 +1719,7 @@ SCDA_API int scda_conv2d_wgrad_bias_hip(const float *dy, const float *x, float *
     g.dOHW = Div(OH * OW); g.dOW = Div(OW);
     g.a_vec4 = ((OH * OW) % 4) == 0 && (((uintptr_t)dy) & 15) == 0;
     g.zp = zero_page();
+    if ((g.row_period = take_row_period("scda_conv2d_wgrad_bias_hip", IH, KH, KW, S, P)) < 0) return SCDA_EINVAL;
     if (!g.zp) { set_error("scda_conv2d_wgrad_bias_hip: could not allocate the zero page"); return SCDA_ELAUNCH; }
     CONV_DISPATCH(launch_wgrad, > (dy, x, g, dw, accumulate, (float *)ws, ws_bytes, as_stream(stream), db, db_accumulate))
 }

@@ -472,13 +472,14 @@ __device__ __forceinline__ RaPoint ra_point(const float *roi, float scale, int C
 __global__ __launch_bounds__(256) void roi_align_fwd_kernel(const long long total, const float *__restrict__ feat,
                                                             const float scale, const int C, const int H, const int W,
                                                             const int AH, const int AW, const float *__restrict__ rois,
-                                                            float *__restrict__ out) {
+                                                            float *__restrict__ out, const int R, const int cmajor) {
+    // cmajor: the output is [C][R][AH][AW] (channel-major RoI-head layout) instead of [R][C][AH][AW]; index runs over the output
     for (long long index = blockIdx.x * (long long)blockDim.x + threadIdx.x; index < total;
          index += (long long)blockDim.x * gridDim.x) {
         const int pw = (int)(index % AW);
         const int ph = (int)((index / AW) % AH);
-        const int c = (int)((index / AW / AH) % C);
-        const int n = (int)(index / AW / AH / C);
+        const int c = cmajor ? (int)(index / AW / AH / R) : (int)((index / AW / AH) % C);
+        const int n = cmajor ? (int)((index / AW / AH) % R) : (int)(index / AW / AH / C);
         const RaPoint p = ra_point(rois + (size_t)n * 5, scale, C, H, W, AH, AW, c, ph, pw);
         if (!p.ok) { out[index] = 0.f; continue; }
         const double hr = p.hr, wr = p.wr;
@@ -491,13 +492,13 @@ __global__ __launch_bounds__(256) void roi_align_fwd_kernel(const long long tota
 __global__ __launch_bounds__(256) void roi_align_bwd_kernel(const long long total, const float *__restrict__ top,
                                                             const float scale, const int C, const int H, const int W,
                                                             const int AH, const int AW, float *__restrict__ bottom,
-                                                            const float *__restrict__ rois) {
+                                                            const float *__restrict__ rois, const int R, const int cmajor) {
     for (long long index = blockIdx.x * (long long)blockDim.x + threadIdx.x; index < total;
          index += (long long)blockDim.x * gridDim.x) {
         const int pw = (int)(index % AW);
         const int ph = (int)((index / AW) % AH);
-        const int c = (int)((index / AW / AH) % C);
-        const int n = (int)(index / AW / AH / C);
+        const int c = cmajor ? (int)(index / AW / AH / R) : (int)((index / AW / AH) % C);
+        const int n = cmajor ? (int)((index / AW / AH) % R) : (int)(index / AW / AH / C);
         const RaPoint p = ra_point(rois + (size_t)n * 5, scale, C, H, W, AH, AW, c, ph, pw);
         if (!p.ok) continue;
         const double hr = p.hr, wr = p.wr, d = top[index];
@@ -516,7 +517,7 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(const long long tota
 __global__ __launch_bounds__(256) void roi_align_bwd_plane_kernel(const float *__restrict__ top, const int R, const float scale,
                                                                   const int C, const int H, const int W, const int AH,
                                                                   const int AW, float *__restrict__ bottom,
-                                                                  const float *__restrict__ rois) {
+                                                                  const float *__restrict__ rois, const int cmajor) {
     extern __shared__ float plane[];
     const int c = blockIdx.x % C, b = blockIdx.x / C;
     const int hw = H * W, bins = AH * AW;
@@ -532,7 +533,7 @@ __global__ __launch_bounds__(256) void roi_align_bwd_plane_kernel(const float *_
             if ((int)roi[0] != b) continue;
             const RaPoint p = ra_point(roi, scale, C, H, W, AH, AW, c, ph, pw);
             if (!p.ok) continue;
-            const double hr = p.hr, wr = p.wr, d = top[((size_t)n * C + c) * bins + bin];
+            const double hr = p.hr, wr = p.wr, d = top[(cmajor ? (size_t)c * R + n : (size_t)n * C + c) * bins + bin];
             const int o = p.upleft - plane_base;
             atomicAdd(plane + o, (float)(d * (1. - hr) * (1 - wr)));
             atomicAdd(plane + o + 1, (float)(d * (1. - hr) * wr));
@@ -828,19 +829,29 @@ SCDA_API int scda_roi_pool_bwd_hip(const float *top_grad, const int32_t *argmax,
     return launch_status("roi_pool_bwd_kernel");
 }
 
-SCDA_API int scda_roi_align_fwd_hip(const float *features, const float *rois, int R, int B, int C, int H, int W, int AH,
-                                    int AW, float spatial_scale, float *out, void *stream) {
+static int roi_align_fwd_impl(const float *features, const float *rois, int R, int B, int C, int H, int W, int AH,
+                              int AW, float spatial_scale, float *out, void *stream, int cmajor) {
     if (R < 0 || B <= 0 || C <= 0 || H <= 1 || W <= 1 || AH <= 1 || AW <= 1) { set_error("scda_roi_align_fwd_hip: bad shape"); return SCDA_EINVAL; }
     if (R == 0) return SCDA_OK;
     if (!features || !rois || !out) { set_error("scda_roi_align_fwd_hip: null pointer"); return SCDA_EINVAL; }
     const long long total = (long long)R * C * AH * AW;
     hipLaunchKernelGGL(roi_align_fwd_kernel, dim3(ew_grid(total) * 8), dim3(256), 0, as_stream(stream), total, features,
-                       spatial_scale, C, H, W, AH, AW, rois, out);
+                       spatial_scale, C, H, W, AH, AW, rois, out, R, cmajor);
     return launch_status("roi_align_fwd_kernel");
 }
 
-SCDA_API int scda_roi_align_bwd_hip(const float *top_grad, const float *rois, int R, int B, int C, int H, int W, int AH,
-                                    int AW, float spatial_scale, float *bottom_grad, void *stream) {
+SCDA_API int scda_roi_align_fwd_hip(const float *features, const float *rois, int R, int B, int C, int H, int W, int AH,
+                                    int AW, float spatial_scale, float *out, void *stream) {
+    return roi_align_fwd_impl(features, rois, R, B, C, H, W, AH, AW, spatial_scale, out, stream, 0);
+}
+
+SCDA_API int scda_roi_align_cmajor_fwd_hip(const float *features, const float *rois, int R, int B, int C, int H, int W, int AH,
+                                           int AW, float spatial_scale, float *out, void *stream) {
+    return roi_align_fwd_impl(features, rois, R, B, C, H, W, AH, AW, spatial_scale, out, stream, 1);
+}
+
+static int roi_align_bwd_impl(const float *top_grad, const float *rois, int R, int B, int C, int H, int W, int AH,
+                              int AW, float spatial_scale, float *bottom_grad, void *stream, int cmajor) {
     if (R < 0 || B <= 0 || C <= 0 || H <= 1 || W <= 1 || AH <= 1 || AW <= 1) { set_error("scda_roi_align_bwd_hip: bad shape"); return SCDA_EINVAL; }
     if (R == 0) return SCDA_OK;
     if (!top_grad || !rois || !bottom_grad) { set_error("scda_roi_align_bwd_hip: null pointer"); return SCDA_EINVAL; }
@@ -850,12 +861,22 @@ SCDA_API int scda_roi_align_bwd_hip(const float *top_grad, const float *rois, in
     // reference too, roi_align_kernel.cu:33); planes that do not fit 64 KB of LDS keep the global-atomic form
     if (lds <= 64 * 1024 && AH * AW <= 256 && !getenv("SCDA_ROI_ALIGN_ATOMIC")) {
         hipLaunchKernelGGL(roi_align_bwd_plane_kernel, dim3((unsigned)((long long)B * C)), dim3(256), lds, as_stream(stream), top_grad, R,
-                           spatial_scale, C, H, W, AH, AW, bottom_grad, rois);
+                           spatial_scale, C, H, W, AH, AW, bottom_grad, rois, cmajor);
         return launch_status("roi_align_bwd_plane_kernel");
     }
     hipLaunchKernelGGL(roi_align_bwd_kernel, dim3(ew_grid(total) * 8), dim3(256), 0, as_stream(stream), total, top_grad,
-                       spatial_scale, C, H, W, AH, AW, bottom_grad, rois);
+                       spatial_scale, C, H, W, AH, AW, bottom_grad, rois, R, cmajor);
     return launch_status("roi_align_bwd_kernel");
+}
+
+SCDA_API int scda_roi_align_bwd_hip(const float *top_grad, const float *rois, int R, int B, int C, int H, int W, int AH,
+                                    int AW, float spatial_scale, float *bottom_grad, void *stream) {
+    return roi_align_bwd_impl(top_grad, rois, R, B, C, H, W, AH, AW, spatial_scale, bottom_grad, stream, 0);
+}
+
+SCDA_API int scda_roi_align_cmajor_bwd_hip(const float *top_grad, const float *rois, int R, int B, int C, int H, int W, int AH,
+                                           int AW, float spatial_scale, float *bottom_grad, void *stream) {
+    return roi_align_bwd_impl(top_grad, rois, R, B, C, H, W, AH, AW, spatial_scale, bottom_grad, stream, 1);
 }
 
 #define FOCAL_CHECK(name)                                                             \

@@ -32,12 +32,16 @@ class RoIAlign(Module):
 
 class RoIAlignAvg(RoIAlign):
     extra = 1
+    channel_major = False   # True: [C, R, h, w] instead of [R, C, h, w] (set by a detector whose RoI head runs channel-major)
 
     def forward(self, features, rois):
-        from scda_amd.autograd_ops import Avg2x2S1Fn
+        from scda_amd.autograd_ops import Avg2x2S1Fn, RoIAlignFn
         assert rois.shape[1] == 5
-        x = RoIAlignFunction(self.aligned_height + 1, self.aligned_width + 1, self.spatial_scale)(features, rois)
-        return Avg2x2S1Fn.apply(x)      # avg_pool2d(kernel_size=2, stride=1) as one kernel (forward and backward)
+        if self.channel_major:
+            x = RoIAlignFn.apply(features, rois, self.aligned_height + 1, self.aligned_width + 1, self.spatial_scale, True)
+        else:
+            x = RoIAlignFunction(self.aligned_height + 1, self.aligned_width + 1, self.spatial_scale)(features, rois)
+        return Avg2x2S1Fn.apply(x)      # avg_pool2d(kernel_size=2, stride=1) as one kernel (forward and backward); per plane
 
 
 class RoIAlignMax(RoIAlign):

@@ -9,6 +9,7 @@ RoI features, 7x7 average pool, `fc_rcnn_cls / fc_rcnn_loc` on 2048 features; st
 (:213-238).  To serve the SCDA step it derives from FasterRCNN_AdEx and `rcnn()` also returns the pooled 2048-d RoI feature
 (the cluster-region generator's input, like VGG's FC7 output).  PERFORMANCE configuration: parity is unpinned by construction."""
 import math
+import os
 
 import torch.nn as nn
 
@@ -81,6 +82,8 @@ class ResNet(FasterRCNN_AdEx):
                     m.weight.data.normal_(0, std)
         self.fix_layer_num = 1
         self._fix_layer(self.fix_layer_num)
+        self.tall_head = True
+        self._head_convs3x3 = [m for m in self.layer4.modules() if isinstance(m, L.Conv2d) and m.kernel_size == (3, 3)]
 
     def _make_layer(self, block, planes, blocks, stride=1):
         downsample = None
@@ -116,9 +119,29 @@ class ResNet(FasterRCNN_AdEx):
         return self.rpn_head(x)
 
     def rcnn(self, x, rois):
+        """RoI head.  MI355X layout: the pooled maps are produced CHANNEL-MAJOR, [C, R, 7, 7], and layer4 runs on the view
+        [1, C, R*7, 7] -- per channel one contiguous row of R*49 pixels.  In the reference's [R, C, 7, 7] every channel is R
+        pieces of 49 floats (196 bytes, never 16-byte aligned): the 1x1 convolutions and batch-norms gather those pieces, and the
+        weight gradient cannot use the direct-to-LDS kernel at all (K-slabs of 16 pixels straddle maps).  On the tall view the
+        1x1 convolutions / batch-norms / residual adds are layout-blind, the three 3x3 convolutions are told that the image is a
+        stack of 7-row maps (`row_period`, include/scda_ops.h) so that no tap crosses from one RoI into the next, and the 7x7
+        average pool sees R*C planes.  Same arithmetic, same results (tests/test_resnet_gpu.py compares the two paths);
+        SCDA_RESNET_HEAD_NCHW=1 keeps the reference layout."""
         assert rois.shape[1] == 5
-        x = self.layer4(self.roipooling(x, rois))
-        x_fea = self.avgpool(x).view(x.size(0), -1)           # [R, 2048]
+        R = rois.shape[0]
+        tall = (self.tall_head and isinstance(self.roipooling, RoIAlignAvg) and R > 0 and (R * 49) % 16 == 0
+                and not os.environ.get("SCDA_RESNET_HEAD_NCHW"))
+        self.roipooling.channel_major = tall
+        for m in self._head_convs3x3:
+            m.row_period = 7 if tall else 0
+        x = self.roipooling(x, rois)
+        if not tall:
+            x = self.layer4(x)
+            x_fea = self.avgpool(x).view(x.size(0), -1)       # [R, 2048]
+        else:
+            C = x.shape[0]
+            x = self.layer4(x.view(1, C, R * 7, 7))           # [1, 2048, R*7, 7]
+            x_fea = self.avgpool(x.view(x.shape[1], R, 7, 7)).t().contiguous()   # [2048, R] -> [R, 2048]
         return x_fea, self.fc_rcnn_cls(x_fea), self.fc_rcnn_loc(x_fea)
 
 

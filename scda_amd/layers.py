@@ -27,10 +27,13 @@ class Conv2d(nn.Conv2d):
         # static fusion plan (plan_act_fusion): act of the layer that feeds this conv / whether our consumer applies our act'
         self.input_act = None
         self.defer_act_bwd = False
+        # > 0: the input is a vertical stack of independent maps of that many rows (the channel-major RoI-head layout
+        # [1, C, R*7, 7] of the ResNet-C4 detector); set per call by the owner (dropin/models/mask_rcnn/resnet.py)
+        self.row_period = 0
 
     def forward(self, x):
         return A.conv2d(x, self.weight, self.bias, self.stride[0], self.padding[0], self.fused_act, self.slope,
-                        (self.input_act, self.defer_act_bwd))
+                        (self.input_act, self.defer_act_bwd), self.row_period)
 
     def extra_repr(self):
         s = super().extra_repr()

@@ -120,24 +120,27 @@ def roi_pool_bwd(top_grad, argmax, rois, feat_shape, ph, pw, scale):
 
 
 # ------------------------------------------------------------ RoIAlign ------
-def roi_align_fwd(features, rois, ah, aw, scale):
+def roi_align_fwd(features, rois, ah, aw, scale, channel_major=False):
+    """-> [R,C,ah,aw], or [C,R,ah,aw] with channel_major (the RoI-head layout of scda_amd/dropin/models/mask_rcnn/resnet.py)"""
     _req(features, "features"); _req(rois, "rois")
     if rois.dim() != 2 or rois.shape[1] != 5:
         raise ValueError("rois must be [R,5]")
     B, C, H, W = features.shape
     R = rois.shape[0]
-    out = torch.empty(R, C, ah, aw, dtype=torch.float32, device=features.device)
-    _check(lib().scda_roi_align_fwd_hip(_p(features), _p(rois), i32(R), i32(B), i32(C), i32(H), i32(W), i32(ah), i32(aw),
-                                        f32(scale), _p(out), _stream()), "scda_roi_align_fwd_hip")
+    out = torch.empty((C, R, ah, aw) if channel_major else (R, C, ah, aw), dtype=torch.float32, device=features.device)
+    fn = lib().scda_roi_align_cmajor_fwd_hip if channel_major else lib().scda_roi_align_fwd_hip
+    _check(fn(_p(features), _p(rois), i32(R), i32(B), i32(C), i32(H), i32(W), i32(ah), i32(aw), f32(scale), _p(out), _stream()),
+           "scda_roi_align_fwd_hip")
     return out
 
 
-def roi_align_bwd(top_grad, rois, feat_shape, ah, aw, scale):
+def roi_align_bwd(top_grad, rois, feat_shape, ah, aw, scale, channel_major=False):
     _req(top_grad, "top_grad"); _req(rois, "rois")
     B, C, H, W = feat_shape
     gi = torch.zeros(B, C, H, W, dtype=torch.float32, device=top_grad.device)
-    _check(lib().scda_roi_align_bwd_hip(_p(top_grad), _p(rois), i32(rois.shape[0]), i32(B), i32(C), i32(H), i32(W),
-                                        i32(ah), i32(aw), f32(scale), _p(gi), _stream()), "scda_roi_align_bwd_hip")
+    fn = lib().scda_roi_align_cmajor_bwd_hip if channel_major else lib().scda_roi_align_bwd_hip
+    _check(fn(_p(top_grad), _p(rois), i32(rois.shape[0]), i32(B), i32(C), i32(H), i32(W), i32(ah), i32(aw), f32(scale), _p(gi),
+              _stream()), "scda_roi_align_bwd_hip")
     return gi
 
 
@@ -343,7 +346,13 @@ def conv2d_pack_all(flat):
         _PACK_CACHE[(w.data_ptr(), d)] = ((w._version, flat.epoch, tuple(w.shape)), out[off:off + n], weakref.ref(w))
 
 
-def conv2d_fwd(x, w, bias, stride, pad, act=ACT_NONE, slope=0.01):
+def _row_period(period):
+    """one-shot modifier of the next conv entry point called on this thread (include/scda_ops.h: scda_conv2d_next_row_period)"""
+    if period:
+        lib().scda_conv2d_next_row_period(i32(period))
+
+
+def conv2d_fwd(x, w, bias, stride, pad, act=ACT_NONE, slope=0.01, row_period=0):
     _req(x, "x"); _req(w, "w")
     if bias is not None:
         _req(bias, "bias")
@@ -356,13 +365,14 @@ def conv2d_fwd(x, w, bias, stride, pad, act=ACT_NONE, slope=0.01):
     wp = conv2d_pack_weight(w, False)
     y = torch.empty(B, Cout, OH, OW, dtype=torch.float32, device=x.device)
     ws, n = _conv_ws(B, Cin, IH, IW, Cout, KH, KW, stride, pad, x.device)
+    _row_period(row_period)
     _check(lib().scda_conv2d_fwd_hip(_p(x), _p(wp), _p(bias), _p(y), i32(B), i32(Cin), i32(IH), i32(IW), i32(Cout), i32(KH),
                                      i32(KW), i32(stride), i32(pad), i32(act), f32(slope), _p(ws), _sz(n), _stream()),
            "scda_conv2d_fwd_hip")
     return y
 
 
-def conv2d_dgrad(dy, w, x_shape, stride, pad, act_src=None, act_slope=0.0):
+def conv2d_dgrad(dy, w, x_shape, stride, pad, act_src=None, act_slope=0.0, row_period=0):
     """act_src (the conv's input x, a ReLU / LeakyReLU output): dx is additionally multiplied by x > 0 ? 1 : act_slope -- the
     activation gradient of the layer that produced x, folded into this kernel's epilogue"""
     _req(dy, "dy"); _req(w, "w")
@@ -381,13 +391,14 @@ def conv2d_dgrad(dy, w, x_shape, stride, pad, act_src=None, act_slope=0.0):
         return dx
     wt = conv2d_pack_weight(w, True)
     ws, n = _conv_ws(B, Cin, IH, IW, Cout, KH, KW, stride, pad, dy.device)
+    _row_period(row_period)
     _check(lib().scda_conv2d_dgrad_act_hip(_p(dy), _p(wt), _p(dx), i32(B), i32(Cin), i32(IH), i32(IW), i32(Cout), i32(KH),
                                            i32(KW), i32(stride), i32(pad), _p(act_src), f32(act_slope), _p(ws), _sz(n), _stream()),
            "scda_conv2d_dgrad_act_hip")
     return dx
 
 
-def conv2d_wgrad(dy, x, w_shape, stride, pad, out=None):
+def conv2d_wgrad(dy, x, w_shape, stride, pad, out=None, row_period=0):
     """dw = wgrad(dy, x); with `out` given, accumulates into it."""
     _req(dy, "dy"); _req(x, "x")
     B, Cin, IH, IW = x.shape
@@ -398,13 +409,14 @@ def conv2d_wgrad(dy, x, w_shape, stride, pad, out=None):
     else:
         _req(out, "out"); acc = 1
     ws, n = _conv_ws(B, Cin, IH, IW, Cout, KH, KW, stride, pad, x.device)
+    _row_period(row_period)
     _check(lib().scda_conv2d_wgrad_hip(_p(dy), _p(x), _p(out), i32(B), i32(Cin), i32(IH), i32(IW), i32(Cout), i32(KH),
                                        i32(KW), i32(stride), i32(pad), i32(acc), _p(ws), _sz(n), _stream()),
            "scda_conv2d_wgrad_hip")
     return out
 
 
-def conv2d_wgrad_bias(dy, x, w_shape, stride, pad, out=None, db_out=None):
+def conv2d_wgrad_bias(dy, x, w_shape, stride, pad, out=None, db_out=None, row_period=0):
     """(dw, db): weight and bias gradient of a conv layer.  One fused pass (the bias gradient rides on the weight-gradient
     GEMM's operand fragments) when the library says the shape allows it, otherwise the two separate kernels.  `out` /
     `db_out` given: accumulate into them."""
@@ -413,7 +425,7 @@ def conv2d_wgrad_bias(dy, x, w_shape, stride, pad, out=None, db_out=None):
     Cout, _, KH, KW = w_shape
     L = lib()
     if not L.scda_conv2d_wgrad_bias_fusable(i32(B), i32(Cout), i32(dy.shape[2]), i32(dy.shape[3]), _p(dy)):
-        return conv2d_wgrad(dy, x, w_shape, stride, pad, out=out), bias_grad_nchw(dy, out=db_out)
+        return conv2d_wgrad(dy, x, w_shape, stride, pad, out=out, row_period=row_period), bias_grad_nchw(dy, out=db_out)
     acc = dbacc = 0
     if out is None:
         out = torch.empty(tuple(w_shape), dtype=torch.float32, device=x.device)
@@ -424,6 +436,7 @@ def conv2d_wgrad_bias(dy, x, w_shape, stride, pad, out=None, db_out=None):
     else:
         _req(db_out, "db_out"); dbacc = 1
     ws, n = _conv_ws(B, Cin, IH, IW, Cout, KH, KW, stride, pad, x.device)
+    _row_period(row_period)
     _check(L.scda_conv2d_wgrad_bias_hip(_p(dy), _p(x), _p(out), _p(db_out), i32(B), i32(Cin), i32(IH), i32(IW), i32(Cout),
                                         i32(KH), i32(KW), i32(stride), i32(pad), i32(acc), i32(dbacc), _p(ws), _sz(n),
                                         _stream()), "scda_conv2d_wgrad_bias_hip")

@@ -114,3 +114,85 @@ def test_resnet50_scda_iteration(cuda):
     assert any(k.startswith('layer2.') for k in moved) and any(k.startswith('layer4.') for k in moved) and 'fc_rcnn_cls.weight' in moved
     assert not [k for k in moved if k.startswith(('conv1.', 'bn1.', 'layer1.'))]
     assert int(after['layer2.0.bn1.num_batches_tracked']) == 2 and int(after['layer1.0.bn1.num_batches_tracked']) == 0
+
+
+@pytest.mark.parametrize("R,C,Co,k", [(32, 32, 48, 3), (48, 16, 16, 3), (16, 64, 32, 1), (5, 8, 8, 3)])
+def test_conv_on_stacked_maps_equals_batched_conv(cuda, R, C, Co, k):
+    """row_period (include/scda_ops.h: scda_conv2d_next_row_period): a 3x3 convolution of the channel-major view [1, C, R*7, 7]
+    with row period 7 == the convolution of the batch [R, C, 7, 7], forward, data gradient and weight gradient (the direct-to-
+    LDS kernels when R*49 % 16 == 0 and C % 16 == 0, the register-staged ones otherwise)"""
+    from scda_amd import native
+    g = torch.Generator().manual_seed(R + C)
+    x = torch.randn(R, C, 7, 7, generator=g); w = torch.randn(Co, C, k, k, generator=g) * 0.1
+    dy = torch.randn(R, Co, 7, 7, generator=g)
+    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+    y = F.conv2d(xr, wr, None, 1, k // 2); y.backward(dy)
+
+    def tall(t):   # [R, C, 7, 7] -> [1, C, R*7, 7]
+        return t.permute(1, 0, 2, 3).reshape(1, t.shape[1], R * 7, 7).contiguous().to(cuda)
+
+    def back(t):   # [1, C, R*7, 7] -> [R, C, 7, 7]
+        return t.view(t.shape[1], R, 7, 7).permute(1, 0, 2, 3).cpu()
+
+    xt, dyt, wg = tall(x), tall(dy), w.to(cuda)
+    close(back(native.conv2d_fwd(xt, wg, None, 1, k // 2, row_period=7)), y, 1e-5)
+    close(back(native.conv2d_dgrad(dyt, wg, xt.shape, 1, k // 2, row_period=7)), xr.grad, 1e-5)
+    close(native.conv2d_wgrad(dyt, xt, w.shape, 1, k // 2, row_period=7).cpu(), wr.grad, 1e-5)
+    if k == 3:   # without the period the taps DO cross maps: the modifier is what makes the difference
+        leak = back(native.conv2d_fwd(xt, wg, None, 1, 1))
+        assert (leak - y).abs().max() > 1e-3
+        with pytest.raises(native.ScdaNativeError):     # a convolution it cannot honour fails loudly
+            native.conv2d_fwd(xt, wg, None, 1, 1, row_period=R * 7 - 1)
+
+
+def test_roi_align_channel_major(cuda):
+    from scda_amd import native
+    from test_oracle_golden import rand_rois
+    rs = np.random.RandomState(5)
+    feat = torch.from_numpy(rs.randn(2, 24, 50, 84).astype(np.float32)).to(cuda)
+    rois = torch.from_numpy(rand_rois(rs, 48, B=2, W=84 * 16, H=50 * 16)).to(cuda)
+    a = native.roi_align_fwd(feat, rois, 8, 8, 1 / 16.)
+    b = native.roi_align_fwd(feat, rois, 8, 8, 1 / 16., channel_major=True)
+    assert b.shape == (24, 48, 8, 8) and torch.equal(b.permute(1, 0, 2, 3), a)
+    top = torch.randn_like(a)
+    ga = native.roi_align_bwd(top, rois, feat.shape, 8, 8, 1 / 16.)
+    gb = native.roi_align_bwd(top.permute(1, 0, 2, 3).contiguous(), rois, feat.shape, 8, 8, 1 / 16., channel_major=True)
+    close(gb, ga, 1e-5)
+
+
+def test_channel_major_roi_head_equals_reference_layout(cuda, monkeypatch):
+    """ResNet.rcnn(): the MI355X layout of the RoI head (pooled maps [C, R, 7, 7], layer4 on the view [1, C, R*7, 7], 3x3
+    convolutions with row period 7) against the reference's [R, C, 7, 7] layout on the same weights: features, class / box
+    outputs, gradient w.r.t. the backbone feature map, every layer4 / head parameter gradient and the BN running statistics."""
+    import bench
+    from scda_amd.dropin.models.mask_rcnn.resnet import resnet50
+    from test_oracle_golden import rand_rois
+    torch.manual_seed(7)
+    det = resnet50(cfg=dict(bench.CFG['shared'], roi_align=True, gan_model_flag=2)).to(cuda).train()
+    rs = np.random.RandomState(9)
+    feat = (torch.randn(1, 1024, 24, 40, generator=torch.Generator().manual_seed(8)) * 0.5).to(cuda)
+    rois = torch.from_numpy(rand_rois(rs, 32, B=1, W=40 * 16, H=24 * 16)).to(cuda)
+    state = {k: v.clone() for k, v in det.state_dict().items()}
+    res = {}
+    for name in ("tall", "nchw"):
+        det.load_state_dict(state)
+        det.zero_grad(set_to_none=True)
+        if name == "nchw":
+            monkeypatch.setenv("SCDA_RESNET_HEAD_NCHW", "1")
+        f = feat.clone().requires_grad_()
+        x_fea, cls, loc = det.rcnn(f, rois)
+        assert det.roipooling.channel_major == (name == "tall")
+        g = torch.Generator().manual_seed(10)
+        loss = (x_fea * torch.randn(x_fea.shape, generator=g).to(cuda)).sum() + (cls * torch.randn(cls.shape, generator=g).to(cuda)).sum() \
+            + (loc * torch.randn(loc.shape, generator=g).to(cuda)).sum()
+        loss.backward()
+        res[name] = dict(x_fea=x_fea.detach(), cls=cls.detach(), loc=loc.detach(), dfeat=f.grad,
+                         grads={k: p.grad.clone() for k, p in det.named_parameters() if p.grad is not None},
+                         stats={k: v.clone() for k, v in det.state_dict().items() if 'layer4' in k and 'running' in k})
+    assert any(k.startswith("layer4.0.conv2") for k in res["tall"]["grads"])
+    for k in ("x_fea", "cls", "loc", "dfeat"):
+        close(res["tall"][k], res["nchw"][k], 2e-5)
+    for k, gr in res["nchw"]["grads"].items():
+        close(res["tall"]["grads"][k], gr, 5e-5)
+    for k, v in res["nchw"]["stats"].items():
+        close(res["tall"]["stats"][k], v, 1e-5)
