@@ -1,0 +1,40 @@
+#!/bin/bash
+# The whole committed evidence set of a round, from ONE snapshot, on the MI355X box:
+#   gpurun --timeout 1500 -- 'bash scripts/collect_all.sh r02'
+# then, back in the build container:  bash scripts/collect_all.sh --install r02   (copies the summaries into profiles/)
+set -u
+if [ "${1:-}" = "--install" ]; then
+  TAG=${2:-r02}; S=gpurun_out/$TAG; D=profiles
+  cp $S/bench_1gpu.json $D/${TAG}_bench_1gpu.json
+  cp $S/bench_under_rocprof.json $D/${TAG}_bench_under_rocprof.json
+  cp $S/kernel_stats.md $D/${TAG}_kernel_stats.md
+  cp $S/kernel_categories.md $D/${TAG}_kernel_categories.md
+  cp $S/pmc_mfma.md $D/${TAG}_pmc_mfma.md
+  cp $S/pmc_traffic.md $D/${TAG}_pmc_traffic.md
+  cp $S/pmc_traffic.json $D/${TAG}_pmc_traffic.json
+  cp $S/exposed_time.md $D/${TAG}_exposed_time.md
+  cp $S/shape_budget.txt $D/${TAG}_shape_budget.txt
+  cp $S/conv_layers.txt $D/${TAG}_conv_layers.txt
+  cp $S/resnet50/bench_under_rocprof.json $D/${TAG}_resnet50_bench_under_rocprof.json
+  cp $S/resnet50/kernel_stats.md $D/${TAG}_resnet50_kernel_stats.md
+  cp $S/resnet50/kernel_categories.md $D/${TAG}_resnet50_kernel_categories.md
+  cp $S/resnet50_bench.json $D/${TAG}_resnet50_bench_1gpu.json
+  exit 0
+fi
+TAG=${1:-r02}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+cd $R
+bash scripts/collect_profiles.sh $TAG > $OUT/collect.log 2>&1
+python scripts/kernel_categories.py $OUT/kernel_stats.md 13 > $OUT/kernel_categories.md
+( cd /tmp; export TMPDIR=/tmp
+  rocprofv3 --kernel-trace --output-format csv -d $OUT/kt_csv -o kt -- python $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline > $OUT/kt_csv.log 2>&1 )
+python scripts/exposed_time.py "$OUT/kt_csv/*kernel_trace.csv" 6 > $OUT/exposed_time.md
+rm -rf $OUT/kt_csv
+python scripts/shape_budget.py > $OUT/shape_budget.txt 2>/dev/null
+python scripts/bench_conv_layers.py > $OUT/conv_layers.txt 2>/dev/null
+python bench.py --config resnet50 --steps 10 --warmup 4 --no-cpu-baseline > $OUT/resnet50_bench.json 2>/dev/null
+mkdir -p $OUT/resnet50
+bash scripts/kt.sh $TAG/resnet50 "--config resnet50" > $OUT/resnet50/kernel_categories.md 2>/dev/null
+cat $OUT/bench_1gpu.json
