@@ -160,7 +160,7 @@ def main():
     bh, bw, f_iter, dominant = H, W, F_ITER_TFLOP, DOMINANT
     if a.config == "resnet50":
         from scda_amd import resnet_config as RC
-        bh, bw, f_iter, dominant = RC.H, RC.W, RC.f_iter_tflop(), None
+        bh, bw, f_iter, dominant = RC.H, RC.W, RC.f_iter_tflop(), RC.DOMINANT
         tr = RC.make_trainer(CFG, dev, lr=1.25e-5, world_size=world)
     else:
         tr = ScdaTrainer(CFG, dev, lr=1.25e-5, new_w=W, new_h=H, world_size=world)
@@ -189,7 +189,7 @@ def main():
     if world > 1:
         dist.barrier()
     native.prof_enable([dominant] if dominant else True)   # event pairs around the dominant kernel only: they are queue markers
-    # (the ResNet configuration has no pre-declared dominant class: every GEMM class is timed and the largest one reported)
+
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):

@@ -607,6 +607,124 @@ __global__ __launch_bounds__(256) void batchnorm_bwd_kernel(const float *__restr
     }
 }
 
+// ---- batch 1 (every layer of a batch-1 detector, and the channel-major RoI head [1, C, R*7, 7]): a channel is ONE contiguous
+// plane.  One 1024-thread workgroup per channel reads the plane ONCE with float4 loads and keeps it in registers (VPT float4 per
+// thread) across the mean / centred-variance / normalise passes, like the instance norm above: 8 B per element forward (the
+// three-pass forms move 16), 12 B backward (20).  Same arithmetic and reduction structure as batchnorm_fwd_kernel.
+template <int VPT>
+__global__ __launch_bounds__(1024) void bn_plane_fwd_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                            const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                            float *__restrict__ run_mean, float *__restrict__ run_var,
+                                                            float *__restrict__ mean_out, float *__restrict__ rstd_out,
+                                                            const int HW, const float eps, const float momentum,
+                                                            const int act, const float slope) {
+    __shared__ float red[16];
+    const int c = blockIdx.x, n4 = HW >> 2;
+    const float n = (float)HW;
+    const float4 *x4 = reinterpret_cast<const float4 *>(x + (size_t)c * HW);
+    float4 v[VPT];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+        const int i = j * 1024 + threadIdx.x;
+        v[j] = i < n4 ? x4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    }
+    const float mean = block_sum(s, red) / n;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+        if (j * 1024 + (int)threadIdx.x < n4) {
+            const float a = v[j].x - mean, b = v[j].y - mean, cc = v[j].z - mean, d = v[j].w - mean;
+            q += (a * a + b * b) + (cc * cc + d * d);
+        }
+    }
+    const float var = block_sum(q, red) / n;
+    const float rstd = 1.f / sqrtf(var + eps);
+    const float ga = gamma[c], be = beta[c];
+    float4 *y4 = reinterpret_cast<float4 *>(y + (size_t)c * HW);
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+        const int i = j * 1024 + threadIdx.x;
+        if (i < n4) {
+            float4 o;
+            o.x = inorm_act((v[j].x - mean) * rstd * ga + be, act, slope);
+            o.y = inorm_act((v[j].y - mean) * rstd * ga + be, act, slope);
+            o.z = inorm_act((v[j].z - mean) * rstd * ga + be, act, slope);
+            o.w = inorm_act((v[j].w - mean) * rstd * ga + be, act, slope);
+            y4[i] = o;
+        }
+    }
+    if (threadIdx.x == 0) {
+        mean_out[c] = mean; rstd_out[c] = rstd;
+        if (run_mean) {
+            run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean;
+            run_var[c] = (1.f - momentum) * run_var[c] + momentum * var * (n / (n - 1.f));
+        }
+    }
+}
+
+template <int VPT>
+__global__ __launch_bounds__(1024) void bn_plane_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ x,
+                                                            const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                            const float *__restrict__ mean_in, const float *__restrict__ rstd_in,
+                                                            float *__restrict__ dx, float *__restrict__ dgamma,
+                                                            float *__restrict__ dbeta, const int HW, const int act,
+                                                            const float slope, const int accumulate) {
+    __shared__ float red[16];
+    const int c = blockIdx.x, n4 = HW >> 2;
+    const float n = (float)HW;
+    const float mean = mean_in[c], rstd = rstd_in[c], ga = gamma[c], be = beta[c];
+    const float4 *x4 = reinterpret_cast<const float4 *>(x + (size_t)c * HW), *g4 = reinterpret_cast<const float4 *>(dy + (size_t)c * HW);
+    auto gate = [&](float g, float xh) -> float {
+        const float pre = xh * ga + be;
+        if (act == 2) return pre > 0.f ? g : g * slope;
+        if (act == 1) return pre > 0.f ? g : 0.f;
+        return g;
+    };
+    float4 xh[VPT], g[VPT];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+        const int i = j * 1024 + threadIdx.x;
+        const bool ok = i < n4;
+        const float4 xv = ok ? x4[i] : make_float4(mean, mean, mean, mean), gv = ok ? g4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        xh[j].x = (xv.x - mean) * rstd; xh[j].y = (xv.y - mean) * rstd; xh[j].z = (xv.z - mean) * rstd; xh[j].w = (xv.w - mean) * rstd;
+        g[j].x = gate(gv.x, xh[j].x); g[j].y = gate(gv.y, xh[j].y); g[j].z = gate(gv.z, xh[j].z); g[j].w = gate(gv.w, xh[j].w);
+        s1 += (g[j].x + g[j].y) + (g[j].z + g[j].w);
+        s2 += (g[j].x * xh[j].x + g[j].y * xh[j].y) + (g[j].z * xh[j].z + g[j].w * xh[j].w);
+    }
+    const float sum1 = block_sum(s1, red), sum2 = block_sum(s2, red);
+    const float m1 = sum1 / n, m2 = sum2 / n;
+    if (dx) {
+        float4 *d4 = reinterpret_cast<float4 *>(dx + (size_t)c * HW);
+        const float k = ga * rstd;
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) {
+            const int i = j * 1024 + threadIdx.x;
+            if (i < n4) {
+                float4 o;
+                o.x = k * (g[j].x - m1 - xh[j].x * m2); o.y = k * (g[j].y - m1 - xh[j].y * m2);
+                o.z = k * (g[j].z - m1 - xh[j].z * m2); o.w = k * (g[j].w - m1 - xh[j].w * m2);
+                d4[i] = o;
+            }
+        }
+    }
+    if (threadIdx.x == 0) {
+        dgamma[c] = accumulate ? dgamma[c] + sum2 : sum2;
+        dbeta[c] = accumulate ? dbeta[c] + sum1 : sum1;
+    }
+}
+
+// VPT of the plane kernels for a batch-1 layer, or 0 when it does not apply (batch > 1, plane not a multiple of 4 floats or larger
+// than 16 float4 per thread, unaligned pointers)
+static int bn_plane_vpt(int B, int HW, const void *a, const void *b, const void *c, int max_vpt = 16) {
+    if (B != 1 || (HW & 3) || HW > max_vpt * 4096 || getenv("SCDA_BN_NO_PLANE")) return 0;
+    if ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c)) & 15) return 0;
+    const int need = (HW / 4 + 1023) / 1024;
+    return need <= 2 ? 2 : need <= 5 ? 5 : need <= 7 ? 7 : need <= 10 ? 10 : 16;
+}
+
 // ---- the same, for maps large enough that one workgroup per channel leaves the chip idle (ResNet layer2/3 at 800 x 1344: 64-256
 // channels x 16800-67200 pixels): S slices per channel, statistics through per-slice partials (fixed summation order).
 //   fwd: bn_slice_sum -> bn_slice_sq (centred, as the one-kernel form) -> bn_slice_apply     bwd: bn_slice_grad_sums -> bn_slice_dx
@@ -1187,6 +1305,12 @@ SCDA_API int scda_batchnorm_fwd_hip(const float *x, float *y, const float *gamma
                                     float *running_var, float *save_mean, float *save_rstd, int B, int C, int HW,
                                     float eps, float momentum, int act, float slope, float *ws, void *stream) {
     NN_CHECK(x && y && gamma && beta && save_mean && save_rstd && B > 0 && C > 0 && HW > 0, "scda_batchnorm_fwd_hip")
+    if (const int vpt = bn_plane_vpt(B, HW, x, y, nullptr)) {
+#define BN_PLANE_FWD(V) hipLaunchKernelGGL(bn_plane_fwd_kernel<V>, dim3(C), dim3(1024), 0, as_stream(stream), x, y, gamma, beta, running_mean, running_var, save_mean, save_rstd, HW, eps, momentum, act, slope)
+        if (vpt == 2) BN_PLANE_FWD(2); else if (vpt == 5) BN_PLANE_FWD(5); else if (vpt == 7) BN_PLANE_FWD(7); else if (vpt == 10) BN_PLANE_FWD(10); else BN_PLANE_FWD(16);
+#undef BN_PLANE_FWD
+        return launch_status("bn_plane_fwd_kernel");
+    }
     const int S = bn_slices(B, C, HW);
     if (S > 1) {
         NN_CHECK(ws, "scda_batchnorm_fwd_hip (workspace)")
@@ -1209,6 +1333,12 @@ SCDA_API int scda_batchnorm_bwd_hip(const float *dy, const float *x, const float
                                     float *dbeta, int B, int C, int HW, int act, float slope, int accumulate,
                                     float *ws, void *stream) {
     NN_CHECK(dy && x && gamma && beta && save_mean && save_rstd && dgamma && dbeta && B > 0 && C > 0 && HW > 0, "scda_batchnorm_bwd_hip")
+    if (const int vpt = bn_plane_vpt(B, HW, x, dy, dx, 10)) {   // backward keeps TWO planes in registers: 16 float4 each would spill
+#define BN_PLANE_BWD(V) hipLaunchKernelGGL(bn_plane_bwd_kernel<V>, dim3(C), dim3(1024), 0, as_stream(stream), dy, x, gamma, beta, save_mean, save_rstd, dx, dgamma, dbeta, HW, act, slope, accumulate)
+        if (vpt == 2) BN_PLANE_BWD(2); else if (vpt == 5) BN_PLANE_BWD(5); else if (vpt == 7) BN_PLANE_BWD(7); else BN_PLANE_BWD(10);
+#undef BN_PLANE_BWD
+        return launch_status("bn_plane_bwd_kernel");
+    }
     const int S = bn_slices(B, C, HW);
     if (S > 1) {
         NN_CHECK(ws, "scda_batchnorm_bwd_hip (workspace)")

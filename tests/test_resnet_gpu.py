@@ -25,9 +25,12 @@ def test_maxpool_3x3_stride2(cuda, shape):
     assert torch.equal(native.maxpool3x3s2_fwd(x.to(cuda)).cpu(), F.max_pool2d(x, 3, 2, 1))
 
 
-@pytest.mark.parametrize("shape", [(512, 32, 7, 7), (1, 16, 50, 84), (1, 64, 100, 168), (2, 8, 200, 336)])
+@pytest.mark.parametrize("shape", [(512, 32, 7, 7), (1, 16, 50, 84), (1, 64, 100, 168), (2, 8, 200, 336),
+                                   (1, 8, 3584, 7), (1, 4, 160, 256), (1, 4, 200, 300), (1, 8, 7, 7), (1, 3, 30, 34)])
 def test_batch_norm_train_on_roi_shaped_input(cuda, shape):
-    """the (image, pixel) index space of a channel is walked as one range: 512 RoIs x 7 x 7 (layer4) and 1 x 50 x 84"""
+    """the (image, pixel) index space of a channel is walked as one range: 512 RoIs x 7 x 7 (layer4) and 1 x 50 x 84; batch-1
+    planes of <= 16 x 4096 floats go through the register-resident plane kernels (2 / 5 / 7 / 10 / 16 float4 per thread: 4200,
+    16800, 25088 = the channel-major RoI head, 40960, 60000 elements), others through the per-channel / sliced forms"""
     from scda_amd import autograd_ops as A
     g = torch.Generator().manual_seed(2)
     x = torch.randn(*shape, generator=g) * 1.3 + 0.2
@@ -160,10 +163,24 @@ def test_roi_align_channel_major(cuda):
     close(gb, ga, 1e-5)
 
 
-def test_channel_major_roi_head_equals_reference_layout(cuda, monkeypatch):
+def rel_l2(a, b):
+    a = a.detach().cpu().double(); b = b.detach().cpu().double()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+@pytest.mark.parametrize("plane_bn", [False, True])
+def test_channel_major_roi_head_equals_reference_layout(cuda, monkeypatch, plane_bn):
     """ResNet.rcnn(): the MI355X layout of the RoI head (pooled maps [C, R, 7, 7], layer4 on the view [1, C, R*7, 7], 3x3
     convolutions with row period 7) against the reference's [R, C, 7, 7] layout on the same weights: features, class / box
-    outputs, gradient w.r.t. the backbone feature map, every layer4 / head parameter gradient and the BN running statistics."""
+    outputs, gradient w.r.t. the backbone feature map, every layer4 / head parameter gradient and the BN running statistics.
+    plane_bn=False: both layouts normalise with the per-channel kernel family -> element-wise agreement to 2e-5 / 5e-5 of the
+    maximum.  plane_bn=True (the default build): the tall layout's batch norms are the register-resident plane kernels; they
+    agree with the others to 2e-7 per call (scripts/debug_bn_plane.py), which is enough to flip the fused ReLU gate of a
+    pre-activation that is zero to the last bit -- one such element moves one row of a weight gradient by a few percent -- so
+    that variant's gradients are compared in relative L2 (< 1e-2; a layout bug -- a tap crossing RoIs, a permuted channel -- is
+    O(1))."""
+    if not plane_bn:
+        monkeypatch.setenv("SCDA_BN_NO_PLANE", "1")
     import bench
     from scda_amd.dropin.models.mask_rcnn.resnet import resnet50
     from test_oracle_golden import rand_rois
@@ -190,9 +207,17 @@ def test_channel_major_roi_head_equals_reference_layout(cuda, monkeypatch):
                          grads={k: p.grad.clone() for k, p in det.named_parameters() if p.grad is not None},
                          stats={k: v.clone() for k, v in det.state_dict().items() if 'layer4' in k and 'running' in k})
     assert any(k.startswith("layer4.0.conv2") for k in res["tall"]["grads"])
-    for k in ("x_fea", "cls", "loc", "dfeat"):
+    for k in ("x_fea", "cls", "loc"):
         close(res["tall"][k], res["nchw"][k], 2e-5)
-    for k, gr in res["nchw"]["grads"].items():
-        close(res["tall"]["grads"][k], gr, 5e-5)
     for k, v in res["nchw"]["stats"].items():
         close(res["tall"]["stats"][k], v, 1e-5)
+    if plane_bn:
+        # a flipped gate changes one element of one gradient map; by the time it has travelled back through the blocks below
+        # it is a dense perturbation of ~1e-3 relative L2 (measured: 2.4e-3 on layer4.0.conv1.weight)
+        assert rel_l2(res["tall"]["dfeat"], res["nchw"]["dfeat"]) < 1e-2
+        for k, gr in res["nchw"]["grads"].items():
+            assert rel_l2(res["tall"]["grads"][k], gr) < 1e-2, k
+    else:
+        close(res["tall"]["dfeat"], res["nchw"]["dfeat"], 2e-5)
+        for k, gr in res["nchw"]["grads"].items():
+            close(res["tall"]["grads"][k], gr, 5e-5)
