@@ -1348,6 +1348,12 @@ static void note_plan(int bm, int bn, int splits, int glds) { g_last_plan[0] = b
 
 static int resident_per_cu(int bm, int bn) { return bm == 256 ? 1 : ((bm == 128 && bn == 128) || bn == 256) ? 2 : (bm == 64 && bn == 64) ? 4 : 3; }
 static double tile_efficiency(int bm, int bn) { return bm == 256 ? 1.05 : ((bm == 128 && bn == 128) || bn == 256) ? 1.0 : (bm == 64 && bn == 64) ? 0.85 : 0.90; }
+// 1x1 convolutions (one filter tap): a K-slab never re-reads lines the previous slabs brought into L1 / L2 (a 3x3 layer's nine taps
+// of a channel group are consecutive slabs over the same input lines), every gather is a fresh L2 / HBM access, and what hides that
+// latency is the number of independent workgroups per CU, not the MFMA work per barrier: brute force over the ResNet-50 shapes
+// (scripts/tune_plans.py resnet) has the 64x64 tile (4 resident per CU) ahead of the 8-wave 256x128 tile by 7 - 23 % on EVERY 1x1
+// forward / data-gradient layer (head 512 -> 2048 on 25088 pixels: 470 vs 561 us), and level with it on every 3x3 layer.
+static double tile_efficiency_one_tap(int bm, int bn) { return (bm == 64 && bn == 64) ? 1.0 : (bm == 64 || (bm == 128 && bn == 64)) ? 0.9 : 0.85; }
 
 // time, in units of one workgroup running at full CU speed, for the busiest CU to finish c workgroups with p resident
 static double cu_rounds(int c, int p, bool eight_waves = false) {
@@ -1361,10 +1367,10 @@ static double cu_rounds(int c, int p, bool eight_waves = false) {
     return t;
 }
 
-static double plan_cost(long long tiles, int splits, int bm, int bn, double flops, double out_bytes) {
+static double plan_cost(long long tiles, int splits, int bm, int bn, double flops, double out_bytes, bool one_tap = false) {
     const long long wgs = tiles * splits;
     const double ideal = (double)wgs / 256.0;
-    const double eff = ideal / cu_rounds(cdiv(wgs, 256), resident_per_cu(bm, bn), bm == 256) * tile_efficiency(bm, bn);
+    const double eff = ideal / cu_rounds(cdiv(wgs, 256), resident_per_cu(bm, bn), bm == 256) * (one_tap ? tile_efficiency_one_tap(bm, bn) : tile_efficiency(bm, bn));
     double t = flops / (eff * 110e12);
     if (splits > 1) t += 2.0 * splits * out_bytes / 3e12;
     return t;
@@ -1372,11 +1378,11 @@ static double plan_cost(long long tiles, int splits, int bm, int bn, double flop
 
 // bn_lo..bn_hi: candidate N-tile widths (64 and/or 128); must_split: the kernel always writes slabs (weight gradient)
 static LaunchPlan plan_search(int M, int N, int K, int bm, bool allow64, bool allow128, bool must_split, size_t ws_bytes,
-                              int k_granule, bool allow256, bool allow_bm256);
+                              int k_granule, bool allow256, bool allow_bm256, bool one_tap);
 
 // memoised per thread (the same ~60 shapes recur every iteration; launches come from the main and the autograd thread)
 static LaunchPlan plan_launch(int M, int N, int K, int bm, bool allow64, bool allow128, bool must_split, size_t ws_bytes,
-                              int k_granule, bool allow256 = false, bool allow_bm256 = false) {
+                              int k_granule, bool allow256 = false, bool allow_bm256 = false, bool one_tap = false) {
     if (const char *f = getenv("SCDA_PLAN_FORCE")) {   // tuning aid: "bm,bn,splits" for every launch (scripts/tune_plans.py)
         int fb = 0, fn = 0, fs = 0;
         if (sscanf(f, "%d,%d,%d", &fb, &fn, &fs) == 3) {
@@ -1389,10 +1395,10 @@ static LaunchPlan plan_launch(int M, int N, int K, int bm, bool allow64, bool al
     struct Key { int M, N, K, flags; size_t ws; };
     struct Entry { Key k; LaunchPlan p; };
     static thread_local std::vector<Entry> cache;
-    const Key key{M, N, K, bm | (allow64 << 8) | (allow128 << 9) | (must_split << 10) | (allow256 << 11) | (k_granule << 12) | (allow_bm256 << 20), ws_bytes};
+    const Key key{M, N, K, bm | (allow64 << 8) | (allow128 << 9) | (must_split << 10) | (allow256 << 11) | (k_granule << 12) | (allow_bm256 << 20) | (one_tap << 21), ws_bytes};
     for (const Entry &e : cache)
         if (e.k.M == key.M && e.k.N == key.N && e.k.K == key.K && e.k.flags == key.flags && e.k.ws == key.ws) return e.p;
-    const LaunchPlan p = plan_search(M, N, K, bm, allow64, allow128, must_split, ws_bytes, k_granule, allow256, allow_bm256);
+    const LaunchPlan p = plan_search(M, N, K, bm, allow64, allow128, must_split, ws_bytes, k_granule, allow256, allow_bm256, one_tap);
     if (getenv("SCDA_PLAN_LOG"))
         fprintf(stderr, "[scda plan] M=%d N=%d K=%d %s-> tile %dx%d splits %d (%lld workgroups)\n", M, N, K, must_split ? "wgrad " : "",
                 p.bm, p.bn, p.splits, (long long)cdiv(M, p.bm) * cdiv(N, p.bn) * p.splits);
@@ -1401,7 +1407,7 @@ static LaunchPlan plan_launch(int M, int N, int K, int bm, bool allow64, bool al
 }
 
 static LaunchPlan plan_search(int M, int N, int K, int bm, bool allow64, bool allow128, bool must_split, size_t ws_bytes,
-                              int k_granule, bool allow256, bool allow_bm256) {
+                              int k_granule, bool allow256, bool allow_bm256, bool one_tap) {
     const double flops = 2.0 * M * (double)N * K, out_bytes = (double)M * N * sizeof(float);
     double best_t = 1e30;
     int max_s = K / (k_granule * 4);   // at least 4 K-steps per split
@@ -1411,7 +1417,8 @@ static LaunchPlan plan_search(int M, int N, int K, int bm, bool allow64, bool al
     LaunchPlan best{allow128 ? 128 : 64, 1, bm};
     // tile-row candidates: the natural one; 256 (8 waves) where legal; 64 for 65..128-row problems (the decoder's 128-channel
     // layers: 512 half-height tiles and no split-K beat 128 full tiles split four ways by ~6 %)
-    const bool allow_bm64 = bm == 128 && M <= 128 && allow64 && !must_split && k_granule == BK;
+    // ... and for 1x1 convolutions of any height (tile_efficiency_one_tap)
+    const bool allow_bm64 = bm == 128 && (M <= 128 || one_tap) && allow64 && !must_split && k_granule == BK;
     for (int pass = 0; pass < 3; ++pass) {
         if ((pass == 1 && !allow_bm256) || (pass == 2 && !allow_bm64)) continue;
         const int tbm = pass == 1 ? 256 : pass == 2 ? 64 : bm;
@@ -1421,7 +1428,7 @@ static LaunchPlan plan_search(int M, int N, int K, int bm, bool allow64, bool al
             const long long tiles = (long long)cdiv(M, tbm) * cdiv(N, bn);
             for (int sp = 1; sp <= max_s; ++sp) {
                 if (tiles * sp > 4096 && sp > 1) break;   // plenty of workgroups already: splitting only adds traffic
-                double t = plan_cost(tiles, sp, tbm, bn, flops, out_bytes);
+                double t = plan_cost(tiles, sp, tbm, bn, flops, out_bytes, one_tap);
                 if (must_split && sp == 1) t += 2.0 * out_bytes / 3e12;
                 if (t < best_t) { best_t = t; best = LaunchPlan{bn, sp, tbm}; }
             }
@@ -1454,8 +1461,10 @@ static int launch_conv(const float *Wm, const float *X, const ConvGeom &g0, Epi 
     const int fbn = force ? (atoi(force) == 64 ? 64 : 128) : 0;
     const char *fbm = getenv("SCDA_CONV_BM");            // experiment / test knob: 256 forces the 8-wave tile where legal
     const bool bm256_ok = g.slab_aligned && (g.M % 256) == 0 && !fbn;
+    static const bool no_one_tap = getenv("SCDA_PLAN_NO_ONE_TAP") != nullptr;   // A/B knob
     LaunchPlan plan = plan_launch(g.M, g.N, g.K, BMv, fbn != 128, fbn != 64, false, ws_bytes, BK,
-                                  small_m && g.slab_aligned && !fbn, bm256_ok && !(fbm && atoi(fbm) != 256));
+                                  small_m && g.slab_aligned && !fbn, bm256_ok && !(fbm && atoi(fbm) != 256),
+                                  KH * KW == 1 && g.slab_aligned && !no_one_tap);
     if (bm256_ok && fbm && atoi(fbm) == 256 && plan.bm != 256) {
         plan.bm = 256; plan.bn = 128;
         while (plan.splits > 1 && (size_t)plan.splits * g.M * g.N * sizeof(float) > ws_bytes) --plan.splits;
