@@ -11,6 +11,7 @@ RoI features, 7x7 average pool, `fc_rcnn_cls / fc_rcnn_loc` on 2048 features; st
 import math
 import os
 
+import torch
 import torch.nn as nn
 
 from scda_amd import autograd_ops as A
@@ -22,6 +23,27 @@ from scda_amd.dropin.models.faster_rcnn.faster_rcnn_adver_expansion_reweight_clu
 from scda_amd.dropin.models.head import NaiveRpnHead
 
 __all__ = ['ResNet', 'Bottleneck', 'resnet50', 'resnet101']
+
+
+def _frozen(conv, bn):
+    return (not bn.training and not conv.weight.requires_grad and not bn.weight.requires_grad and bn.running_mean is not None
+            and conv.bias is None and not os.environ.get("SCDA_RESNET_NO_FOLD"))
+
+
+def folded_conv_bn(x, conv, bn, act):
+    """conv -> eval-mode BN (-> ReLU) of a FROZEN pair (stem and layer1: models/mask_rcnn/resnet.py:213-238 keep them in eval mode
+    with requires_grad = False) as ONE convolution: w' = w * gamma / sqrt(var + eps) per output channel, b' = beta - mean * gamma /
+    sqrt(var + eps), bias and ReLU in the MFMA kernel's epilogue -- the affine map of a frozen batch norm is a constant, so the
+    separate pass over the layer's output (69 MB per layer1 map at 800 x 1344) disappears.  The folded tensors are cached and
+    rebuilt when any of the five source tensors changes (load_state_dict copies in place and bumps their versions)."""
+    key = tuple(t._version for t in (conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var)) + (conv.weight.data_ptr(),)
+    cache = getattr(conv, "_scda_folded", None)
+    if cache is None or cache[0] != key:
+        with torch.no_grad():
+            k = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+            cache = (key, (conv.weight * k.view(-1, 1, 1, 1)).contiguous(), (bn.bias - bn.running_mean * k).contiguous())
+        conv._scda_folded = cache
+    return A.conv2d(x, cache[1], cache[2], conv.stride[0], conv.padding[0], act, 0.0, (None, False), conv.row_period)
 
 
 class Bottleneck(nn.Module):
@@ -41,6 +63,12 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
+        if _frozen(self.conv1, self.bn1) and _frozen(self.conv2, self.bn2) and _frozen(self.conv3, self.bn3):
+            out = folded_conv_bn(x, self.conv1, self.bn1, ACT_RELU)
+            out = folded_conv_bn(out, self.conv2, self.bn2, ACT_RELU)
+            out = folded_conv_bn(out, self.conv3, self.bn3, ACT_NONE)
+            residual = x if self.downsample is None else folded_conv_bn(x, self.downsample[0], self.downsample[1], ACT_NONE)
+            return A.AddReluFn.apply(out, residual)
         out = self.bn1(self.conv1(x))
         out = self.bn2(self.conv2(out))
         out = self.bn3(self.conv3(out))
@@ -112,7 +140,10 @@ class ResNet(FasterRCNN_AdEx):
                 p.requires_grad = False
 
     def feature_extractor(self, x):
-        x = self.maxpool(self.bn1(self.conv1(x)))
+        if _frozen(self.conv1, self.bn1):
+            x = self.maxpool(folded_conv_bn(x, self.conv1, self.bn1, ACT_RELU))
+        else:
+            x = self.maxpool(self.bn1(self.conv1(x)))
         return self.layer3(self.layer2(self.layer1(x)))
 
     def rpn(self, x):

@@ -221,3 +221,44 @@ def test_channel_major_roi_head_equals_reference_layout(cuda, monkeypatch, plane
         close(res["tall"]["dfeat"], res["nchw"]["dfeat"], 2e-5)
         for k, gr in res["nchw"]["grads"].items():
             close(res["tall"]["grads"][k], gr, 5e-5)
+
+
+def test_frozen_conv_bn_folding(cuda, monkeypatch):
+    """stem + layer1 (frozen, eval-mode BN): conv -> BN -> ReLU as one convolution with folded weights and a bias / ReLU epilogue
+    against the separate kernels (SCDA_RESNET_NO_FOLD=1), on non-trivial BN parameters and running statistics; the cache follows
+    an in-place weight update"""
+    import bench
+    from scda_amd.dropin.models.mask_rcnn.resnet import resnet50
+    torch.manual_seed(11)
+    det = resnet50(cfg=dict(bench.CFG['shared'], roi_align=True, gan_model_flag=2)).to(cuda).train()
+    g = torch.Generator().manual_seed(12)
+    with torch.no_grad():
+        for m in list(det.layer1.modules()) + [det.bn1]:
+            if isinstance(m, nn.BatchNorm2d):
+                m.weight.copy_(torch.rand(m.weight.shape, generator=g) + 0.5); m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.2); m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+    x = torch.randn(1, 3, 96, 160, generator=g).to(cuda)
+
+    def stem_layer1():
+        if not_folded:
+            monkeypatch.setenv("SCDA_RESNET_NO_FOLD", "1")
+        else:
+            monkeypatch.delenv("SCDA_RESNET_NO_FOLD", raising=False)
+        with torch.no_grad():
+            if not_folded:
+                t = det.maxpool(det.bn1(det.conv1(x)))
+            else:
+                from scda_amd.dropin.models.mask_rcnn.resnet import folded_conv_bn
+                from scda_amd.autograd_ops import ACT_RELU
+                t = det.maxpool(folded_conv_bn(x, det.conv1, det.bn1, ACT_RELU))
+            return det.layer1(t)
+    not_folded = True; ref = stem_layer1()
+    not_folded = False; got = stem_layer1()
+    assert hasattr(det.layer1[0].conv1, "_scda_folded") and not det.layer1[0].bn1.training
+    close(got, ref, 2e-5)
+    with torch.no_grad():
+        det.layer1[1].conv2.weight.mul_(1.5)         # e.g. load_state_dict: in place, version bump -> re-folded
+    not_folded = True; ref2 = stem_layer1()
+    not_folded = False; got2 = stem_layer1()
+    close(got2, ref2, 2e-5)
+    assert (ref2 - ref).abs().max() > 1e-3
