@@ -12,10 +12,11 @@ Work per iteration (2 FLOP / MAC, conv + FC only, necessary work as in SURVEY.md
 import torch
 
 H, W = 800, 1344
-# kernel class that holds most of the iteration's device time (profiles/r02_resnet50_kernel_stats.md): the head's and layer3's 1x1
-# convolutions, forward.  bench.py wraps ONLY this class in event pairs -- events are queue markers, and timing every GEMM-class
-# launch (340 per iteration) cost 5 ms of the 53 this configuration was first measured at.
-DOMINANT = "conv_igemm_glds_kernel<128|256,*,1,1,1,fwd>"
+# kernel class that holds most of the iteration's device time (profiles/r02_resnet50_kernel_stats.md): the 1x1 convolutions of
+# layer2 / layer3 / the RoI head, forward, on the 64x64 tile the planner gives one-tap layers (86 launches, 9.2 ms per iteration).
+# bench.py times it with event pairs in a separate pass after the timed region (events are queue markers: timing every GEMM-class
+# launch inside the region cost 5 ms of the 53 this configuration was first measured at).
+DOMINANT = "conv_igemm_glds_kernel<64,*,1,1,1,fwd>"
 FEAT_HW = (32, 64)            # view of the 2048-d RoI feature (h, w)
 RECON_HW = (128, 256)
 

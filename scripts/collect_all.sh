@@ -19,6 +19,7 @@ if [ "${1:-}" = "--install" ]; then
   cp $S/resnet50/kernel_stats.md $D/${TAG}_resnet50_kernel_stats.md
   cp $S/resnet50/kernel_categories.md $D/${TAG}_resnet50_kernel_categories.md
   cp $S/resnet50_bench.json $D/${TAG}_resnet50_bench_1gpu.json
+  cp $S/resnet50/exposed_time.md $D/${TAG}_resnet50_exposed_time.md
   exit 0
 fi
 TAG=${1:-r02}
@@ -37,4 +38,8 @@ python scripts/bench_conv_layers.py > $OUT/conv_layers.txt 2>/dev/null
 python bench.py --config resnet50 --steps 10 --warmup 4 --no-cpu-baseline > $OUT/resnet50_bench.json 2>/dev/null
 mkdir -p $OUT/resnet50
 bash scripts/kt.sh $TAG/resnet50 "--config resnet50" > $OUT/resnet50/kernel_categories.md 2>/dev/null
+( cd /tmp; export TMPDIR=/tmp
+  rocprofv3 --kernel-trace --output-format csv -d $OUT/kt_csv -o kt -- python $R/bench.py --config resnet50 --steps 6 --warmup 3 --no-cpu-baseline > $OUT/kt_csv.log 2>&1 )
+python scripts/exposed_time.py "$OUT/kt_csv/*kernel_trace.csv" 6 > $OUT/resnet50/exposed_time.md
+rm -rf $OUT/kt_csv
 cat $OUT/bench_1gpu.json
