@@ -26,6 +26,10 @@ import os
 import sys
 import time
 
+# the host driver of the MI355X boxes only supports dmabuf IPC: without this RCCL's intra-node set-up (and any CUDA-tensor sharing
+# across processes) fails with hipIpcGetMemHandle: invalid argument.  Must be in the environment before HIP initialises.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np
 import torch
 import torch.distributed as dist

@@ -70,6 +70,8 @@ def _first_slurm_host(nodelist):
 
 
 def dist_init(port, backend='nccl'):
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC (the only form the MI355X hosts' driver supports); harmless
+    # when HIP is already initialised with it exported, as the launch environment does
     if 'SLURM_PROCID' in os.environ:
         rank = int(os.environ['SLURM_PROCID'])
         world = int(os.environ['SLURM_NTASKS'])
