@@ -29,6 +29,7 @@
 // vertically adjacent pixel tiles) run on the same XCD at about the same time and share its L2.
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <vector>
 
@@ -1402,6 +1403,18 @@ static LaunchPlan plan_launch(int M, int N, int K, int bm, bool allow64, bool al
                             !(fb == 256 && fn != 128) && fs >= 1 && (fs == 1 || (size_t)fs * M * N * sizeof(float) <= ws_bytes) &&
                             fs <= (K / (k_granule * 2) > 0 ? K / (k_granule * 2) : 1);
             if (ok) return LaunchPlan{fn, fs, fb};
+        }
+    }
+    if (const char *ov = getenv("SCDA_PLAN_OVERRIDE")) {   // tuning aid: "M,N,K:bm,bn,splits;..." for individual shapes, inside the real iteration
+        for (const char *q = ov; q && *q;) {
+            int m = 0, n = 0, k = 0, fb = 0, fn = 0, fs = 0;
+            if (sscanf(q, "%d,%d,%d:%d,%d,%d", &m, &n, &k, &fb, &fn, &fs) == 6 && m == M && n == N && k == K && !must_split) {
+                const bool ok = (fb == bm || (fb == 256 && allow_bm256) || fb == 64) && ((fn == 64 && allow64) || (fn == 128 && allow128) || (fn == 256 && allow256)) &&
+                                !(fb == 256 && fn != 128) && fs >= 1 && (fs == 1 || (size_t)fs * M * N * sizeof(float) <= ws_bytes);
+                if (ok) return LaunchPlan{fn, fs, fb};
+            }
+            q = strchr(q, ';');
+            if (q) ++q;
         }
     }
     struct Key { int M, N, K, flags; size_t ws; };
