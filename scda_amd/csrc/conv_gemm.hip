@@ -677,9 +677,7 @@ __global__ __launch_bounds__((WgradGldsCfg<BM, BN>::THREADS)) void conv_wgrad_gl
     tile_coords(g.nx, g.ny, g.swz, tx, ty, tz);
     const int m0 = ty * BM, n0 = tx * BN;
     const int s_begin = tz * (g.k_per_split / BK);
-    // a batch-1 plane whose pixel count is not a multiple of 16 (ResNet layer3: 50 x 84) ends in a partial slab: it is staged with
-    // the lanes beyond the plane out of range (zeros), see `tail` in issue()
-    const int s_end = (min(g.K, (tz + 1) * g.k_per_split) + BK - 1) / BK;
+    const int s_end = min(g.K, (tz + 1) * g.k_per_split) / BK;
     const int ohw = g.dOHW.d, ihw = g.IH * g.IW;
 
     if (wave >= NWC) {
@@ -736,17 +734,8 @@ __global__ __launch_bounds__((WgradGldsCfg<BM, BN>::THREADS)) void conv_wgrad_gl
         auto issue = [&](int buf) {
             float *st = lds + buf * STAGE;
             const char *a_slab = a_img + (size_t)pix0 * 4;
-            const int left = ohw - pix0;       // pixels of the plane from this slab on; < BK only in the last slab of a batch-1 plane
-            const bool tail = left < BK;       // (the launcher admits OH*OW % 16 != 0 for batch 1 only; OH*OW % 4 == 0 always)
 #pragma unroll
-            for (int i = 0; i < C::A_PP; ++i) {
-                unsigned v = a_voff[i];
-                if (tail) {   // the lane's 16-byte chunk (4 pixels) lies beyond the plane: the next channel's data, not zeros
-                    const int row = (p * C::A_PP + i) * 16 + (lane >> 2);
-                    if (4 * ((lane & 3) ^ ((row >> 2) & 3)) >= left) v = OOB;
-                }
-                buffer_load_lds_b128(a_slab, v, st + (p * C::A_PP + i) * 16 * 16);
-            }
+            for (int i = 0; i < C::A_PP; ++i) buffer_load_lds_b128(a_slab, a_voff[i], st + (p * C::A_PP + i) * 16 * 16);
             float *Bb = st + BK * BM;
             const bool wrap = pix0 + BK >= ohw;
             if (row_slab) {
@@ -786,7 +775,6 @@ __global__ __launch_bounds__((WgradGldsCfg<BM, BN>::THREADS)) void conv_wgrad_gl
                 unsigned mask = 0;
 #pragma unroll
                 for (int kh = 0; kh < KH; ++kh) mask |= ((rowb >> kh) & 1u) ? colb << (kh * KW) : 0u;
-                if (tail && klp[c] + g.pad >= left) mask = 0;   // the lane's pixel is beyond the plane
                 const unsigned off_taps = ~mask;
                 const unsigned x_pix = (unsigned)((oy[c] * S * g.IW + ox[c] * S) * 4);
 #pragma unroll
@@ -1543,8 +1531,10 @@ static int launch_wgrad(const float *dY, const float *X, WgradGeom g, float *dW,
     static const bool no_glds = getenv("SCDA_WGRAD_NO_GLDS") != nullptr;   // A/B knob
     // the LDS-DMA kernel addresses one image of dY / X through a buffer descriptor with 32-bit lane offsets
     const bool fits_2g = (long long)g.Cout * g.OH * g.OW * 4 < (1LL << 31) && (long long)g.Cin * g.IH * g.IW * 4 < (1LL << 31);
-    // K-slabs of 16 pixels must not straddle two images: OH*OW % 16 == 0, or a single image (its last slab is staged partially)
-    const bool glds = !no_glds && g.a_vec4 && ((g.dOHW.d % BK) == 0 || g.batch == 1) && fits_2g;
+    // K-slabs of 16 pixels must not straddle two images: OH*OW % 16 == 0.  (A partial last slab for batch-1 planes was built and
+    // measured: ResNet layer3's 50 x 84 weight gradients took 325 us on this kernel's general addressing path against 162 us on the
+    // register-staged one -- those layers have only 4200 pixels of K to amortise the pipeline over; removed.)
+    const bool glds = !no_glds && g.a_vec4 && (g.dOHW.d % BK) == 0 && fits_2g;
     const char *fbm = getenv("SCDA_CONV_BM");                              // 256 forces the 8-wave tile where legal
     const bool bm256_ok = glds && BNv == 128 && (g.M % 256) == 0;
     LaunchPlan plan = plan_launch(g.M, g.N, g.K, small ? 64 : 128, BNv == 64, BNv == 128, true, ws_bytes, 32, false,

@@ -32,8 +32,8 @@ CONV_CASES = [
     (4, 32, 32, 32, 3, 1, 1, 0),      # decoder's final 1x1
     (1, 64, 20, 28, 128, 1, 2, 0),    # ResNet down-sampling shortcut: 1x1 stride 2
     (2, 256, 15, 21, 512, 1, 2, 0),   # ... odd extents, batch 2
-    # batch-1 planes whose pixel count is a multiple of 4 but not of 16: the weight gradient's last K-slab is partial (50 x 84 = 4200
-    # pixels: ResNet layer3 at 800 x 1344), also across split-K boundaries, with stride 2 and on the 8-wave tile
+    # batch-1 planes whose pixel count is a multiple of 4 but not of 16 (50 x 84 = 4200 pixels: ResNet layer3 at 800 x 1344): the
+    # register-staged weight gradient with float4 dy loads
     (1, 32, 50, 84, 64, 3, 1, 1),
     (1, 64, 50, 84, 256, 1, 1, 0),
     (1, 256, 10, 14, 256, 3, 1, 1),
@@ -147,16 +147,3 @@ def test_conv_full_size_linearity(cuda):
     ref = F.conv2d(x1[:, :, :10, :66].cpu(), w.cpu(), None, padding=1)
     close(y1[:, :, :9, :65], ref[:, :, :9, :65])
 
-
-def test_partial_last_slab_runs_the_lds_dma_weight_gradient(cuda):
-    """batch 1, 50 x 84 = 4200 output pixels (a multiple of 4, not of 16): the weight gradient stays on the direct-to-LDS kernel
-    (its last K-slab is staged with the lanes beyond the plane out of range); with batch 2 the same plane size falls back to the
-    register-staged kernel (a slab would straddle the two images)"""
-    from scda_amd import native
-    g = torch.Generator().manual_seed(5)
-    for B, want in ((1, True), (2, False)):
-        x = torch.randn(B, 32, 50, 84, generator=g); dy = torch.randn(B, 64, 50, 84, generator=g)
-        dw = native.conv2d_wgrad(dy.to(cuda), x.to(cuda), (64, 32, 3, 3), 1, 1)
-        assert native.last_plan()[3] is want
-        ref = torch.nn.grad.conv2d_weight(x, (64, 32, 3, 3), dy, stride=1, padding=1)
-        close(dw, ref, 2e-4)
