@@ -281,3 +281,34 @@ def test_vgg16_bn_detector_trains(cuda):
     sd = tr.model.state_dict()
     assert int(sd['features.1.num_batches_tracked']) == 2          # source and target pass
     assert float(sd['features.1.running_mean'].abs().sum()) > 0
+
+
+def test_gan_phases_as_hipgraph_match_eager(cuda, monkeypatch):
+    """SCDA_GAN_GRAPH=1: phases 1 + 2 (image discriminators + patch discriminator: forward, losses, both backward passes, ~170
+    launches on two streams) recorded once as a hipGraph and replayed from the third iteration on.  Same kernels, same order,
+    same inputs: every parameter bucket, the BN statistics / counters and the logged losses must be BIT-identical to the eager
+    step after five iterations."""
+    from scda_amd.train_step import ScdaTrainer
+    res = {}
+    for name in ("eager", "graph"):
+        if name == "graph":
+            monkeypatch.setenv("SCDA_GAN_GRAPH", "1")
+        else:
+            monkeypatch.delenv("SCDA_GAN_GRAPH", raising=False)
+        torch.manual_seed(1)
+        tr = ScdaTrainer(mc.CFG, cuda, lr=1e-3, new_w=512, new_h=256, models=mc.seeded_models(build_product))
+        np.random.seed(5)
+        losses = []
+        for it in range(5):
+            src, tgt, gts, info = mc.seeded_inputs(256, 512, sample=it % 3)
+            out = tr.step(src.to(cuda), gts, info, tgt.to(cuda))
+            losses.append([float(out[k]) for k in ('loss', 'adloss', 'dis_patch_loss', 'recon_loss')])
+        torch.cuda.synchronize()
+        if name == "graph":
+            assert "graph" in tr._g12 and tr._g12["calls"] == 5
+        sd = tr.dis_patch.state_dict()
+        res[name] = dict(losses=losses, sums={k: (float(f.data.double().sum()), float(f.data.double().abs().sum())) for k, f in tr.flat.items()},
+                         bn={k: v.double().sum().item() for k, v in sd.items() if 'running' in k or 'num_batches' in k})
+    assert res["graph"]["losses"] == res["eager"]["losses"]
+    assert res["graph"]["sums"] == res["eager"]["sums"]
+    assert res["graph"]["bn"] == res["eager"]["bn"]
