@@ -16,16 +16,28 @@
  *     (oracle/build_ref.py; tests/golden/make_golden_nms.py -> nms_ref.npz:
  *     300 ... 12000 boxes, RPN-like / clustered / integer, thresholds .7/.5/.3,
  *     inputs tie-free at the threshold where ">=" and ">" part ways).
- *   RoIPool, RoIAlign, focal loss, the "+1/clamped" IoU: PARITY UNPINNED
- *     against a build of the reference.  Their sources cannot be built or run
- *     here: the .cu files need nvcc and the TH/THC headers torch 2.x no longer
- *     ships; roi_pooling.c uses the removed TH API; roi_pool_py.py indexes
- *     0-dim tensors and relies on torch<=0.3 `max` keeping the reduced
- *     dimension.  The reference holds no tests or vectors for them.  What they
- *     ARE checked against: independent second statements written from the
- *     operator definitions (tests/np_restate.py, float64 autograd closed forms:
- *     tests/test_oracle_golden.py), and their use inside the reference's own
- *     Python call sites run end to end on CPU (tests/golden/ref_harness.py).
+ *   RoIPool forward: BIT-EXACT against outputs of the reference's own pure-Python
+ *     RoIPool, extensions/_roi_pooling/modules/roi_pool_py.py:7-47, imported
+ *     UNMODIFIED (tests/golden/ref_harness.py adds the torch<=0.3 semantics it was
+ *     written for: identity .cuda(), `max(x, dim)` keeping the reduced dimension,
+ *     0.3-style row indexing).  tests/golden/make_golden_roipool.py ->
+ *     roi_pool_ref.npz: [1,512,32,64] x 512 RoIs (the hot path's call) and two
+ *     ragged shapes (two images, 3x5 pooling, RoIs outside the map, tied values).
+ *     The inputs (tests/roipool_cases.py) stay off the two points where that file
+ *     and roi_pooling_kernel.cu -- the canonical text -- are different operators:
+ *     scaled corners on an exact .5 (np.round is half-to-even, CUDA round() half
+ *     away from zero) and RoI extents of 29 / 57 / 58 cells (double vs float bin
+ *     edges); both have tests of their own against the kernel's text.  The argmax
+ *     and the backward are not part of roi_pool_py.py: argmax is checked through
+ *     the contract the values imply (features[argmax] == value, first maximum of
+ *     the bin in scan order, -1 <=> empty), the backward against the gather text
+ *     of roi_pooling_kernel.cu:128-203 restated twice (C gather, numpy scatter).
+ *   RoIAlign, focal loss, the "+1/clamped" IoU: PARITY UNPINNED against a build or a
+ *     run of the reference.  Their only sources are .cu files (nvcc + the TH/THC
+ *     headers torch 2.x no longer ships) and the reference holds no Python statement,
+ *     test or vector of them.  What they ARE checked against: independent second
+ *     statements written from the operator definitions (tests/np_restate.py,
+ *     float64 autograd closed forms: tests/test_oracle_golden.py).
  *
  * Build: gcc -O2 -ffp-contract=off -fno-fast-math -shared -fPIC (oracle/Makefile).
  * -ffp-contract=off is part of the definition: the canonical arithmetic of the

@@ -212,3 +212,69 @@ def import_reference_driver(argv):
     T.args = T.parser.parse_args(argv)
     ns.T = T
     return ns
+
+
+# ---------------------------------------------------------------------------
+# The reference's own pure-Python RoIPool (extensions/_roi_pooling/modules/roi_pool_py.py:7-47),
+# imported UNMODIFIED.  It is torch<=0.3 code; three harness-side legacy semantics make it run:
+#   * Tensor.cuda() -> identity (install_shims)
+#   * the module's `torch.max(x, dim)` keeps the reduced dimension, as torch<=0.3 did (:45-46
+#     reduce [C,h,w] over dim 1 and then over dim 2)
+#   * iterating `rois` yields rows whose integer index gives a 1-element tensor, so that
+#     `roi[0].data[0]` (:20) works as it did on 0.3 Variables
+# ---------------------------------------------------------------------------
+class _LegacyTorch:
+    """`torch` as the module sees it: everything forwarded, `max(x, dim)` with keepdim=True."""
+
+    def __init__(self, real):
+        self._real = real
+
+    def __getattr__(self, name):
+        return getattr(self._real, name)
+
+    def max(self, x, dim=None, *a, **k):
+        if dim is None:
+            return self._real.max(x)
+        return self._real.max(x, dim, keepdim=True)
+
+
+class _LegacyRow:
+    def __init__(self, t):
+        self.t = t
+
+    def __getitem__(self, i):
+        return self.t[i:i + 1] if isinstance(i, int) else self.t[i]
+
+
+class _LegacyRois:
+    """[R,5] tensor that iterates as torch 0.3 Variables did."""
+
+    def __init__(self, t):
+        self.t = t
+
+    def size(self):
+        return self.t.size()
+
+    def __iter__(self):
+        return (_LegacyRow(r) for r in self.t)
+
+
+def import_reference_roi_pool_py():
+    """Returns f(features[B,C,H,W], rois[R,5], ph, pw, scale) -> out[R,C,ph,pw] computed by the
+    reference's roi_pool_py.RoIPool.forward."""
+    if not os.path.isdir(REF):
+        raise RuntimeError(f"reference tree not found at {REF}")
+    install_shims()
+    import importlib.util
+    path = os.path.join(REF, "extensions", "_roi_pooling", "modules", "roi_pool_py.py")
+    spec = importlib.util.spec_from_file_location("_ref_roi_pool_py", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.torch = _LegacyTorch(torch)
+
+    def run(features, rois, ph, pw, scale):
+        m = mod.RoIPool(ph, pw, scale)
+        with torch.no_grad():
+            return m.forward(features, _LegacyRois(rois))
+
+    return run
