@@ -28,23 +28,22 @@ def _load_matching(model, state, what, allow_mismatch=False):
     error, as in the reference (`load_state_dict(strict=False)` raises on size mismatches, utils/load_helper.py:22), unless
     allow_mismatch=True (e.g. deliberately re-using a backbone under a head with another num_classes)."""
     own = model.state_dict()
-    used, skipped = [], []
-    with torch.no_grad():
-        for k, v in state.items():
-            if k in own and tuple(own[k].shape) == tuple(v.shape):
-                own[k].copy_(v.to(device=own[k].device, dtype=own[k].dtype))   # in place: flat-bucket views survive
-                used.append(k)
-            elif k in own:
-                skipped.append(k)
+    # first pass decides, second pass copies: a caller that catches the error keeps an untouched model (the parameters are views of
+    # the flat buckets -- a half-loaded bucket cannot be told from a loaded one afterwards)
+    used = [k for k, v in state.items() if k in own and tuple(own[k].shape) == tuple(v.shape)]
+    skipped = [k for k, v in state.items() if k in own and tuple(own[k].shape) != tuple(v.shape)]
     if skipped and not allow_mismatch:
         raise ValueError('%s: shape mismatch for %s (pass allow_mismatch=True to skip them)' % (
             what, ', '.join('%s %s vs %s' % (k, tuple(state[k].shape), tuple(own[k].shape)) for k in skipped[:8])))
+    assert used, 'load NONE from pretrained checkpoint'      # reference: utils/load_helper.py:17
+    with torch.no_grad():
+        for k in used:
+            own[k].copy_(state[k].to(device=own[k].device, dtype=own[k].dtype))   # in place: flat-bucket views survive
     if skipped:
         logger.warning('%s: skipped %d keys with mismatching shapes: %s', what, len(skipped), skipped)
     missing = [k for k in own if k not in state]
     logger.info('%s: used keys:%d missing keys:%d unused checkpoint keys:%d shape mismatches:%d',
                 what, len(used), len(missing), len(state) - len(used) - len(skipped), len(skipped))
-    assert used, 'load NONE from pretrained checkpoint'      # reference: utils/load_helper.py:17
     return used, missing
 
 
@@ -100,13 +99,13 @@ def save_checkpoint(trainer, path, epoch, best_recall=0.0, arch='vgg16_FasterRCN
     return ck
 
 
-def restore(trainer, path_or_state):
+def restore(trainer, path_or_state, allow_mismatch=False):
     """-> (epoch, best_recall, arch)"""
     ck = _read(path_or_state)
-    _load_matching(trainer.model, remove_prefix(ck['state_dict']), 'restore detector')
+    _load_matching(trainer.model, remove_prefix(ck['state_dict']), 'restore detector', allow_mismatch)
     for name, module in (('dec', trainer.dec), ('dis', trainer.dis), ('dis_patch', trainer.dis_patch)):
         if 'gan' in ck and name in ck['gan']:
-            _load_matching(module, ck['gan'][name], 'restore ' + name)
+            _load_matching(module, ck['gan'][name], 'restore ' + name, allow_mismatch)
     if isinstance(ck.get('optimizer'), dict) and 'exp_avg' in ck['optimizer']:
         _load_adam(trainer.opt['det'], ck['optimizer'])
     for name, st in ck.get('optimizers', {}).items():

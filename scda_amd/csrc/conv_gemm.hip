@@ -1631,6 +1631,8 @@ SCDA_API size_t scda_conv2d_workspace_bytes(int batch, int Cin, int IH, int IW, 
 SCDA_API int scda_conv2d_fwd_hip(const float *x, const float *w, const float *bias, float *y, int batch, int Cin, int IH,
                                  int IW, int Cout, int KH, int KW, int S, int P, int act, float slope, void *ws,
                                  size_t ws_bytes, void *stream) {
+    const int row_period = take_row_period("scda_conv2d_fwd_hip", IH, KH, KW, S, P);   // first: a rejected call must not leave it armed
+    if (row_period < 0) return SCDA_EINVAL;
     if (!x || !w || !y || batch <= 0 || Cin <= 0 || Cout <= 0) { set_error("scda_conv2d_fwd_hip: bad arguments"); return SCDA_EINVAL; }
     if (!zero_page()) { set_error("scda_conv2d_fwd_hip: could not allocate the zero page"); return SCDA_ELAUNCH; }
     const int OH = conv_out_dim(IH, KH, S, P), OW = conv_out_dim(IW, KW, S, P);
@@ -1641,7 +1643,7 @@ SCDA_API int scda_conv2d_fwd_hip(const float *x, const float *w, const float *bi
     g.dPHW = Div(OH * OW); g.dPW = Div(OW); g.dCB = Div(Cin);
     g.slab_aligned = (Cin % BK) == 0;
     g.zp = zero_page();
-    if ((g.row_period = take_row_period("scda_conv2d_fwd_hip", IH, KH, KW, S, P)) < 0) return SCDA_EINVAL;
+    g.row_period = row_period;
     Epi e{y, nullptr, bias, 0, act, slope, 1, 0, nullptr, 0.f};
     if (KH == 7 && KW == 7 && S == 2)   // the ResNet stem (3 -> 64, frozen in the reference: models/mask_rcnn/resnet.py:230-238): forward only
         return launch_conv<7, 7, 2, false>(w, x, g, e, (float *)ws, ws_bytes, as_stream(stream));
@@ -1659,6 +1661,8 @@ SCDA_API int scda_conv2d_dgrad_hip(const float *dy, const float *wt, float *dx, 
 SCDA_API int scda_conv2d_dgrad_act_hip(const float *dy, const float *wt, float *dx, int batch, int Cin, int IH, int IW,
                                        int Cout, int KH, int KW, int S, int P, const float *act_src, float act_slope,
                                        void *ws, size_t ws_bytes, void *stream) {
+    const int row_period = take_row_period("scda_conv2d_dgrad_hip", IH, KH, KW, S, P);   // first, as in the forward
+    if (row_period < 0) return SCDA_EINVAL;
     if (!dy || !wt || !dx || batch <= 0) { set_error("scda_conv2d_dgrad_hip: bad arguments"); return SCDA_EINVAL; }
     const int OH = conv_out_dim(IH, KH, S, P), OW = conv_out_dim(IW, KW, S, P);
     ConvGeom g;
@@ -1667,7 +1671,7 @@ SCDA_API int scda_conv2d_dgrad_act_hip(const float *dy, const float *wt, float *
     g.dPHW = Div(IH * IW); g.dPW = Div(IW); g.dCB = Div(Cout);
     g.slab_aligned = (Cout % BK) == 0;
     g.zp = zero_page();
-    if ((g.row_period = take_row_period("scda_conv2d_dgrad_hip", IH, KH, KW, S, P)) < 0) return SCDA_EINVAL;
+    g.row_period = row_period;
     if (!g.zp) { set_error("scda_conv2d_dgrad_hip: could not allocate the zero page"); return SCDA_ELAUNCH; }
     Epi e{dx, nullptr, nullptr, 0, (int)ACT_NONE, 0.f, 1, 0, act_src, act_slope};
     CONV_DISPATCH(launch_conv, , true > (wt, dy, g, e, (float *)ws, ws_bytes, as_stream(stream)))
@@ -1715,6 +1719,8 @@ SCDA_API int scda_conv2d_pack_weights_batched_hip(const float *base, float *out,
 SCDA_API int scda_conv2d_wgrad_hip(const float *dy, const float *x, float *dw, int batch, int Cin, int IH, int IW,
                                    int Cout, int KH, int KW, int S, int P, int accumulate, void *ws, size_t ws_bytes,
                                    void *stream) {
+    const int row_period = take_row_period("scda_conv2d_wgrad_hip", IH, KH, KW, S, P);   // first, as in the forward
+    if (row_period < 0) return SCDA_EINVAL;
     if (!dy || !x || !dw || !ws) { set_error("scda_conv2d_wgrad_hip: bad arguments"); return SCDA_EINVAL; }
     const int OH = conv_out_dim(IH, KH, S, P), OW = conv_out_dim(IW, KW, S, P);
     WgradGeom g;
@@ -1723,7 +1729,7 @@ SCDA_API int scda_conv2d_wgrad_hip(const float *dy, const float *x, float *dw, i
     g.dOHW = Div(OH * OW); g.dOW = Div(OW);
     g.a_vec4 = ((OH * OW) % 4) == 0 && (((uintptr_t)dy) & 15) == 0;
     g.zp = zero_page();
-    if ((g.row_period = take_row_period("scda_conv2d_wgrad_hip", IH, KH, KW, S, P)) < 0) return SCDA_EINVAL;
+    g.row_period = row_period;
     if (!g.zp) { set_error("scda_conv2d_wgrad_hip: could not allocate the zero page"); return SCDA_ELAUNCH; }
     CONV_DISPATCH(launch_wgrad, > (dy, x, g, dw, accumulate, (float *)ws, ws_bytes, as_stream(stream)))
 }
@@ -1736,6 +1742,8 @@ SCDA_API int scda_conv2d_wgrad_bias_fusable(int batch, int Cout, int OH, int OW,
 SCDA_API int scda_conv2d_wgrad_bias_hip(const float *dy, const float *x, float *dw, float *db, int batch, int Cin, int IH,
                                         int IW, int Cout, int KH, int KW, int S, int P, int accumulate, int db_accumulate,
                                         void *ws, size_t ws_bytes, void *stream) {
+    const int row_period = take_row_period("scda_conv2d_wgrad_bias_hip", IH, KH, KW, S, P);   // first, as in the forward
+    if (row_period < 0) return SCDA_EINVAL;
     if (!dy || !x || !dw || !db || !ws) { set_error("scda_conv2d_wgrad_bias_hip: bad arguments"); return SCDA_EINVAL; }
     const int OH = conv_out_dim(IH, KH, S, P), OW = conv_out_dim(IW, KW, S, P);
     WgradGeom g;
@@ -1744,7 +1752,7 @@ SCDA_API int scda_conv2d_wgrad_bias_hip(const float *dy, const float *x, float *
     g.dOHW = Div(OH * OW); g.dOW = Div(OW);
     g.a_vec4 = ((OH * OW) % 4) == 0 && (((uintptr_t)dy) & 15) == 0;
     g.zp = zero_page();
-    if ((g.row_period = take_row_period("scda_conv2d_wgrad_bias_hip", IH, KH, KW, S, P)) < 0) return SCDA_EINVAL;
+    g.row_period = row_period;
     if (!g.zp) { set_error("scda_conv2d_wgrad_bias_hip: could not allocate the zero page"); return SCDA_ELAUNCH; }
     CONV_DISPATCH(launch_wgrad, > (dy, x, g, dw, accumulate, (float *)ws, ws_bytes, as_stream(stream), db, db_accumulate))
 }

@@ -47,6 +47,8 @@ def average_gradients(model, async_op=False):
 
 def broadcast_params(model):
     """rank 0's parameters and buffers to everyone"""
+    from scda_amd.layers import flush_counters
+    flush_counters(model)              # BatchNorm batch counters are kept on the host between reads of the buffer
     flat = _flat_of(model)
     if flat is not None:
         dist.broadcast(flat.data, 0)
@@ -85,9 +87,12 @@ def dist_init(port, backend='nccl'):
         # (utils/distributed_utils.py:27-35); never let every node rendezvous with itself.
         nnodes = int(os.environ.get('SLURM_NNODES', os.environ.get('SLURM_JOB_NUM_NODES', 1)))
         if 'SLURM_PROCID' in os.environ and nnodes > 1:
-            addr = os.environ.get('SLURM_LAUNCH_NODE_IPADDR') or _first_slurm_host(os.environ.get('SLURM_NODELIST', ''))
+            # rank 0 (SLURM_PROCID 0) runs on the FIRST host of the step's node list.  SLURM_LAUNCH_NODE_IPADDR is where `srun` was
+            # typed -- a login node when the job is started as the reference's scripts do (`srun -p ...` from the front end,
+            # examples/faster-rcnn/cityscapes/vgg/4cluster.sh:13) -- and nobody listens there.
+            addr = _first_slurm_host(os.environ.get('SLURM_STEP_NODELIST') or os.environ.get('SLURM_NODELIST', ''))
             if not addr:
-                raise RuntimeError('dist_init: %d SLURM nodes but neither MASTER_ADDR, SLURM_LAUNCH_NODE_IPADDR nor a usable '
+                raise RuntimeError('dist_init: %d SLURM nodes but neither MASTER_ADDR nor a usable SLURM_STEP_NODELIST / '
                                    'SLURM_NODELIST is set' % nnodes)
             os.environ['MASTER_ADDR'] = addr
         else:

@@ -70,6 +70,7 @@ class FlatParams:
                     view.copy_(p.grad)     # accumulate into the bucket while p.grad IS the view): it replaces the stale slice
                 else:
                     view.zero_()
+                self.fresh.discard(id(p))  # the slice has just been written as a whole: finalize_grads() must not zero-fill it
                 p.grad = view
 
     def take_fresh(self, p):

@@ -193,6 +193,8 @@ class BatchNorm2d(nn.BatchNorm2d):
                 raise NotImplementedError("scda_amd.BatchNorm2d: eval mode without running statistics")
             return A.BatchNormEvalFn.apply(x, self.weight.detach(), self.bias.detach(), self.running_mean, self.running_var,
                                            self.eps, self.fused_act, self.slope)
+        if self.momentum is None:   # cumulative moving average: needs the counter on the device at every call; no SCDA net uses it
+            raise NotImplementedError("scda_amd.BatchNorm2d: momentum=None (cumulative average) is not implemented")
         if self.num_batches_tracked is not None:
             self._nbt_pending = getattr(self, "_nbt_pending", 0) + 1    # counted on the host, written into the buffer when it is read
         if A.replay is not None and self.fused_act != A.ACT_NONE:   # parity tests: see InstanceNorm2d
@@ -220,8 +222,22 @@ def _bn_save(self, destination, prefix, keep_vars):
     return nn.BatchNorm2d._save_to_state_dict(self, destination, prefix, keep_vars)
 
 
+def _bn_load(self, *args, **kw):
+    self._nbt_pending = 0       # the loaded counter replaces everything counted so far, pending increments included
+    return nn.BatchNorm2d._load_from_state_dict(self, *args, **kw)
+
+
 BatchNorm2d._save_to_state_dict = _bn_save
 BatchNorm2d.state_dict = _bn_state_dict
+BatchNorm2d._load_from_state_dict = _bn_load
+
+
+def flush_counters(module):
+    """write the host-side batch counters of every BatchNorm2d below `module` into their `num_batches_tracked` buffers: call before
+    reading those buffers directly (state_dict() does it by itself; broadcast_params() calls this)"""
+    for m in module.modules():
+        if isinstance(m, BatchNorm2d):
+            _flush_nbt(m)
 
 
 class Upsample2x(nn.Module):

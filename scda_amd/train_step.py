@@ -105,6 +105,20 @@ class _Frozen:
             p.requires_grad_(True)
 
 
+def active_test_hooks(fail=False):
+    """The parity tests steer three module-level hooks of the product path (selection replay in scda_amd.autograd_ops, the RPN-output
+    hand-over in dropin.functions.rpn_proposal, injected dropout masks in scda_amd.layers).  -> names of those that are set.  A
+    trainer refuses to start with a stale one (left behind by an earlier user of the process) unless SCDA_ALLOW_TEST_HOOKS=1
+    (tests/conftest.py sets it and checks after every test that none is left behind)."""
+    from . import layers as L
+    from .dropin.functions import rpn_proposal
+    on = [n for n, v in (("scda_amd.autograd_ops.replay", A.replay), ("dropin.functions.rpn_proposal.rpn_output_hook",
+                         rpn_proposal.rpn_output_hook), ("scda_amd.layers.Dropout.mask_source", L.Dropout.mask_source)) if v is not None]
+    if on and fail:
+        raise RuntimeError("test hooks are installed in the product path: %s (set SCDA_ALLOW_TEST_HOOKS=1 if that is intended)" % ", ".join(on))
+    return on
+
+
 class ScdaTrainer:
     def __init__(self, cfg, device, lr=1.25e-5, cluster_num=4, threshold=128, recon_size=256, new_w=1024, new_h=512,
                  weight_decay=1e-4, world_size=1, models=None, recon_hw=None, reference_style=False, collectives=None):
@@ -118,6 +132,7 @@ class ScdaTrainer:
         collectives: issue the four per-phase all-reduces (default: world_size > 1).  True with a one-rank process group runs
         the whole RCCL path -- async all-reduce on the device buckets, waits, stream hand-over -- on a single GPU
         (tests/test_distributed_gpu.py::test_rccl_one_rank_group_matches_plain_step)."""
+        active_test_hooks(fail=os.environ.get("SCDA_ALLOW_TEST_HOOKS") != "1")
         self.cfg, self.device = cfg, device
         self.collectives = (world_size > 1) if collectives is None else bool(collectives)
         from .hostenv import configure_host_threads

@@ -8,6 +8,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+os.environ["SCDA_ALLOW_TEST_HOOKS"] = "1"     # the parity tests steer the product path's three test hooks (train_step.active_test_hooks)
 
 
 def pytest_configure(config):
@@ -25,3 +26,13 @@ def cuda():
     if not torch.cuda.is_available():
         pytest.fail("GPU test selected but no HIP device is visible (tests never fall back to CPU)")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def no_test_hook_left_behind():
+    """a hook one test forgets to clear would silently change every later test of the process"""
+    yield
+    import sys
+    if "scda_amd.train_step" in sys.modules:
+        left = sys.modules["scda_amd.train_step"].active_test_hooks()
+        assert not left, "test left product-path hooks installed: %s" % left

@@ -13,11 +13,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def test_bench_two_ranks(cuda):
+@pytest.mark.parametrize("how", ["torchrun", "plain"])
+def test_bench_two_ranks(cuda, how):
+    """`torchrun`: as the driver's documented N > 1 command.  `plain`: `python bench.py --gpus 2` by itself -- bench.py then starts
+    its own ranks (one process per GPU, as the reference's launcher does)."""
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, SCDA_BENCH_DEVICE="0", SCDA_BENCH_BACKEND="gloo")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2"]
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2"]
+    if how == "torchrun":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port)] + tail
+    else:
+        cmd = [sys.executable] + tail
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -27,3 +36,4 @@ def test_bench_two_ranks(cuda):
     assert d["config"]["parallelism"] == "dp2" and "cpu_baseline" not in d
     assert abs(d["value"] - 2 * 2 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-3      # whole-job images/s
     assert d["roofline"]["launches"] > 0
+    assert d["collective"]["ranks"] == 2 and d["collective"]["backend"] == "gloo"

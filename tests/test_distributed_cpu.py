@@ -130,7 +130,16 @@ def test_slurm_master_address_is_not_loopback_on_several_nodes(monkeypatch):
         monkeypatch.delenv(k, raising=False)
     assert D.dist_init("23456", backend="gloo") == (3, 16)
     assert os.environ["MASTER_ADDR"] == "cn07" and os.environ["MASTER_PORT"] == "23456" and seen["world_size"] == 16
+    # started as the reference's scripts do -- `srun` typed on a login node (4cluster.sh:13): SLURM_LAUNCH_NODE_IPADDR is THAT host, where
+    # no rank runs.  The rendezvous must go to the first host of the step (where SLURM_PROCID 0 is), as the reference derives it.
     monkeypatch.delenv("MASTER_ADDR")
+    monkeypatch.setenv("SLURM_LAUNCH_NODE_IPADDR", "10.0.0.250")
+    assert D.dist_init("23456", backend="gloo") == (3, 16) and os.environ["MASTER_ADDR"] == "cn07"
+    monkeypatch.delenv("MASTER_ADDR")
+    monkeypatch.setenv("SLURM_STEP_NODELIST", "cn08")           # a step on a subset of the allocation: its own list wins
+    assert D.dist_init("23456", backend="gloo") == (3, 16) and os.environ["MASTER_ADDR"] == "cn08"
+    monkeypatch.delenv("MASTER_ADDR")
+    monkeypatch.delenv("SLURM_STEP_NODELIST")
     monkeypatch.setenv("SLURM_NODELIST", "")
     with pytest.raises(RuntimeError):
         D.dist_init("23456", backend="gloo")

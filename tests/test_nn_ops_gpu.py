@@ -378,3 +378,14 @@ def test_lazily_zeroed_dense_gradients(cuda):
         ref = lambda x: F.linear(F.linear(x, w, b), w2, b2)  # noqa: E731
         (ref(x1).square().sum() + ref(x2).sum()).backward()
         close(net[0].weight.grad, w.grad, 2e-5); close(net[1].weight.grad, w2.grad, 2e-5); close(net[0].bias.grad, b.grad, 2e-5)
+    # zero_grad() on the bucket, then Module.zero_grad() (set_to_none) on top: autograd now builds the big weight's gradient OUTSIDE the
+    # bucket (LinearFn has no sink, the `fresh` token is never taken); check_aliases() copies it in -- and finalize_grads() must not wipe
+    # the slice it has just filled (it did: FC6 / FC7 would have trained on weight decay alone)
+    flat.zero_grad()
+    net.zero_grad(set_to_none=True)
+    assert net[0].weight.grad is None and flat.fresh
+    net(x1).square().sum().backward()
+    outside = net[0].weight.grad.clone()
+    flat.check_aliases(); flat.finalize_grads()
+    assert flat._inside(net[0].weight.grad, flat.grad) and not flat.fresh
+    assert float(outside.abs().sum()) > 0 and torch.equal(net[0].weight.grad, outside)
