@@ -1,0 +1,149 @@
+"""mAP parity -- the north_star's acceptance line "mAP within +-0.3 of reference" (BASELINE.md section 1), on a detector that
+actually detects.
+
+A VGG16 Faster-R-CNN (+ the SCDA nets, the whole 4-phase iteration) is trained ON THE DEVICE on a handful of synthetic 256x512
+images (coloured rectangles, colour = class) until its mAP@0.5 on them is far from trivial; the SAME checkpoint is then evaluated
+  (a) by the CPU oracle detector (oracle/torch_ref.py RefDetector: torch-CPU convolutions, the C restatements of NMS / RoIPool /
+      IoU -- the oracle that reproduces the reference's own train() and validate_single() outputs, tests/test_oracle_model.py,
+      tests/test_eval_path.py), and
+  (b) by the HIP detector,
+both through the same validate() loop (tools/faster_rcnn_train_val.py:773-884) and utils.cal_mAP (:95-171).  Asserted: both
+mAPs non-trivial, |mAP_hip - mAP_oracle| <= 0.3 points, equal numbers of result rows.
+
+Run by hand to see the numbers / tune:  python tests/test_map_parity_gpu.py [iterations] [lr]"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+from test_host_functions import CFG  # noqa: E402
+
+H, W, N_IMG, PER_IMG = 256, 512, 8, 3
+PALETTE = np.array([[a, b, c] for a in (-0.9, 0.9) for b in (-0.9, 0.9) for c in (-0.9, 0.9)], np.float32)   # class k+1 -> colour k
+
+
+def make_dataset(seed=7):
+    """N_IMG images [1,3,H,W] in [-1,1]: faint noise + PER_IMG non-overlapping filled rectangles whose colour IS the class (1..8);
+    every class occurs three times.  -> images, gts [1,PER_IMG,5] (x1,y1,x2,y2,class; integer corners), names"""
+    rs = np.random.RandomState(seed)
+    classes = np.concatenate([rs.permutation(8) + 1 for _ in range(N_IMG * PER_IMG // 8)])
+    images, gts, names = [], [], []
+    for i in range(N_IMG):
+        img = (0.05 * rs.standard_normal((3, H, W))).astype(np.float32)
+        boxes = []
+        while len(boxes) < PER_IMG:
+            w, h = rs.randint(56, 150), rs.randint(48, 110)
+            x1, y1 = rs.randint(4, W - w - 4), rs.randint(4, H - h - 4)
+            if any(not (x1 > b[2] + 8 or x1 + w < b[0] - 8 or y1 > b[3] + 8 or y1 + h < b[1] - 8) for b in boxes):
+                continue
+            c = int(classes[i * PER_IMG + len(boxes)])
+            img[:, y1:y1 + h + 1, x1:x1 + w + 1] = PALETTE[c - 1][:, None, None] + 0.05 * rs.standard_normal((3, h + 1, w + 1))
+            boxes.append([x1, y1, x1 + w, y1 + h, c])
+        images.append(torch.from_numpy(np.clip(img, -1, 1))[None])
+        gts.append(torch.tensor(boxes, dtype=torch.float32)[None])
+        names.append("synth_%06d_leftImg8bit" % i)
+    return images, gts, names
+
+
+def meta_lines(names, gts):
+    """the val meta list parse_gts() reads (utils/cal_mAP.py:16-47)"""
+    out = []
+    for i, (n, g) in enumerate(zip(names, gts)):
+        g = g[0].numpy()
+        out += ["# %d\n" % i, "val/city/%s.png\n" % n, "3\n", "%d\n" % H, "%d\n" % W, "0\n", "0\n", "%d\n" % len(g)]
+        out += ["%d %d %d %d %d\n" % (b[4], b[0], b[1], b[2], b[3]) for b in g]
+    return out
+
+
+def loader(images, gts, names, device=None):
+    info = torch.tensor([[H, W, 1.0]])
+    return [(img if device is None else img.to(device), info.clone(), g.clone(), ["leftImg8bit/val/city/%s.png" % n])
+            for img, g, n in zip(images, gts, names)]
+
+
+def train_on_device(cuda, images, gts, iters, lr):
+    from scda_amd.train_step import ScdaTrainer
+    torch.manual_seed(3)
+    np.random.seed(3)
+    tr = ScdaTrainer(CFG, cuda, lr=lr, new_w=W, new_h=H)
+    info = torch.tensor([[H, W, 1.0]])
+    dev_imgs = [im.to(cuda) for im in images]
+    hist = []
+    for it in range(iters):
+        k = it % N_IMG
+        out = tr.step(dev_imgs[k], gts[k], info, dev_imgs[(k + 3) % N_IMG])     # another image of the set plays the target domain
+        if it % 50 == 49 or it == iters - 1:
+            hist.append((it + 1, float(out['rpn_cls']), float(out['rpn_loc']), float(out['rcnn_cls']), float(out['rcnn_loc']),
+                         float(out['rcnn_acc'])))
+    return tr, hist
+
+
+def score(results_dir, meta_file):
+    from scda_amd.dropin.utils import cal_mAP as C
+    import contextlib
+    import io
+    with np.errstate(all="ignore"), contextlib.redirect_stdout(io.StringIO()):
+        m = C.Cal_MAP(results_dir, meta_file, 9)
+    rows = open(os.path.join(results_dir, "results.txt")).read().splitlines()
+    return 100.0 * float(m), rows
+
+
+def run(cuda, workdir, iters=400, lr=1e-4, verbose=False):
+    from oracle import torch_ref as R
+    from scda_amd.evaluate import validate
+    images, gts, names = make_dataset()
+    meta = os.path.join(workdir, "val_meta.txt")
+    with open(meta, "w") as f:
+        f.writelines(meta_lines(names, gts))
+    tr, hist = train_on_device(cuda, images, gts, iters, lr)
+    if verbose:
+        for h in hist:
+            print("iter %4d  rpn_cls %.4f rpn_loc %.4f rcnn_cls %.4f rcnn_loc %.4f rcnn_acc %.1f" % h)
+    state = {k: v.detach().cpu().clone() for k, v in tr.model.state_dict().items()}          # THE checkpoint both sides evaluate
+    # (b) HIP detector
+    d_hip = os.path.join(workdir, "hip")
+    rc_hip = validate(loader(images, gts, names), tr.model, CFG, d_hip, score=False)
+    map_hip, rows_hip = score(d_hip, meta)
+    # (a) CPU oracle detector, same weights
+    torch.manual_seed(1)
+    ref = R.build_models(CFG)[0]
+    missing = ref.load_state_dict(state, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    d_ref = os.path.join(workdir, "oracle")
+    R.use_cpu_backend()
+    try:
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+        rc_ref = validate(loader(images, gts, names), ref, CFG, d_ref, score=False)
+    finally:
+        R.reset_backend()
+        torch.set_num_threads(1)
+    map_ref, rows_ref = score(d_ref, meta)
+    return dict(map_hip=map_hip, map_ref=map_ref, rows_hip=len(rows_hip), rows_ref=len(rows_ref), recall_hip=rc_hip, recall_ref=rc_ref,
+                hist=hist)
+
+
+@pytest.mark.gpu
+def test_map_of_one_checkpoint_hip_vs_oracle(cuda, tmp_path):
+    r = run(cuda, str(tmp_path))
+    print("mAP@0.5 of the same checkpoint: HIP detector %.3f, CPU oracle detector %.3f (rows %d / %d, RPN recall %.3f / %.3f)"
+          % (r["map_hip"], r["map_ref"], r["rows_hip"], r["rows_ref"], r["recall_hip"], r["recall_ref"]))
+    assert r["map_ref"] > 30.0 and r["map_hip"] > 30.0, r          # a detector that detects: the comparison is not 0 == 0
+    assert abs(r["map_hip"] - r["map_ref"]) <= 0.3, r              # north_star: within +-0.3 mAP points
+    assert r["rows_hip"] == r["rows_ref"], r
+    assert abs(r["recall_hip"] - r["recall_ref"]) <= 1.0 / (N_IMG * PER_IMG) + 1e-9, r
+
+
+if __name__ == "__main__":
+    import tempfile
+    os.environ.setdefault("SCDA_ALLOW_TEST_HOOKS", "1")
+    it = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+    lr = float(sys.argv[2]) if len(sys.argv) > 2 else 1e-4
+    with tempfile.TemporaryDirectory() as d:
+        r = run(torch.device("cuda:0"), d, it, lr, verbose=True)
+    print({k: v for k, v in r.items() if k != "hist"})
