@@ -22,7 +22,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
-from test_host_functions import CFG  # noqa: E402
+import copy  # noqa: E402
+from test_host_functions import CFG as _CFG  # noqa: E402
+
+CFG = copy.deepcopy(_CFG)
+for _k in CFG:
+    CFG[_k]['gan_model_flag'] = 2
 
 H, W, N_IMG, PER_IMG = 256, 512, 8, 3
 PALETTE = np.array([[a, b, c] for a in (-0.9, 0.9) for b in (-0.9, 0.9) for c in (-0.9, 0.9)], np.float32)   # class k+1 -> colour k
