@@ -1,0 +1,130 @@
+"""ResNet-50 C4 detector (BASELINE.json configs[3]) against its CPU oracle (oracle/resnet_ref.py: plain torch-CPU convolutions /
+batch norms / autograd + the C RoIAlign), whole detector: the four losses and the gradient of every trainable tensor.
+
+The oracle records which element it selected at every ReLU (tests/model_common.ReplaySource, as the VGG iteration test does) and
+its RPN outputs are handed to the proposal ranking after checking that the device agrees to 1e-5 -- what is compared is then the
+kernels' arithmetic on identical RoIs: losses 1e-4, gradients 1e-4 relative L2 per tensor, batch-norm running statistics 1e-5.
+Plus one full SCDA iteration at the configuration's own size, 800 x 1344."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+import model_common as mc      # puts tests/golden on the path (seeded_init)
+
+pytestmark = pytest.mark.gpu
+
+CFG = copy.deepcopy(mc.CFG)
+for _k in CFG:
+    CFG[_k].update(gan_model_flag=2, roi_align=True)
+
+
+def rel_l2(a, b):
+    a = a.detach().double().cpu(); b = b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.mark.parametrize("H,W,G", [(256, 384, 4)])
+def test_resnet_detector_losses_and_gradients_match_oracle(cuda, H, W, G):
+    from oracle import resnet_ref as RR, torch_ref as R
+    from scda_amd import autograd_ops as A
+    from scda_amd.dropin.functions import rpn_proposal
+    from scda_amd.dropin.models.mask_rcnn.resnet import resnet50
+    import seeded_init
+    torch.manual_seed(1)
+    ref = RR.RefResNetDetector(dict(CFG['shared']))
+    seeded_init.seeded_reinit(ref, 51, 'det')
+    ref.train()
+    src, tgt = seeded_init.synth_images(61, H, W)
+    gts = seeded_init.synth_gts(G, 62, H, W)
+    info = torch.tensor([[H, W, 1.0]])
+
+    def inputs(dev=None):
+        return {'cfg': CFG, 'image': src if dev is None else src.to(dev), 'image_info': info, 'ground_truth_bboxes': gts,
+                'ignore_regions': None, 'cluster_num': 4, 'threshold': 128}
+
+    # ---- oracle, CPU
+    rec = R.SelectionRecorder()
+    handles = rec.attach(ref)
+
+    def record_rpn(cls, loc):
+        rec.add("rpn_cls", cls, cls.detach().clone())
+        rec.add("rpn_loc", loc, loc.detach().clone())
+        return cls, loc
+    R.use_cpu_backend()
+    rpn_proposal.rpn_output_hook = record_rpn
+    try:
+        np.random.seed(7)
+        torch.set_num_threads(16)
+        want = ref(inputs(), tgt)
+        sum(want['losses']).backward()
+    finally:
+        rpn_proposal.rpn_output_hook = None
+        rec.detach(handles)
+        R.reset_backend()
+        torch.set_num_threads(1)
+    before = {k: v.clone() for k, v in ref.state_dict().items()}
+
+    # ---- product, device: same weights (the oracle's state BEFORE its forward updated the BN statistics is gone: re-draw)
+    det = resnet50(cfg=dict(CFG['shared']))
+    seeded_init.seeded_reinit(det, 51, 'det')
+    det = det.to(cuda).train()
+    A.replay = mc.ReplaySource(rec, cuda)
+    rpn_proposal.rpn_output_hook = A.replay.rpn
+    try:
+        np.random.seed(7)
+        got = det(inputs(cuda), tgt.to(cuda))
+        sum(got['losses']).backward()
+        torch.cuda.synchronize()
+        used = A.replay.used
+    finally:
+        A.replay = None
+        rpn_proposal.rpn_output_hook = None
+    assert used >= 30, used
+    for name, a, b in zip(("rpn_cls", "rpn_loc", "rcnn_cls", "rcnn_loc"), got['losses'], want['losses']):
+        assert abs(float(a) - float(b)) <= 1e-4 * max(1.0, abs(float(b))), (name, float(a), float(b))
+    rp = dict(ref.named_parameters())
+    worst, n = ("", 0.0), 0
+    for k, p in det.named_parameters():
+        if not p.requires_grad:
+            assert rp[k].grad is None and p.grad is None, k          # stem + layer1 frozen on both sides
+            continue
+        e = rel_l2(p.grad, rp[k].grad)
+        n += 1
+        if e > worst[1]:
+            worst = (k, e)
+    assert n > 100 and worst[1] <= 1e-4, worst
+    sd = det.state_dict()
+    for k, v in before.items():
+        if k.endswith(("running_mean", "running_var")):
+            d = float((sd[k].cpu() - v).abs().max() / (v.abs().max() + 1e-12))
+            assert d <= 1e-5, (k, d)
+        if k.endswith("num_batches_tracked"):
+            assert int(sd[k]) == int(v), k
+    assert int(sd['layer1.0.bn1.num_batches_tracked']) == 0 and int(sd['layer2.0.bn1.num_batches_tracked']) == 2
+
+
+def test_resnet50_scda_iteration_at_800x1344(cuda):
+    """BASELINE.json configs[3]'s own size: one full SCDA iteration (detector + decoders + discriminators, four optimiser steps) on
+    800 x 1344 -- finite losses, the RoI quota is reached on both images (512 sampled RoIs need >= 512 proposals from the target
+    image, else the reference's fallback reuses the source clusters), trainable layers move, the frozen stem / layer1 do not."""
+    import bench
+    from scda_amd import resnet_config as RC
+    torch.manual_seed(0); np.random.seed(0)
+    tr = RC.make_trainer(bench.CFG, cuda, lr=1e-4)
+    det = tr.model
+    before = {k: v.clone() for k, v in det.state_dict().items()}
+    src, tgt, gts, info = bench.synth_batch(0, RC.H, RC.W)
+    out = tr.step(src.to(cuda), gts, info, tgt.to(cuda))
+    torch.cuda.synchronize()
+    for k in ('loss', 'rpn_cls', 'rpn_loc', 'rcnn_cls', 'rcnn_loc', 'adloss', 'dis_patch_loss', 'recon_loss', 'fake_loss_source',
+              'fake_loss_target'):
+        assert np.isfinite(float(out[k])), k
+    assert min(tr.last_num_proposals) >= 512, tr.last_num_proposals
+    after = det.state_dict()
+    moved = [k for k in before if before[k].dtype.is_floating_point and not torch.equal(before[k], after[k])]
+    assert all(any(k.startswith(p) for k in moved) for p in ('layer2.', 'layer3.', 'layer4.', 'rpn_head.', 'fc_rcnn_cls.', 'fc_rcnn_loc.'))
+    assert not [k for k in moved if k.startswith(('conv1.', 'bn1.', 'layer1.'))]
+    assert int(after['layer3.5.bn3.num_batches_tracked']) == 2 and int(after['layer4.2.bn3.num_batches_tracked']) == 2
+    assert int(after['layer1.0.bn1.num_batches_tracked']) == 0
