@@ -182,10 +182,12 @@ size_t scda_conv2d_workspace_bytes(int batch, int Cin, int IH, int IW, int Cout,
 size_t scda_conv2d_packed_elems(int Cout, int Cin, int KH, int KW, int for_dgrad);
 int scda_conv2d_pack_weight_hip(const float *w, float *out, int Cout, int Cin, int KH, int KW, int for_dgrad,
                                 void *stream);
-/* The same packing for MANY weights in one launch (all conv layers of an optimiser group, right after its Adam step):
- * desc = n rows of 6 int64 {source offset in floats from `base`, destination offset in floats from `out`, Cout, Cin,
- * KH*KW, for_dgrad}, destinations ascending, back to back, total = their summed scda_conv2d_packed_elems(). */
-int scda_conv2d_pack_weights_batched_hip(const float *base, float *out, const long long *desc, int n, long long total,
+/* The same packing for MANY weights in one launch (all conv layers of an optimiser group, right after its Adam step), one
+ * workgroup per tile, both sides coalesced through LDS: desc = n rows of 7 int64 {source offset in floats from `base`, destination
+ * offset in floats from `out`, Cout, Cin, KH*KW, for_dgrad, first tile id}, destinations ascending and back to back, tile ids
+ * consecutive: a row owns scda_conv2d_pack_tiles(...) of them; n_tiles = their sum. */
+long long scda_conv2d_pack_tiles(int Cout, int Cin, int KH, int KW, int for_dgrad);
+int scda_conv2d_pack_weights_batched_hip(const float *base, float *out, const long long *desc, int n, long long n_tiles,
                                          void *stream);
 /* wp = pack(w, 0) */
 int scda_conv2d_fwd_hip(const float *x, const float *wp, const float *bias /*[Cout] or NULL*/, float *y, int batch,

@@ -305,10 +305,14 @@ struct GldsOperand {
 // workgroup went through the ~55-instruction staging phase at the same time (the per-slab barrier keeps them in step) and the
 // matrix pipe sat idle for its length; now that phase runs underneath the other waves' MFMAs.  NP is chosen so that two
 // slabs of one staging wave's loads fit the 6-bit vmcnt counter (2 L <= 63).
+// The 32 x 256 tile (layers with <= 32 output rows: the decoders' 64 -> 32 stage, the data gradient into a 32-channel map): 1 x 4
+// compute waves of 32 x 64 -- on a 64-row tile half of every MFMA of such a layer multiplies padding.  Its weight tile is two
+// LDS-DMA instructions per slab, fewer than the four staging waves its 64 pixel-row pieces need: staging wave 0 issues both
+// (A_P0), so the waves' instruction counts differ and each waits on its own count.
 template <int BM, int BN>
 struct ConvGldsCfg {
     static constexpr int NWC = BM == 256 ? 8 : 4;                    // compute waves
-    static constexpr int WGN = BN == 256 ? 4 : 2, WGM = NWC / WGN;   // ... along N / M
+    static constexpr int WGN = BM == 32 ? 4 : BN == 256 ? 4 : 2, WGM = NWC / WGN;   // ... along N / M
     static constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
     static constexpr int A_LPR = BM / 4;            // lanes per weight row (dwordx4 each)
     static constexpr int A_RPI = 64 / A_LPR;        // rows per wave-instruction
@@ -316,10 +320,12 @@ struct ConvGldsCfg {
     static constexpr int HALVES = BN / 64;          // 64-pixel pieces per B row
     static constexpr int L_TOTAL = A_TOTAL + BK * HALVES;
     static constexpr int NP = L_TOTAL <= 31 ? 1 : L_TOTAL <= 62 ? 2 : 4;   // staging waves
-    static constexpr int A_PP = A_TOTAL / NP, ROWS_PP = BK / NP;    // per staging wave: A instructions, B rows
-    static constexpr int L = A_PP + ROWS_PP * HALVES;               // LDS-DMA instructions per staging wave per slab
+    static constexpr bool A_P0 = (A_TOTAL % NP) != 0;               // the weight tile is staged by staging wave 0 alone
+    static constexpr int A_PP = A_P0 ? A_TOTAL : A_TOTAL / NP, ROWS_PP = BK / NP;    // per staging wave: A instructions, B rows
+    static constexpr int LB = ROWS_PP * HALVES;                     // pixel-operand LDS-DMA instructions per staging wave per slab
+    static constexpr int L = A_PP + LB;                             // ... all of them (with A_P0: staging wave 0's count)
     static constexpr int THREADS = (NWC + NP) * 64;
-    static_assert(A_TOTAL % NP == 0 && BK % NP == 0 && 2 * L <= 63, "staging split");
+    static_assert(BK % NP == 0 && 2 * L <= 63 && WM >= 32 && WN >= 32, "staging split");
 };
 
 template <int BM, int BN, int KH, int KW, int S, bool DGRAD>
@@ -379,14 +385,17 @@ __global__ __launch_bounds__((ConvGldsCfg<BM, BN>::THREADS)) void conv_igemm_gld
         }
         // A: a lane's 4 consecutive output channels of row i*A_RPI + lane/A_LPR of the slab
         const unsigned a_voff = (unsigned)(((lane / A_LPR) * g.mpad + (lane % A_LPR) * 4) * 4);
-        const char *wbase = reinterpret_cast<const char *>(Wt + (size_t)(p * C::A_PP * A_RPI) * g.mpad + m0);
+        const int a_first = C::A_P0 ? 0 : p * C::A_PP * A_RPI;     // first weight row of the slab this wave stages
+        const char *wbase = reinterpret_cast<const char *>(Wt + (size_t)a_first * g.mpad + m0);
 
         auto issue = [&](int s, int buf) {
-            float *Ab = lds + buf * STAGE + (p * C::A_PP * A_RPI) * BM;
+            float *Ab = lds + buf * STAGE + a_first * BM;
             float *Bb = lds + buf * STAGE + BK * BM + (p * C::ROWS_PP) * BN;
             const char *wa = wbase + (size_t)s * BK * g.mpad * 4;
+            if (!C::A_P0 || p == 0) {
 #pragma unroll
-            for (int i = 0; i < C::A_PP; ++i) buffer_load_lds_b128(wa, a_voff, Ab + i * A_RPI * BM, i * A_RPI * g.mpad * 4);
+                for (int i = 0; i < C::A_PP; ++i) buffer_load_lds_b128(wa, a_voff, Ab + i * A_RPI * BM, i * A_RPI * g.mpad * 4);
+            }
             const int cb = s / (KH * KW), r = s - cb * (KH * KW);
             const int kh = r / KW, kw = r - kh * KW;
             const char *xs = xbase + (size_t)cb * BK * plane * 4;
@@ -412,9 +421,9 @@ __global__ __launch_bounds__((ConvGldsCfg<BM, BN>::THREADS)) void conv_igemm_gld
             // with it.  Then wait until slab s (two slabs back in this wave's queue) has landed, and release it.
             if (s + 2 < s_end) {
                 issue(s + 2, nbuf);
-                SCDA_WAIT_VMCNT(2 * L);
+                if (C::A_P0 && p != 0) SCDA_WAIT_VMCNT(2 * C::LB); else SCDA_WAIT_VMCNT(2 * L);
             } else if (s + 1 < s_end) {
-                SCDA_WAIT_VMCNT(L);
+                if (C::A_P0 && p != 0) SCDA_WAIT_VMCNT(C::LB); else SCDA_WAIT_VMCNT(L);
             } else {
                 SCDA_WAIT_VMCNT(0);
             }
@@ -1317,19 +1326,78 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float *__restric
         out[idx] = packed_weight_elem(w, idx, Cout, Cin, R, for_dgrad);
 }
 
-__global__ __launch_bounds__(256) void pack_weights_batched_kernel(const float *__restrict__ base, float *__restrict__ out,
-                                                                   const long long *__restrict__ desc, const int n,
-                                                                   const long long total) {
-    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
-         idx += (long long)blockDim.x * gridDim.x) {
-        int lo = 0, hi = n - 1;   // last descriptor whose destination offset is <= idx
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (desc[mid * 6 + 1] <= idx) lo = mid; else hi = mid - 1;
+// One workgroup = one tile of one layer.  desc[j] = {source offset (floats, from `base`), destination offset (floats, from `out`),
+// Cout, Cin, R, for_dgrad, first tile id of this layer}; the layers' tiles are numbered consecutively.
+//   blocked layers (C % 16 == 0, R <= 9): tile = 64 packed columns (m) x one 16-channel block (16*R packed rows).  The tile goes
+//     through LDS so that BOTH sides are coalesced: the source is read in runs along its own fastest dimensions ([co][ci][r]:
+//     16*R consecutive floats per output channel forward, 64*R per channel for the data-gradient layout), the destination is
+//     written in 256-byte row segments along m.  (The element-wise form read the source with a stride of Cin*R floats between
+//     neighbouring lanes and divided 64-bit indices per element: 219 us for the detector's 2 x 14.7 M weights, 0.8 TB/s.)
+//   other layers (3-channel stems, 30/60-channel heads as C): 4096 elements per tile through packed_weight_elem.
+constexpr int PACK_TILE_ELEMS = 4096;
+template <int R>
+__device__ __forceinline__ void pack_tile_blocked(const float *__restrict__ w, float *__restrict__ out, const int Cout, const int Cin,
+                                                  const int for_dgrad, const int t, float *tile) {
+    const int C = for_dgrad ? Cout : Cin, M = for_dgrad ? Cin : Cout;
+    const int mpad = conv_packed_mpad(M);
+    const int tiles_m = mpad / 64;
+    const int cb = t / tiles_m, m0 = (t - cb * tiles_m) * 64;
+    (void)C;
+    constexpr int KL = 16 * R;               // packed rows of the tile
+    const int tid = threadIdx.x;
+    if (!for_dgrad) {                        // source rows = output channels: 16*R consecutive floats each
+        for (int i = tid; i < 64 * KL; i += 256) {
+            const int ml = i / KL, j = i - ml * KL;
+            const int cl = j / R, r = j - cl * R;
+            const float v = (m0 + ml < M) ? w[((size_t)(m0 + ml) * Cin + cb * 16) * R + j] : 0.f;
+            tile[(r * 16 + cl) * 65 + ml] = v;
         }
-        const long long *d = desc + lo * 6;
-        out[idx] = packed_weight_elem(base + d[0], idx - d[1], (int)d[2], (int)d[3], (int)d[4], (int)d[5]);
+    } else {                                 // source rows = this block's 16 output channels: 64*R consecutive floats each
+        for (int i = tid; i < 16 * 64 * R; i += 256) {
+            const int cl = i / (64 * R), j = i - cl * (64 * R);
+            const int ml = j / R, r = j - ml * R;
+            const float v = (m0 + ml < M) ? w[((size_t)(cb * 16 + cl) * Cin + m0) * R + j] : 0.f;
+            tile[(r * 16 + cl) * 65 + ml] = v;
+        }
     }
+    __syncthreads();
+    float *o = out + ((size_t)cb * KL) * mpad + m0;
+    for (int i = tid; i < KL * 64; i += 256) {
+        const int kl = i >> 6, ml = i & 63;
+        o[(size_t)kl * mpad + ml] = tile[kl * 65 + ml];
+    }
+}
+
+__global__ __launch_bounds__(256) void pack_weights_batched_kernel(const float *__restrict__ base, float *__restrict__ out,
+                                                                   const long long *__restrict__ desc, const int n) {
+    __shared__ float tile[16 * 9 * 65];
+    const long long id = blockIdx.x;
+    int lo = 0, hi = n - 1;   // last layer whose first tile id is <= id (uniform: scalar loads)
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (desc[mid * 7 + 6] <= id) lo = mid; else hi = mid - 1;
+    }
+    const long long *d = desc + lo * 7;
+    const float *w = base + d[0];
+    float *o = out + d[1];
+    const int Cout = (int)d[2], Cin = (int)d[3], R = (int)d[4], for_dgrad = (int)d[5], t = (int)(id - d[6]);
+    const int C = for_dgrad ? Cout : Cin, M = for_dgrad ? Cin : Cout;
+    if ((C % BK) == 0 && R == 9) pack_tile_blocked<9>(w, o, Cout, Cin, for_dgrad, t, tile);
+    else if ((C % BK) == 0 && R == 1) pack_tile_blocked<1>(w, o, Cout, Cin, for_dgrad, t, tile);
+    else {
+        const long long total = (long long)((C % BK) == 0 ? conv_packed_mpad(M) : M) * C * R;
+        const long long first = (long long)t * PACK_TILE_ELEMS;
+        for (long long idx = first + threadIdx.x; idx < first + PACK_TILE_ELEMS && idx < total; idx += 256)
+            o[idx] = packed_weight_elem(w, idx, Cout, Cin, R, for_dgrad);
+    }
+}
+
+// tiles of one layer in pack_weights_batched_kernel's numbering (the caller builds the descriptor table with it)
+SCDA_API long long scda_conv2d_pack_tiles(int Cout, int Cin, int KH, int KW, int for_dgrad) {
+    const int C = for_dgrad ? Cout : Cin, M = for_dgrad ? Cin : Cout, R = KH * KW;
+    if ((C % BK) == 0 && (R == 9 || R == 1)) return (long long)(conv_packed_mpad(M) / 64) * (C / BK);
+    const long long total = (long long)((C % BK) == 0 ? conv_packed_mpad(M) : M) * C * R;
+    return (total + PACK_TILE_ELEMS - 1) / PACK_TILE_ELEMS;
 }
 
 // ----------------------------- host-side dispatch --------------------------
@@ -1482,6 +1550,17 @@ static int launch_conv(const float *Wm, const float *X, const ConvGeom &g0, Epi 
         plan.bm = 256; plan.bn = 128;
         while (plan.splits > 1 && (size_t)plan.splits * g.M * g.N * sizeof(float) > ws_bytes) --plan.splits;
     }
+    // <= 32 output rows on many pixels (the decoders' 64 -> 32 stage: 262144 pixels; the data gradient into the discriminators'
+    // 32-channel map): the 32 x 256 tile, one K pass.  SCDA_PLAN_FORCE=32,256,1 forces it wherever it is legal (tests),
+    // any other forced plan keeps it out.
+    {
+        static const bool no_bm32 = getenv("SCDA_CONV_NO_BM32") != nullptr;   // A/B knob
+        const char *f = getenv("SCDA_PLAN_FORCE");
+        int fb = 0, fnn = 0, fs = 0;
+        const bool forced = f && sscanf(f, "%d,%d,%d", &fb, &fnn, &fs) == 3;
+        const bool legal = g.M <= 32 && g.slab_aligned && !fbn;
+        if (legal && (forced ? (fb == 32 && fnn == 256 && fs == 1) : (!no_bm32 && g.N >= 256 * 256))) plan = LaunchPlan{256, 1, 32};
+    }
     const int BNv = plan.bn;
     const int BMt = plan.bm;                             // tile rows of this launch (BMv unless the 8-wave tile was chosen)
     int splits = plan.splits;
@@ -1492,7 +1571,7 @@ static int launch_conv(const float *Wm, const float *X, const ConvGeom &g0, Epi 
     g.nx = cdiv(g.N, BNv); g.ny = cdiv(g.M, BMt); g.swz = xcd_swizzle_enabled();
     dim3 grid((unsigned)g.nx * g.ny * splits);
     note_plan(BMt, BNv, splits, g.slab_aligned);
-    prof_begin(g.slab_aligned ? PK_CONV + ((DGRAD ? 2 : 0) + (BMt == 64 ? 1 : 0)) * 3 + prof_shape(KH, S) : (int)PK_CONV_GATHER,
+    prof_begin(g.slab_aligned ? PK_CONV + ((DGRAD ? 2 : 0) + (BMt <= 64 ? 1 : 0)) * 3 + prof_shape(KH, S) : (int)PK_CONV_GATHER,
                2.0 * g.M * (double)g.N * g.K, st,
                4.0 * ((double)g.batch * g.CB * g.HB * g.WB + (double)g.M * g.K + (double)g.M * g.N));
     g.mpad = conv_packed_mpad(g.M);
@@ -1504,6 +1583,7 @@ static int launch_conv(const float *Wm, const float *X, const ConvGeom &g0, Epi 
             hipLaunchKernelGGL((conv_igemm_kernel<BM_, BN_, KH, KW, S, DGRAD>), grid, dim3(256), 0, st, Wm, X, g, e);        \
     } while (0)
     if (BMt == 256) hipLaunchKernelGGL((conv_igemm_glds_kernel<256, 128, KH, KW, S, DGRAD>), grid, dim3(ConvGldsCfg<256, 128>::THREADS), 0, st, Wm, X, g, e);
+    else if (BMt == 32) hipLaunchKernelGGL((conv_igemm_glds_kernel<32, 256, KH, KW, S, DGRAD>), grid, dim3(ConvGldsCfg<32, 256>::THREADS), 0, st, Wm, X, g, e);
     else if (BMt == 64 && BNv == 256) hipLaunchKernelGGL((conv_igemm_glds_kernel<64, 256, KH, KW, S, DGRAD>), grid, dim3(ConvGldsCfg<64, 256>::THREADS), 0, st, Wm, X, g, e);
     else if (BMt == 64 && BNv == 64) CONV_LAUNCH(64, 64);
     else if (BMt == 64) CONV_LAUNCH(64, 128);
@@ -1710,9 +1790,9 @@ SCDA_API int scda_conv2d_pack_weight_hip(const float *w, float *out, int Cout, i
 }
 
 SCDA_API int scda_conv2d_pack_weights_batched_hip(const float *base, float *out, const long long *desc, int n,
-                                                  long long total, void *stream) {
-    if (!base || !out || !desc || n <= 0 || total <= 0) { set_error("scda_conv2d_pack_weights_batched_hip: bad arguments"); return SCDA_EINVAL; }
-    hipLaunchKernelGGL(pack_weights_batched_kernel, dim3(ew_grid(total)), dim3(256), 0, as_stream(stream), base, out, desc, n, total);
+                                                  long long n_tiles, void *stream) {
+    if (!base || !out || !desc || n <= 0 || n_tiles <= 0 || n_tiles > 0x7fffffffLL) { set_error("scda_conv2d_pack_weights_batched_hip: bad arguments"); return SCDA_EINVAL; }
+    hipLaunchKernelGGL(pack_weights_batched_kernel, dim3((unsigned)n_tiles), dim3(256), 0, as_stream(stream), base, out, desc, n);
     return launch_status("pack_weights_batched_kernel");
 }
 

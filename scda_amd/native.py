@@ -324,22 +324,24 @@ def conv2d_pack_all(flat):
     L = lib()
     if plan is None:
         L.scda_conv2d_packed_elems.restype = ctypes.c_size_t
-        rows, entries, off = [], [], 0
+        L.scda_conv2d_pack_tiles.restype = ctypes.c_longlong
+        rows, entries, off, tiles = [], [], 0, 0
         base = flat.data.data_ptr()
         for w in ws:
             Cout, Cin, KH, KW = w.shape
             src = (w.data_ptr() - base) // 4
             for d in (0, 1):
                 n = int(L.scda_conv2d_packed_elems(i32(Cout), i32(Cin), i32(KH), i32(KW), i32(d)))
-                rows.append([src, off, Cout, Cin, KH * KW, d])
+                rows.append([src, off, Cout, Cin, KH * KW, d, tiles])
                 entries.append((w, bool(d), off, n))
                 off += n
+                tiles += int(L.scda_conv2d_pack_tiles(i32(Cout), i32(Cin), i32(KH), i32(KW), i32(d)))
         desc = upload(torch.tensor(rows, dtype=torch.int64), flat.data.device)
         out = torch.empty(off, dtype=torch.float32, device=flat.data.device)
-        plan = flat._scda_pack_plan = (desc, out, entries, off)
-    desc, out, entries, total = plan
+        plan = flat._scda_pack_plan = (desc, out, entries, tiles)
+    desc, out, entries, tiles = plan
     _check(L.scda_conv2d_pack_weights_batched_hip(_p(flat.data), _p(out), _p(desc), i32(len(entries)),
-                                                  ctypes.c_longlong(total), _stream()), "scda_conv2d_pack_weights_batched_hip")
+                                                  ctypes.c_longlong(tiles), _stream()), "scda_conv2d_pack_weights_batched_hip")
     for w, d, off, n in entries:
         if w.data_ptr() < flat.data.data_ptr():   # parameter was re-homed: fall back to the lazy path for it
             continue

@@ -147,3 +147,30 @@ def test_conv_full_size_linearity(cuda):
     ref = F.conv2d(x1[:, :, :10, :66].cpu(), w.cpu(), None, padding=1)
     close(y1[:, :, :9, :65], ref[:, :, :9, :65])
 
+
+
+def test_batched_weight_pack_equals_per_layer_pack(cuda):
+    """native.conv2d_pack_all (one launch after every optimiser step: tiles through LDS, both sides coalesced) against the per-layer
+    element-wise kernel, bit for bit, both directions: blocked layouts with full and partial 64-column tiles (M = 96 -> mpad 128, M =
+    30 / 3 / 1 -> mpad 64), 1x1 and 3x3 taps, and the un-blocked layouts of channel counts that are no multiple of 16 (3, 30, 60)."""
+    from scda_amd import layers as L
+    from scda_amd import native
+    from scda_amd.flat import FlatParams
+    shapes = [(64, 3, 3), (64, 64, 3), (30, 512, 1), (60, 512, 1), (128, 64, 3), (256, 256, 3), (3, 32, 1), (1, 128, 1), (32, 64, 3),
+              (96, 48, 3), (48, 96, 1), (16, 16, 3)]
+    torch.manual_seed(9)
+    net = torch.nn.Sequential(*[L.Conv2d(ci, co, kernel_size=k, padding=k // 2) for co, ci, k in shapes]).to(cuda)
+    flat = FlatParams(net)
+    assert len(flat.conv_weights) == len(shapes)
+    native.conv2d_pack_all(flat)
+    for w in flat.conv_weights:
+        for d in (False, True):
+            got = native._PACK_CACHE[(w.data_ptr(), d)][1]
+            want = native.conv2d_pack_weight(w.detach().clone(), d, cache=False)
+            assert got.shape == want.shape and torch.equal(got, want), (tuple(w.shape), d)
+    with torch.no_grad():                      # a second step: new values, same plan
+        flat.data.mul_(1.5).add_(0.25)
+    flat.epoch += 1
+    native.conv2d_pack_all(flat)
+    w = flat.conv_weights[5]
+    assert torch.equal(native._PACK_CACHE[(w.data_ptr(), True)][1], native.conv2d_pack_weight(w.detach().clone(), True, cache=False))

@@ -103,6 +103,34 @@ def test_conv_dgrad_forced_plan(cuda, case, plan):
     close(got, x.grad)
 
 
+# the 32-row tile (layers with <= 32 output rows): shape, direction
+TILE32 = [
+    ((4, 64, 32, 32, 32, 3, 1, 1), "fwd"),     # the decoders' 64 -> 32 stage
+    ((4, 32, 32, 32, 3, 1, 1, 0), "fwd"),      # their 32 -> 3 head, 1x1: 3 valid rows of 32
+    ((2, 64, 30, 34, 24, 3, 1, 1), "fwd"),     # ragged: 24 rows, 2040 pixels (no multiple of the 256-pixel tile), image seam inside a tile
+    ((4, 16, 32, 32, 32, 3, 2, 1), "fwd"),     # stride 2, one K-slab per tap
+    ((4, 32, 32, 32, 64, 3, 2, 1), "dgrad"),   # data gradient into the discriminators' 32-channel map (stride 2: general tap path)
+    ((4, 32, 32, 32, 64, 3, 1, 1), "dgrad"),
+    ((1, 16, 40, 52, 48, 1, 1, 0), "dgrad"),   # 1x1, 16 rows
+]
+
+
+@pytest.mark.parametrize("case,direction", TILE32)
+def test_conv_32_row_tile(cuda, case, direction):
+    from scda_amd import native
+    s, p = case[6], case[7]
+    x, w, b, y, dy = _conv_ref(case, 17 + sum(case), True)
+    with force_plan(32, 256, 1):
+        if direction == "fwd":
+            got = native.conv2d_fwd(x.detach().to(cuda), w.detach().to(cuda), b.detach().to(cuda), s, p, 1, 0.01)
+            want = F.relu(y)
+        else:
+            got = native.conv2d_dgrad(dy.to(cuda), w.detach().to(cuda), x.shape, s, p)
+            want = x.grad
+        assert native.last_plan() == (32, 256, 1, True), native.last_plan()
+    close(got, want)
+
+
 WGRAD = [
     (CONV1_2, (64, 128, 4)), (CONV1_2, (64, 128, 16)), (CONV1_2, (64, 128, 1)),
     (CONV2_2, (128, 128, 2)), (CONV2_2, (128, 128, 8)),
