@@ -161,6 +161,21 @@ int scda_proposal_decode_hip(const int *order, const float *exp_wh, int n, const
 /* out6 [max_rows,6] rows i < min(max_rows, *num_keep) = (image_index, props5[keep[i]]) */
 int scda_proposal_gather_hip(const float *props5, const long long *keep, const long long *num_keep, float image_index, int max_rows,
                              float *out6, void *stream);
+/* RoI sampling for the RCNN head with the candidates resident on the device (functions/proposal_target.py:38-62, one image).
+ * Step 1: candidates = the n_prop proposals (rows (b, x1, y1, x2, y2, ...), stride prop_stride) followed by the G ground-truth
+ * boxes (rows (x1, y1, x2, y2, class), stride gt_stride), clipped to the image (utils/bbox_helper.py:105-110) -> rois [n_prop+G,4];
+ * per candidate the first best gt and its IoU (cython_bbox.pyx:32-73 arithmetic); labels 1 (IoU > pos_thresh) / 0 (neg_lo <= IoU <
+ * neg_hi, not foreground) / -1; pos_list / neg_list = the ascending index lists np.where returns, counts [2] their lengths.  The
+ * host then orders the negatives as the reference's Python-set arithmetic does, draws np.random.choice, and evaluates the <= 128
+ * foreground rows' regression targets with numpy (its float32 log is numpy's own routine). */
+int scda_proposal_match_hip(const float *props, int n_prop, int prop_stride, const float *gts, int G, int gt_stride, float img_h,
+                            float img_w, float pos_thresh, float neg_hi, float neg_lo, float *rois, float *best_iou, int *best_gt,
+                            signed char *labels, int *pos_list, int *neg_list, int *counts, void *stream);
+/* Step 2 (:64-136): sel i32 [R] = sampled candidate indices, gt_of i32 [R] = matched gt (-1: background), enc f32 [R,4] = the
+ * foreground rows' normalised targets -> rois5 [R,5] = (image_index, box), labels int64 [R], loc_targets / loc_weights [R, 4*C]. */
+int scda_proposal_finalize_hip(const float *cand_rois, const int *sel, const int *gt_of, const float *enc, const float *gts,
+                               int gt_stride, int R, int num_classes, float image_index, float *rois5, long long *labels,
+                               float *loc_targets, float *loc_weights, void *stream);
 
 /* ------------------------------------------------- convolution / GEMM ---- */
 /* The reference reaches these through torch.nn (cuDNN / cuBLAS): nn.Conv2d in

@@ -189,6 +189,60 @@ __global__ __launch_bounds__(256) void proposal_gather_kernel(const float *__res
     }
 }
 
+// ---- RoI sampling for the RCNN head: functions/proposal_target.py:38-62 ----------------------------------------------------
+// Candidate r < n_prop is proposal r's box (row stride prop_stride, box at columns 1..4 of a (b, x1, y1, x2, y2, score) row),
+// candidate n_prop + g is ground-truth box g (append_gts).  Per candidate: clip to the image as utils/bbox_helper.py:105-110 does
+// (np.clip on float32 columns), IoU against every gt on the CLIPPED box, first maximum (ndarray.argmax) -> best_gt / best_iou, and
+// the class of the threshold tests of :55-59: 1 = foreground (best_iou > pos), 0 = background (lo <= best_iou < hi and not
+// foreground), -1 = neither.  The ordered index lists np.where would return come from anchor_compact_kernel.
+__global__ __launch_bounds__(256) void proposal_match_kernel(const float *__restrict__ props, const int n_prop, const int prop_stride,
+                                                             const float *__restrict__ gts, const int G, const int gt_stride,
+                                                             const float hi_x, const float hi_y, const float pos_thresh,
+                                                             const float neg_hi, const float neg_lo, float *__restrict__ rois,
+                                                             float *__restrict__ best_iou, int *__restrict__ best_gt,
+                                                             signed char *__restrict__ labels) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_prop + G) return;
+    const float *src = r < n_prop ? props + (size_t)r * prop_stride + 1 : gts + (size_t)(r - n_prop) * gt_stride;
+    float box[4];
+    box[0] = fminf(fmaxf(src[0], 0.f), hi_x); box[1] = fminf(fmaxf(src[1], 0.f), hi_y);
+    box[2] = fminf(fmaxf(src[2], 0.f), hi_x); box[3] = fminf(fmaxf(src[3], 0.f), hi_y);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) rois[(size_t)r * 4 + c] = box[c];
+    float bi = -1.f;
+    int bg = 0;
+    for (int g = 0; g < G; ++g) {
+        const float v = bbox_iou(box, gts + (size_t)g * gt_stride);
+        if (v > bi) { bi = v; bg = g; }
+    }
+    best_iou[r] = bi;
+    best_gt[r] = bg;
+    labels[r] = (signed char)(bi > pos_thresh ? 1 : (bi < neg_hi && bi >= neg_lo) ? 0 : -1);
+}
+
+// The sampled RoIs of one image, after the host drew them: sel[i] = candidate index, gt_of[i] = its matched gt (>= 0: foreground,
+// label = that gt's class; -1: background, label 0), enc [R,4] = the normalised regression target of the foreground rows as numpy
+// computed it (:131-135; its float32 log is numpy's own routine).  -> rois [R,5] = (image, clipped box), labels int64 [R],
+// loc_targets / loc_weights [R, 4*C] (the foreground row's target and ones in the four columns of its class, zeros elsewhere).
+__global__ __launch_bounds__(256) void proposal_finalize_kernel(const float *__restrict__ cand_rois, const int *__restrict__ sel,
+                                                                const int *__restrict__ gt_of, const float *__restrict__ enc,
+                                                                const float *__restrict__ gts, const int gt_stride, const int R,
+                                                                const int C, const float image_index, float *__restrict__ rois5,
+                                                                long long *__restrict__ labels, float *__restrict__ loc_t,
+                                                                float *__restrict__ loc_w) {
+    const int cols = 4 * C;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < R * cols; idx += blockDim.x * gridDim.x) {
+        const int i = idx / cols, c = idx - i * cols;
+        const int g = gt_of[i];
+        const int lab = g >= 0 ? (int)gts[(size_t)g * gt_stride + 4] : 0;
+        const bool on = g >= 0 && (c >> 2) == lab;
+        loc_t[idx] = on ? enc[(size_t)i * 4 + (c & 3)] : 0.f;
+        loc_w[idx] = on ? 1.f : 0.f;
+        if (c == 0) labels[i] = lab;
+        if (c < 5) rois5[(size_t)i * 5 + c] = c == 0 ? image_index : cand_rois[(size_t)sel[i] * 4 + c - 1];
+    }
+}
+
 }  // namespace scda
 
 using namespace scda;
@@ -251,4 +305,33 @@ SCDA_API int scda_proposal_gather_hip(const float *props5, const long long *keep
     hipLaunchKernelGGL(proposal_gather_kernel, dim3(ew_grid(max_rows)), dim3(256), 0, as_stream(stream), props5, keep, num_keep,
                        image_index, max_rows, out6);
     return launch_status("proposal_gather_kernel");
+}
+
+// RoI sampling, step 1 of 2 (functions/proposal_target.py:38-62): candidates = proposals (+ ground-truth boxes), clipped; their
+// best gt / IoU; foreground / background classes; ordered index lists and counts.  props [n_prop, prop_stride >= 5] fp32 rows
+// (b, x1, y1, x2, y2, ...), gts [G, gt_stride >= 5] fp32 (x1, y1, x2, y2, class).  Outputs (caller-owned): rois [n_prop+G, 4],
+// best_iou / best_gt / labels [n_prop+G], pos_list / neg_list [n_prop+G] i32, counts [2] i32.
+SCDA_API int scda_proposal_match_hip(const float *props, int n_prop, int prop_stride, const float *gts, int G, int gt_stride,
+                                     float img_h, float img_w, float pos_thresh, float neg_hi, float neg_lo, float *rois,
+                                     float *best_iou, int *best_gt, signed char *labels, int *pos_list, int *neg_list, int *counts,
+                                     void *stream) {
+    BOX_CHECK(gts && rois && best_iou && best_gt && labels && pos_list && neg_list && counts && n_prop >= 0 && (n_prop == 0 || props) &&
+              G > 0 && prop_stride >= 5 && gt_stride >= 5, "scda_proposal_match_hip")
+    hipStream_t st = as_stream(stream);
+    const int n = n_prop + G;
+    hipLaunchKernelGGL(proposal_match_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, props, n_prop, prop_stride, gts, G, gt_stride,
+                       img_w - 1.f, img_h - 1.f, pos_thresh, neg_hi, neg_lo, rois, best_iou, best_gt, labels);
+    hipLaunchKernelGGL(anchor_compact_kernel, dim3(1), dim3(1024), 0, st, labels, n, pos_list, neg_list, counts);
+    return launch_status("proposal_match kernels");
+}
+
+// step 2 of 2 (:64-136): gather what the host sampled (see proposal_finalize_kernel)
+SCDA_API int scda_proposal_finalize_hip(const float *cand_rois, const int *sel, const int *gt_of, const float *enc, const float *gts,
+                                        int gt_stride, int R, int num_classes, float image_index, float *rois5, long long *labels,
+                                        float *loc_targets, float *loc_weights, void *stream) {
+    BOX_CHECK(cand_rois && sel && gt_of && enc && gts && rois5 && labels && loc_targets && loc_weights && R > 0 && num_classes > 1 &&
+              gt_stride >= 5, "scda_proposal_finalize_hip")
+    hipLaunchKernelGGL(proposal_finalize_kernel, dim3(ew_grid((long long)R * 4 * num_classes)), dim3(256), 0, as_stream(stream),
+                       cand_rois, sel, gt_of, enc, gts, gt_stride, R, num_classes, image_index, rois5, labels, loc_targets, loc_weights);
+    return launch_status("proposal_finalize_kernel");
 }

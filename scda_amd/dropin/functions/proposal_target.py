@@ -24,6 +24,12 @@ def _np(x):
 def compute_proposal_targets(proposals, cfg, ground_truth_bboxes, image_info, ignore_regions=None, use_ohem=False):
     """proposals [N,>=5] (b,x1,y1,x2,y2,..) -> rois fp32 [R,5], labels int64 [R], loc_targets, loc_weights fp32 [R,4C]"""
     dev = ground_truth_bboxes.device if torch.is_tensor(ground_truth_bboxes) else torch.device('cpu')
+    if dev.type == 'cuda':
+        from scda_amd import device_boxes
+        if device_boxes.proposal_targets_legal(cfg, ground_truth_bboxes, ignore_regions, use_ohem):
+            out = device_boxes.proposal_targets(proposals, cfg, ground_truth_bboxes, image_info)   # IoU / matching / gather on the MI355X
+            if out is not None:
+                return out
     proposals, gts_all, image_info, ignore_regions = map(_np, (proposals, ground_truth_bboxes, image_info, ignore_regions))
     C = cfg['num_classes']
     per_image = cfg['batch_size']

@@ -231,6 +231,30 @@ def anchor_finalize(bufs, drop_pos, drop_neg, anchors64, gts, A, fh, fw):
     return cls_t, loc_t, loc_m
 
 
+def proposal_match(props, gts, img_h, img_w, pos_thresh, neg_hi, neg_lo, bufs):
+    """props [n,>=5] fp32 rows (b,x1,y1,x2,y2,..), gts [G,>=5]; bufs: caller-owned device buffers rois [n+G,4], best_iou, best_gt,
+    labels, pos_list, neg_list [n+G], counts [2] (scda_proposal_match_hip)"""
+    _req(props, "props"); _req(gts, "gts")
+    _check(lib().scda_proposal_match_hip(_p(props), i32(props.shape[0]), i32(props.shape[1]), _p(gts), i32(gts.shape[0]), i32(gts.shape[1]),
+                                         f32(img_h), f32(img_w), f32(pos_thresh), f32(neg_hi), f32(neg_lo), _p(bufs["rois"]),
+                                         _p(bufs["best_iou"]), _p(bufs["best_gt"]), _p(bufs["labels"]), _p(bufs["pos_list"]),
+                                         _p(bufs["neg_list"]), _p(bufs["counts"]), _stream()), "scda_proposal_match_hip")
+
+
+def proposal_finalize(cand_rois, sel, gt_of, enc, gts, num_classes, image_index):
+    """-> rois [R,5] fp32, labels int64 [R], loc_targets, loc_weights fp32 [R, 4*num_classes] (scda_proposal_finalize_hip)"""
+    _req(cand_rois, "cand_rois"); _req(sel, "sel", torch.int32); _req(gt_of, "gt_of", torch.int32); _req(enc, "enc"); _req(gts, "gts")
+    R, dev = sel.numel(), gts.device
+    rois = torch.empty(R, 5, dtype=torch.float32, device=dev)
+    labels = torch.empty(R, dtype=torch.int64, device=dev)
+    t = torch.empty(R, 4 * num_classes, dtype=torch.float32, device=dev)
+    w = torch.empty(R, 4 * num_classes, dtype=torch.float32, device=dev)
+    _check(lib().scda_proposal_finalize_hip(_p(cand_rois), _p(sel), _p(gt_of), _p(enc), _p(gts), i32(gts.shape[1]), i32(R),
+                                            i32(num_classes), f32(image_index), _p(rois), _p(labels), _p(t), _p(w), _stream()),
+           "scda_proposal_finalize_hip")
+    return rois, labels, t, w
+
+
 def proposals_from_ranking(order, exp_wh, anchors64, loc, prob, A, fh, fw, img_h, img_w, min_size, nms_thresh, max_keep, image_index):
     """order int32 [n], exp_wh f32 [n,2] (device) -> (out6 fp32 [rows,6], num int64 [1]) on the device: decode + clip + size test,
     NMS, gather"""

@@ -84,7 +84,11 @@ def check_l2(golden_dir, G, device=None):
     np.testing.assert_array_equal(props_test.numpy(), g["proposals_test"])
 
     np.random.seed(seed + 1)
-    rois, labels, pt, pw = compute_proposal_targets(props, CFG["train_proposal_target_cfg"], gts, info, None)
+    rois, labels, pt, pw = compute_proposal_targets(props, CFG["train_proposal_target_cfg"], gts_in, info, None)
+    if device is not None:      # matched, compacted, gathered on the device (device_boxes.proposal_targets); the sampled rows' host copy rides along
+        assert rois.is_cuda and labels.is_cuda and pt.is_cuda and labels.dtype == torch.int64
+        np.testing.assert_array_equal(rois._scda_host, g["pt_rois"])
+        rois, labels, pt, pw = rois.cpu(), labels.cpu(), pt.cpu(), pw.cpu()
     np.testing.assert_array_equal(rois.numpy(), g["pt_rois"])
     np.testing.assert_array_equal(labels.numpy().astype(np.int16), g["pt_labels"])
     nzp = np.nonzero(pw.numpy().reshape(-1))[0]

@@ -16,9 +16,10 @@ def test_l2_functions_match_reference_on_device(cuda, golden_dir, G):
 
 @pytest.mark.parametrize("G", [3, 12, 30])
 def test_device_resident_box_logic_matches_reference(cuda, golden_dir, G):
-    """anchor labelling (IoU, labels, sub-sampling with host-drawn indices, target maps) and proposal generation (decode, clip,
-    size test, NMS, gather) entirely on the MI355X -- scda_amd/device_boxes.py, box_ops.hip -- against the SAME vectors the
-    reference's numpy code produced: labels, target values, proposal lists bit for bit"""
+    """anchor labelling (IoU, labels, sub-sampling with host-drawn indices, target maps), proposal generation (decode, clip,
+    size test, NMS, gather) and RoI sampling (clip, IoU, best gt, threshold tests, ordered index lists, gather of the sampled rows,
+    target / weight maps) on the MI355X -- scda_amd/device_boxes.py, box_ops.hip -- against the SAME vectors the reference's numpy
+    code produced: labels, target values, proposal lists, sampled RoIs bit for bit"""
     from scda_amd import device_boxes
     from scda_amd.dropin import backend
     backend.reset()
@@ -101,3 +102,46 @@ def test_device_box_logic_equals_numpy_path_on_edge_cases(cuda, case, monkeypatc
         assert tuple(a[4].shape) == (0, 6)
     if case == "few_candidates":
         assert 0 < a[4].shape[0] <= 50
+
+
+@pytest.mark.parametrize("case", ["pad_by_resampling", "one_gt", "no_foreground_surplus", "zero_padded_gts", "host_proposals"])
+def test_device_roi_sampling_equals_numpy_path(cuda, case, monkeypatch):
+    """device_boxes.proposal_targets against THIS repository's numpy path (pinned to the reference's vectors by the fixtures) where
+    the fixtures do not reach: fewer candidates than the 512-RoI batch (the padding draw), a single gt, fewer foreground rows than
+    the 25 % budget, zero-padded gt rows, proposals that exist on the host only."""
+    import copy
+    import numpy as np
+    import torch
+    from test_host_functions import CFG
+    from scda_amd.dropin.functions.proposal_target import compute_proposal_targets
+    cfg = copy.deepcopy(CFG["train_proposal_target_cfg"])
+    rs = np.random.RandomState(5)
+    gts = np.array([[[100, 80, 400, 300, 3], [600, 200, 900, 480, 5], [30, 300, 200, 500, 1]]], dtype=np.float32)
+    n = 1500
+    if case == "pad_by_resampling":
+        n = 200
+    elif case == "one_gt":
+        gts = gts[:, :1]
+    elif case == "zero_padded_gts":
+        gts = np.concatenate([gts, np.zeros((1, 2, 5), np.float32)], 1)
+    x1 = rs.uniform(-30, 1000, n); y1 = rs.uniform(-30, 500, n)
+    b = np.stack([np.zeros(n), x1, y1, x1 + rs.uniform(8, 400, n), y1 + rs.uniform(8, 300, n), np.sort(rs.uniform(0, 1, n))[::-1]], 1)
+    k = 60 if case != "no_foreground_surplus" else 6
+    for j in range(k):      # some candidates close to a gt box: foreground
+        g = gts[0, j % (1 if case == "one_gt" else 3)]
+        b[(j * 7) % n, 1:5] = g[:4] + rs.uniform(-12, 12, 4)
+    props = torch.from_numpy(b.astype(np.float32))
+    info = torch.tensor([[512, 1024, 1.0]])
+    gd = torch.from_numpy(gts).to(cuda)
+    gd._scda_host = gts
+    if case != "host_proposals":
+        props._scda_dev = props.to(cuda)
+    out = {}
+    for dev_boxes in ("1", "0"):
+        monkeypatch.setenv("SCDA_DEVICE_BOXES", dev_boxes)
+        np.random.seed(11)
+        r = compute_proposal_targets(props, cfg, gd, info, None)
+        out[dev_boxes] = [t.cpu().numpy() for t in r] + [r[0]._scda_host, np.random.uniform()]     # ... and the RNG stream ends in the same state
+    for a, c in zip(out["1"], out["0"]):
+        np.testing.assert_array_equal(a, c)
+    assert out["1"][0].shape == (512, 5) and out["1"][2].shape == (512, 36)
