@@ -879,21 +879,40 @@ __global__ __launch_bounds__(256) void batchnorm_eval_kernel(const float *__rest
 
 // ------------------------------------------- bilinear x2, align_corners -----
 // Interpolate(scale_factor=2, mode='bilinear', align_corners=True): common_net.py:160-170
-// grid: x = plane * OH + output row, y = column blocks (no per-element integer division)
+// One workgroup = ROWS consecutive output rows of one plane (OH % ROWS == 0), a thread = four consecutive output pixels per step
+// (16-byte stores).  (One workgroup per output ROW with a pixel per thread was 65536 half-empty workgroups for the decoders'
+// [4, 64, 128, 128] -> 256 x 256 stage: 39-48 us for 84 MB, workgroup dispatch, not memory, set its pace.)
+template <int ROWS>
 __global__ __launch_bounds__(256) void upsample2_fwd_kernel(const float *__restrict__ x, float *__restrict__ y,
                                                             const int IH, const int IW, const int OH, const int OW,
                                                             const float sh, const float sw) {
-    const int row = blockIdx.x, oy = row % OH, pc = row / OH;       // workgroup-uniform
-    const float fy = sh * (float)oy;
-    const int y0 = (int)fy, y1 = y0 + (y0 < IH - 1 ? 1 : 0);
-    const float ly1 = fminf(fmaxf(fy - (float)y0, 0.f), 1.f), ly0 = 1.f - ly1;
-    const float *p0 = x + ((size_t)pc * IH + y0) * IW, *p1 = x + ((size_t)pc * IH + y1) * IW;
-    float *out = y + (size_t)row * OW;
-    for (int ox = blockIdx.y * blockDim.x + threadIdx.x; ox < OW; ox += blockDim.x * gridDim.y) {
-        const float fx = sw * (float)ox;
-        const int x0 = (int)fx, x1 = x0 + (x0 < IW - 1 ? 1 : 0);
-        const float lx1 = fminf(fmaxf(fx - (float)x0, 0.f), 1.f), lx0 = 1.f - lx1;
-        out[ox] = ly0 * (lx0 * p0[x0] + lx1 * p0[x1]) + ly1 * (lx0 * p1[x0] + lx1 * p1[x1]);
+    const int row0 = blockIdx.x * ROWS, pc = row0 / OH, oy0 = row0 - pc * OH;       // workgroup-uniform
+    const int q_per_row = (OW + 3) >> 2;
+    const float *plane = x + (size_t)pc * IH * IW;
+    for (int i = threadIdx.x; i < ROWS * q_per_row; i += 256) {
+        const int r = i / q_per_row, q = i - r * q_per_row;
+        const int oy = oy0 + r;
+        const float fy = sh * (float)oy;
+        const int y0 = (int)fy, y1 = y0 + (y0 < IH - 1 ? 1 : 0);
+        const float ly1 = fminf(fmaxf(fy - (float)y0, 0.f), 1.f), ly0 = 1.f - ly1;
+        const float *p0 = plane + (size_t)y0 * IW, *p1 = plane + (size_t)y1 * IW;
+        float *out = y + ((size_t)row0 + r) * OW;
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ox = min(q * 4 + k, OW - 1);
+            const float fx = sw * (float)ox;
+            const int x0 = (int)fx, x1 = x0 + (x0 < IW - 1 ? 1 : 0);
+            const float lx1 = fminf(fmaxf(fx - (float)x0, 0.f), 1.f), lx0 = 1.f - lx1;
+            v[k] = ly0 * (lx0 * p0[x0] + lx1 * p0[x1]) + ly1 * (lx0 * p1[x0] + lx1 * p1[x1]);
+        }
+        if (q * 4 + 3 < OW && (OW & 3) == 0) {
+            *reinterpret_cast<float4 *>(out + q * 4) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (q * 4 + k < OW) out[q * 4 + k] = v[k];
+        }
     }
 }
 
@@ -913,14 +932,19 @@ __device__ __forceinline__ void up2_candidates(int i, int In, int On, float s, i
 // 10 coalesced loads per result instead of 25-56 predicated ones; deterministic (fixed order, no atomics).
 constexpr int kUpMaxOW = 4096;
 
+template <int ROWS>
 __global__ __launch_bounds__(256) void upsample2_bwd_kernel(const float *__restrict__ dy, float *__restrict__ dx,
                                                             const int IH, const int IW, const int OH, const int OW,
                                                             const float sh, const float sw) {
     __shared__ float rowbuf[kUpMaxOW];
-    const int row = blockIdx.x, iy = row % IH, pc = row / IH;       // workgroup-uniform
+    // ROWS consecutive input rows of one plane per workgroup, one after the other (IH % ROWS == 0): a workgroup per input row was
+    // 32768 workgroups of 256 threads for 128 results each
+    for (int rr = 0; rr < ROWS; ++rr) {
+    const int row = blockIdx.x * ROWS + rr, iy = row % IH, pc = row / IH;       // workgroup-uniform
     int ylo, yhi;
     up2_candidates(iy, IH, OH, sh, ylo, yhi);
     const float *g = dy + (size_t)pc * OH * OW;
+    if (rr) __syncthreads();
     for (int ox = threadIdx.x; ox < OW; ox += blockDim.x) {
         float acc = 0.f;
         for (int oy = ylo; oy <= yhi; ++oy) {
@@ -945,6 +969,7 @@ __global__ __launch_bounds__(256) void upsample2_bwd_kernel(const float *__restr
             if (wx != 0.f) acc += wx * rowbuf[ox];
         }
         dx[(size_t)row * IW + ix] = acc;
+    }
     }
 }
 
@@ -1370,8 +1395,12 @@ static float up_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (flo
 SCDA_API int scda_upsample2x_fwd_hip(const float *x, float *y, int planes, int IH, int IW, void *stream) {
     NN_CHECK(x && y && planes > 0 && IH > 0 && IW > 0, "scda_upsample2x_fwd_hip")
     const int OH = IH * 2, OW = IW * 2;
-    hipLaunchKernelGGL(upsample2_fwd_kernel, dim3(planes * OH, cdiv(OW, 256)), dim3(256), 0, as_stream(stream), x, y, IH, IW, OH, OW,
-                       up_scale(IH, OH), up_scale(IW, OW));
+    if ((OH % 8) == 0)
+        hipLaunchKernelGGL(upsample2_fwd_kernel<8>, dim3(planes * OH / 8), dim3(256), 0, as_stream(stream), x, y, IH, IW, OH, OW,
+                           up_scale(IH, OH), up_scale(IW, OW));
+    else
+        hipLaunchKernelGGL(upsample2_fwd_kernel<2>, dim3(planes * OH / 2), dim3(256), 0, as_stream(stream), x, y, IH, IW, OH, OW,
+                           up_scale(IH, OH), up_scale(IW, OW));
     return launch_status("upsample2_fwd_kernel");
 }
 
@@ -1379,8 +1408,12 @@ SCDA_API int scda_upsample2x_bwd_hip(const float *dy, float *dx, int planes, int
     NN_CHECK(dy && dx && planes > 0 && IH > 1 && IW > 1, "scda_upsample2x_bwd_hip")
     const int OH = IH * 2, OW = IW * 2;
     if (OW > kUpMaxOW) { set_error("scda_upsample2x_bwd_hip: rows wider than %d are not supported", kUpMaxOW); return SCDA_EINVAL; }
-    hipLaunchKernelGGL(upsample2_bwd_kernel, dim3(planes * IH), dim3(256), 0, as_stream(stream), dy, dx, IH, IW, OH, OW,
-                       up_scale(IH, OH), up_scale(IW, OW));
+    if ((IH % 4) == 0)
+        hipLaunchKernelGGL(upsample2_bwd_kernel<4>, dim3(planes * IH / 4), dim3(256), 0, as_stream(stream), dy, dx, IH, IW, OH, OW,
+                           up_scale(IH, OH), up_scale(IW, OW));
+    else
+        hipLaunchKernelGGL(upsample2_bwd_kernel<1>, dim3(planes * IH), dim3(256), 0, as_stream(stream), dy, dx, IH, IW, OH, OW,
+                           up_scale(IH, OH), up_scale(IW, OW));
     return launch_status("upsample2_bwd_kernel");
 }
 
