@@ -359,7 +359,12 @@ __global__ __launch_bounds__((ConvGldsCfg<BM, BN>::THREADS)) void conv_igemm_gld
         // it shares a SIMD with starved this wave and the ring ran dry (conv3_2 forward 121 vs 128 TFLOP/s)
         __builtin_amdgcn_s_setprio(3);
         constexpr unsigned OOB = 0x80000000u;
-        constexpr bool FAST = KH * KW <= 32 && (S == 1 || !DGRAD);   // tap offset = lane constant + slab scalar
+        // tap offset = lane constant + slab scalar.  Also for the stride-2 data gradient: tap (kh, kw) of input pixel (py, px) reads
+        // dY at ((py + pad - kh) / 2, (px + pad - kw) / 2) where both differences are even, and for those taps the quotients are
+        // ((py + pad) >> 1) - (kh >> 1) and ((px + pad) >> 1) - (kw >> 1) -- a lane constant minus a slab scalar again; which taps
+        // exist for a lane (parity and range) is in its validity bits like the padding.  (The general path re-derived every
+        // lane's offset, two divisions included, for every slab: the discriminators' stride-2 data gradients ran at 11-25 TFLOP/s.)
+        constexpr bool FAST = KH * KW <= 32 && S <= 2;
         const int plane = g.HB * g.WB;
         const int img_first = __builtin_amdgcn_readfirstlane(g.dPHW.div(n0));
         const char *xbase = reinterpret_cast<const char *>(X + ((size_t)img_first * g.CB + p * C::ROWS_PP) * plane);
@@ -376,7 +381,8 @@ __global__ __launch_bounds__((ConvGldsCfg<BM, BN>::THREADS)) void conv_igemm_gld
             lane_img[h] = (img - img_first) * g.CB * plane;
             lane_base[h] = 0; off_taps[h] = 0;
             if (FAST) {
-                lane_base[h] = lane_img[h] + (DGRAD ? (py[h] + g.pad) * g.WB + px[h] + g.pad
+                lane_base[h] = lane_img[h] + (DGRAD ? (S == 2 ? ((py[h] + g.pad) >> 1) * g.WB + ((px[h] + g.pad) >> 1)
+                                                                      : (py[h] + g.pad) * g.WB + px[h] + g.pad)
                                                     : (py[h] * S - g.pad) * g.WB + px[h] * S - g.pad);
 #pragma unroll
                 for (int r = 0; r < KH * KW; ++r)
@@ -403,7 +409,7 @@ __global__ __launch_bounds__((ConvGldsCfg<BM, BN>::THREADS)) void conv_igemm_gld
             for (int h = 0; h < HALVES; ++h) {
                 unsigned voff;
                 if (FAST) {
-                    const int tap = DGRAD ? -(kh * g.WB + kw) : kh * g.WB + kw;
+                    const int tap = DGRAD ? (S == 2 ? -((kh >> 1) * g.WB + (kw >> 1)) : -(kh * g.WB + kw)) : kh * g.WB + kw;
                     voff = ((unsigned)(lane_base[h] + tap) << 2) | (((off_taps[h] >> r) & 1u) << 31);
                 } else {
                     const int off = conv_tap_offset<S, DGRAD>(g, n_ok[h], py[h], px[h], kh, kw);
