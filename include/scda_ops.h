@@ -304,6 +304,13 @@ int scda_instnorm_fwd_hip(const float *x, float *y, float *mean, float *rstd, in
                           float slope, void *stream);
 int scda_instnorm_bwd_hip(const float *dy, const float *x, const float *mean, const float *rstd, float *dx, int planes,
                           int HW, int act, float slope, void *stream);
+/* The tail of a residual block, x + Dropout(InstanceNorm(h)) (INSResBlock, common_net.py:59-80), as ONE launch each way: the norm of
+ * `x`, nn.Dropout(p) with the keep decision of element i recomputed from (seed, i) exactly as scda_dropout_seeded_hip makes it, plus
+ * `residual` -- and the matching gradient w.r.t. x (the residual's gradient is dy itself).  Bit-identical to the three launches. */
+int scda_instnorm_drop_add_fwd_hip(const float *x, const float *residual, float *y, float *mean, float *rstd, int planes, int HW,
+                                   float eps, float p, uint64_t seed, float scale /* 1 / (1 - p) */, void *stream);
+int scda_instnorm_drop_bwd_hip(const float *dy, const float *x, const float *mean, const float *rstd, float *dx, int planes, int HW,
+                               float p, uint64_t seed, float scale, void *stream);
 /* nn.BatchNorm2d, training mode, with optional fused activation : common_net.py:214-223 */
 size_t scda_batchnorm_workspace_bytes(int B, int C, int HW);   /* 0: the one-workgroup-per-channel form needs none (ws may be NULL) */
 int scda_batchnorm_fwd_hip(const float *x, float *y, const float *gamma, const float *beta, float *running_mean,

@@ -369,6 +369,28 @@ class InstanceNormFn(Function):
         return N.instnorm_bwd(_c(dy), x, mean, rstd, act, slope), None, None, None
 
 
+class InstNormDropAddFn(Function):
+    """residual + Dropout_p(InstanceNorm(x)) -- the tail of INSResBlock (common_net.py:59-80) as one launch each way; the keep
+    decisions come from the 64-bit seed in both passes (as DropoutSeededFn).  Bit-identical to InstanceNormFn -> DropoutSeededFn ->
+    AddFn."""
+
+    @staticmethod
+    def forward(ctx, x, residual, eps, p, seed):
+        x = _c(x)
+        y, mean, rstd = N.instnorm_drop_add_fwd(x, _c(residual), eps, p, seed)
+        ctx.save_for_backward(x, mean, rstd)
+        ctx.cfg = (p, seed)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd = ctx.saved_tensors
+        p, seed = ctx.cfg
+        dy = _c(dy)
+        dx = N.instnorm_drop_bwd(dy, x, mean, rstd, p, seed) if ctx.needs_input_grad[0] else None
+        return dx, (dy if ctx.needs_input_grad[1] else None), None, None, None
+
+
 class BatchNormTrainFn(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, run_mean, run_var, eps, momentum, act, slope):

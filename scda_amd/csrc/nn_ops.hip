@@ -418,14 +418,31 @@ __device__ __forceinline__ float inorm_act(float o, const int act, const float s
     return o;
 }
 
+// Tail of a residual block fused into the norm (INSResBlock: x + Dropout(IN(conv(..))), common_net.py:59-80): with `residual` set the
+// kernel writes residual + dropout(normalised value) -- the keep decision of element i from (seed, flat index i) exactly as
+// dropout_seeded_kernel makes it -- and the backward applies the same mask to dy before the norm's gradient.  Same arithmetic,
+// same bits as the three separate launches (norm, dropout, add); two launches and two passes over the map fewer each way.
+struct DropTail {
+    const float *residual;   // null: plain instance norm
+    unsigned thr;            // keep(i) = mix_hash(seed, i) >= thr
+    unsigned long long seed;
+    float scale;             // 1 / (1 - p)
+    int on;                  // backward: mask dy
+};
+
 template <int VPT>
 __global__ __launch_bounds__(1024) void instnorm_fwd_kernel(const float *__restrict__ x, float *__restrict__ y,
                                                             float *__restrict__ mean_out, float *__restrict__ rstd_out,
                                                             const int HW, const float eps, const int act,
-                                                            const float slope) {
+                                                            const float slope, const DropTail dt) {
     __shared__ float red[16];
     const size_t base = (size_t)blockIdx.x * HW;
     float mean, rstd;
+    auto tail = [&](float o, const size_t i) -> float {      // i: flat index into the tensor
+        if (!dt.residual) return o;
+        const float d = mix_hash(dt.seed, (uint64_t)i) >= dt.thr ? o * dt.scale : 0.f;
+        return d + dt.residual[i];
+    };
     if (VPT > 0) {
         const float4 *x4 = reinterpret_cast<const float4 *>(x + base);
         float4 v[VPT > 0 ? VPT : 1];
@@ -447,10 +464,11 @@ __global__ __launch_bounds__(1024) void instnorm_fwd_kernel(const float *__restr
 #pragma unroll
         for (int j = 0; j < VPT; ++j) {
             float4 o;
-            o.x = inorm_act((v[j].x - mean) * rstd, act, slope);
-            o.y = inorm_act((v[j].y - mean) * rstd, act, slope);
-            o.z = inorm_act((v[j].z - mean) * rstd, act, slope);
-            o.w = inorm_act((v[j].w - mean) * rstd, act, slope);
+            const size_t i0 = base + 4 * (size_t)(j * 1024 + threadIdx.x);
+            o.x = tail(inorm_act((v[j].x - mean) * rstd, act, slope), i0);
+            o.y = tail(inorm_act((v[j].y - mean) * rstd, act, slope), i0 + 1);
+            o.z = tail(inorm_act((v[j].z - mean) * rstd, act, slope), i0 + 2);
+            o.w = tail(inorm_act((v[j].w - mean) * rstd, act, slope), i0 + 3);
             y4[j * 1024 + threadIdx.x] = o;
         }
     } else {
@@ -460,7 +478,7 @@ __global__ __launch_bounds__(1024) void instnorm_fwd_kernel(const float *__restr
         float q = 0.f;
         for (int i = threadIdx.x; i < HW; i += blockDim.x) { const float d = x[base + i] - mean; q += d * d; }
         rstd = 1.f / sqrtf(block_sum(q, red) / (float)HW + eps);
-        for (int i = threadIdx.x; i < HW; i += blockDim.x) y[base + i] = inorm_act((x[base + i] - mean) * rstd, act, slope);
+        for (int i = threadIdx.x; i < HW; i += blockDim.x) y[base + i] = tail(inorm_act((x[base + i] - mean) * rstd, act, slope), base + i);
     }
     if (threadIdx.x == 0) { mean_out[blockIdx.x] = mean; rstd_out[blockIdx.x] = rstd; }
 }
@@ -472,10 +490,14 @@ template <int VPT, bool CACHE_X>
 __global__ __launch_bounds__(1024) void instnorm_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ x,
                                                             const float *__restrict__ mean_in,
                                                             const float *__restrict__ rstd_in, float *__restrict__ dx,
-                                                            const int HW, const int act, const float slope) {
+                                                            const int HW, const int act, const float slope, const DropTail dt) {
     __shared__ float red[16];
     const size_t base = (size_t)blockIdx.x * HW;
     const float mean = mean_in[blockIdx.x], rstd = rstd_in[blockIdx.x];
+    auto drop = [&](float g, const size_t i) -> float {      // the fused dropout's gradient (see DropTail)
+        if (!dt.on) return g;
+        return mix_hash(dt.seed, (uint64_t)i) >= dt.thr ? g * dt.scale : 0.f;
+    };
     auto gate = [&](float g, float xh) -> float {
         if (act == 1) return xh > 0.f ? g : 0.f;
         if (act == 2) return xh > 0.f ? g : g * slope;
@@ -492,7 +514,10 @@ __global__ __launch_bounds__(1024) void instnorm_bwd_kernel(const float *__restr
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int j = 0; j < VPT; ++j) {
-            const float4 xh = norm4(x4[j * 1024 + threadIdx.x]), gv = g4[j * 1024 + threadIdx.x];
+            const float4 xh = norm4(x4[j * 1024 + threadIdx.x]);
+            float4 gv = g4[j * 1024 + threadIdx.x];
+            const size_t i0 = base + 4 * (size_t)(j * 1024 + threadIdx.x);
+            gv.x = drop(gv.x, i0); gv.y = drop(gv.y, i0 + 1); gv.z = drop(gv.z, i0 + 2); gv.w = drop(gv.w, i0 + 3);
             if (CACHE_X) xc[j] = xh;
             g[j].x = gate(gv.x, xh.x); g[j].y = gate(gv.y, xh.y); g[j].z = gate(gv.z, xh.z); g[j].w = gate(gv.w, xh.w);
             s1 += (g[j].x + g[j].y) + (g[j].z + g[j].w);
@@ -513,7 +538,7 @@ __global__ __launch_bounds__(1024) void instnorm_bwd_kernel(const float *__restr
         float s1 = 0.f, s2 = 0.f;
         for (int i = threadIdx.x; i < HW; i += blockDim.x) {
             const float xh = (x[base + i] - mean) * rstd;
-            const float g = gate(dy[base + i], xh);
+            const float g = gate(drop(dy[base + i], base + i), xh);
             s1 += g;
             s2 += g * xh;
         }
@@ -521,7 +546,7 @@ __global__ __launch_bounds__(1024) void instnorm_bwd_kernel(const float *__restr
         const float m2 = block_sum(s2, red) / (float)HW;
         for (int i = threadIdx.x; i < HW; i += blockDim.x) {
             const float xh = (x[base + i] - mean) * rstd;
-            dx[base + i] = rstd * (gate(dy[base + i], xh) - m1 - xh * m2);
+            dx[base + i] = rstd * (gate(drop(dy[base + i], base + i), xh) - m1 - xh * m2);
         }
     }
 }
@@ -1295,11 +1320,15 @@ SCDA_API int scda_smooth_l1_bwd_hip(const float *pred, const float *mask, const 
     return launch_status("smooth_l1_bwd_kernel");
 }
 
-SCDA_API int scda_instnorm_fwd_hip(const float *x, float *y, float *mean, float *rstd, int planes, int HW, float eps,
-                                   int act, float slope, void *stream) {
-    NN_CHECK(x && y && mean && rstd && planes > 0 && HW > 0, "scda_instnorm_fwd_hip")
-    const bool al = ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0;
-#define INORM_FWD(V) hipLaunchKernelGGL(instnorm_fwd_kernel<V>, dim3(planes), dim3(1024), 0, as_stream(stream), x, y, mean, rstd, HW, eps, act, slope)
+static unsigned drop_threshold(float p) {
+    const double t = (double)p * 4294967296.0;
+    return (unsigned)(t > 4294967295.0 ? 4294967295.0 : t);
+}
+
+static int instnorm_fwd_launch(const float *x, float *y, float *mean, float *rstd, int planes, int HW, float eps, int act, float slope,
+                               const DropTail dt, void *stream) {
+    const bool al = ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)dt.residual)) & 15) == 0;
+#define INORM_FWD(V) hipLaunchKernelGGL(instnorm_fwd_kernel<V>, dim3(planes), dim3(1024), 0, as_stream(stream), x, y, mean, rstd, HW, eps, act, slope, dt)
     if (al && HW == 4096) INORM_FWD(1);
     else if (al && HW == 16384) INORM_FWD(4);
     else if (al && HW == 65536) INORM_FWD(16);
@@ -1308,17 +1337,42 @@ SCDA_API int scda_instnorm_fwd_hip(const float *x, float *y, float *mean, float 
     return launch_status("instnorm_fwd_kernel");
 }
 
-SCDA_API int scda_instnorm_bwd_hip(const float *dy, const float *x, const float *mean, const float *rstd, float *dx,
-                                   int planes, int HW, int act, float slope, void *stream) {
-    NN_CHECK(dy && x && mean && rstd && dx && planes > 0 && HW > 0, "scda_instnorm_bwd_hip")
+static int instnorm_bwd_launch(const float *dy, const float *x, const float *mean, const float *rstd, float *dx, int planes, int HW,
+                               int act, float slope, const DropTail dt, void *stream) {
     const bool al = ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx)) & 15) == 0;
-#define INORM_BWD(V, CX) hipLaunchKernelGGL((instnorm_bwd_kernel<V, CX>), dim3(planes), dim3(1024), 0, as_stream(stream), dy, x, mean, rstd, dx, HW, act, slope)
+#define INORM_BWD(V, CX) hipLaunchKernelGGL((instnorm_bwd_kernel<V, CX>), dim3(planes), dim3(1024), 0, as_stream(stream), dy, x, mean, rstd, dx, HW, act, slope, dt)
     if (al && HW == 4096) INORM_BWD(1, true);
     else if (al && HW == 16384) INORM_BWD(4, true);
     else if (al && HW == 65536) INORM_BWD(16, false);
     else INORM_BWD(0, false);
 #undef INORM_BWD
     return launch_status("instnorm_bwd_kernel");
+}
+
+SCDA_API int scda_instnorm_fwd_hip(const float *x, float *y, float *mean, float *rstd, int planes, int HW, float eps,
+                                   int act, float slope, void *stream) {
+    NN_CHECK(x && y && mean && rstd && planes > 0 && HW > 0, "scda_instnorm_fwd_hip")
+    return instnorm_fwd_launch(x, y, mean, rstd, planes, HW, eps, act, slope, DropTail{nullptr, 0u, 0ull, 1.f, 0}, stream);
+}
+
+SCDA_API int scda_instnorm_bwd_hip(const float *dy, const float *x, const float *mean, const float *rstd, float *dx,
+                                   int planes, int HW, int act, float slope, void *stream) {
+    NN_CHECK(dy && x && mean && rstd && dx && planes > 0 && HW > 0, "scda_instnorm_bwd_hip")
+    return instnorm_bwd_launch(dy, x, mean, rstd, dx, planes, HW, act, slope, DropTail{nullptr, 0u, 0ull, 1.f, 0}, stream);
+}
+
+// y = residual + dropout_p,seed(instance_norm(x)): the tail of a residual block in one launch (see DropTail)
+SCDA_API int scda_instnorm_drop_add_fwd_hip(const float *x, const float *residual, float *y, float *mean, float *rstd, int planes,
+                                            int HW, float eps, float p, uint64_t seed, float scale, void *stream) {
+    NN_CHECK(x && residual && y && mean && rstd && planes > 0 && HW > 0 && p >= 0.f && p < 1.f, "scda_instnorm_drop_add_fwd_hip")
+    return instnorm_fwd_launch(x, y, mean, rstd, planes, HW, eps, 0, 0.f, DropTail{residual, drop_threshold(p), seed, scale, 1}, stream);
+}
+
+// dx of the same: the dropout's mask (recomputed from the seed) applied to dy, then the norm's gradient
+SCDA_API int scda_instnorm_drop_bwd_hip(const float *dy, const float *x, const float *mean, const float *rstd, float *dx, int planes,
+                                        int HW, float p, uint64_t seed, float scale, void *stream) {
+    NN_CHECK(dy && x && mean && rstd && dx && planes > 0 && HW > 0 && p >= 0.f && p < 1.f, "scda_instnorm_drop_bwd_hip")
+    return instnorm_bwd_launch(dy, x, mean, rstd, dx, planes, HW, 0, 0.f, DropTail{nullptr, drop_threshold(p), seed, scale, 1}, stream);
 }
 
 SCDA_API size_t scda_batchnorm_workspace_bytes(int B, int C, int HW) {

@@ -3,10 +3,13 @@ models/faster_rcnn/common_net.py (only the blocks the SCDA path instantiates: :5
 :205-245, :251-293).  Every conv / norm / activation runs on the HIP kernels; norm+activation pairs are one
 kernel, conv+LeakyReLU pairs are the conv's epilogue.  nn.Sequential indices (hence state_dict keys such as
 `model.0.weight`, `model.3.weight`) are identical to the reference's."""
+import os
+
+import torch
 import torch.nn as nn
 
 from scda_amd import layers as L
-from scda_amd.autograd_ops import ACT_LEAKY, ACT_NONE, ACT_RELU, AddFn
+from scda_amd.autograd_ops import ACT_LEAKY, ACT_NONE, ACT_RELU, AddFn, InstNormDropAddFn
 from scda_amd.dropin.models.faster_rcnn.init import gaussian_weights_init, xavier_weights_init  # noqa: F401
 
 
@@ -26,6 +29,15 @@ class INSResBlock(nn.Module):
         self.model.apply(gaussian_weights_init)
 
     def forward(self, x):
+        tail = self.model[-2:]
+        if (len(self.model) == 6 and self.training and isinstance(tail[0], L.InstanceNorm2d) and tail[0].fused_act == ACT_NONE
+                and isinstance(tail[1], L.Dropout) and 0.0 < tail[1].p < 1.0 and L.Dropout.mask_source is None and x.is_cuda
+                and not os.environ.get("SCDA_NO_RESBLOCK_TAIL_FUSION")):
+            # IN -> Dropout -> (+ x) in one launch each way (autograd_ops.InstNormDropAddFn); the seed is drawn where the un-fused
+            # Dropout module draws it, so the torch generator is consumed identically
+            h = self.model[:-2](x)
+            seed = int(torch.randint(0, 1 << 62, (1,), dtype=torch.int64))
+            return InstNormDropAddFn.apply(h, x, tail[0].eps, tail[1].p, seed)
         return AddFn.apply(self.model(x), x)
 
 

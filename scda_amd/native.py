@@ -729,6 +729,29 @@ def instnorm_bwd(dy, x, mean, rstd, act, slope):
     return dx
 
 
+def instnorm_drop_add_fwd(x, residual, eps, p, seed):
+    """residual + dropout_{p,seed}(instance_norm(x)) in one launch -> (y, mean, rstd)"""
+    _req(x, "x"); _req(residual, "residual")
+    if residual.shape != x.shape:
+        raise ValueError("residual must have the shape of x")
+    B, C, H, W = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(B * C, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(B * C, dtype=torch.float32, device=x.device)
+    _check(lib().scda_instnorm_drop_add_fwd_hip(_p(x), _p(residual), _p(y), _p(mean), _p(rstd), i32(B * C), i32(H * W), f32(eps), f32(p),
+                                                u64(seed & 0xFFFFFFFFFFFFFFFF), f32(1.0 / (1.0 - p)), _stream()), "scda_instnorm_drop_add_fwd_hip")
+    return y, mean, rstd
+
+
+def instnorm_drop_bwd(dy, x, mean, rstd, p, seed):
+    _req(dy, "dy"); _req(x, "x")
+    B, C, H, W = x.shape
+    dx = torch.empty_like(x)
+    _check(lib().scda_instnorm_drop_bwd_hip(_p(dy), _p(x), _p(mean), _p(rstd), _p(dx), i32(B * C), i32(H * W), f32(p),
+                                            u64(seed & 0xFFFFFFFFFFFFFFFF), f32(1.0 / (1.0 - p)), _stream()), "scda_instnorm_drop_bwd_hip")
+    return dx
+
+
 def _bn_ws(B, C, HW, device):
     L = lib()
     L.scda_batchnorm_workspace_bytes.restype = ctypes.c_size_t

@@ -389,3 +389,40 @@ def test_lazily_zeroed_dense_gradients(cuda):
     flat.check_aliases(); flat.finalize_grads()
     assert flat._inside(net[0].weight.grad, flat.grad) and not flat.fresh
     assert float(outside.abs().sum()) > 0 and torch.equal(net[0].weight.grad, outside)
+
+
+@pytest.mark.parametrize("shape", [(4, 128, 64, 64), (2, 3, 128, 128), (1, 2, 256, 256), (2, 5, 9, 13)])
+def test_resblock_tail_fused_equals_three_launches(cuda, shape):
+    """x + Dropout(InstanceNorm(h)) as ONE launch each way (autograd_ops.InstNormDropAddFn: the register-resident plane kernels for
+    64x64 / 128x128 / 256x256 maps, the generic one otherwise) against InstanceNormFn -> DropoutSeededFn -> AddFn: outputs and both
+    gradients bit for bit"""
+    from scda_amd import autograd_ops as A
+    g = gen(91)
+    h = torch.randn(*shape, generator=g).to(cuda); x = torch.randn(*shape, generator=g).to(cuda); dy = torch.randn(*shape, generator=g).to(cuda)
+    seed, p = 0x1234567890ABCDE, 0.5
+    h1, x1 = h.clone().requires_grad_(), x.clone().requires_grad_()
+    y1 = A.InstNormDropAddFn.apply(h1, x1, 1e-5, p, seed); y1.backward(dy)
+    h2, x2 = h.clone().requires_grad_(), x.clone().requires_grad_()
+    y2 = A.AddFn.apply(A.DropoutSeededFn.apply(A.InstanceNormFn.apply(h2, 1e-5, A.ACT_NONE, 0.0), p, seed, False), x2); y2.backward(dy)
+    assert torch.equal(y1, y2) and torch.equal(h1.grad, h2.grad) and torch.equal(x1.grad, x2.grad)
+    kept = float((y1 != x).float().mean())
+    assert 0.4 < kept < 0.6, kept
+
+
+def test_ins_res_block_uses_fused_tail(cuda, monkeypatch):
+    """the decoder's residual block with and without the fused tail (SCDA_NO_RESBLOCK_TAIL_FUSION=1): same seed draw, same results"""
+    from scda_amd.dropin.models.faster_rcnn.common_net import INSResBlock
+    torch.manual_seed(3)
+    blk = INSResBlock(16, 16, dropout=0.5).to(cuda).train()
+    x = torch.randn(2, 16, 64, 64, generator=gen(92)).to(cuda)
+    outs = []
+    for off in ("", "1"):
+        if off:
+            monkeypatch.setenv("SCDA_NO_RESBLOCK_TAIL_FUSION", off)
+        torch.manual_seed(7)
+        xi = x.clone().requires_grad_()
+        y = blk(xi); y.square().sum().backward()
+        outs.append((y.detach().clone(), xi.grad.clone(), [p.grad.clone() for p in blk.parameters()], torch.rand(1).item()))
+        blk.zero_grad()
+    a, b = outs
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and all(torch.equal(u, v) for u, v in zip(a[2], b[2])) and a[3] == b[3]
