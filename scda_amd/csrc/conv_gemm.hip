@@ -480,12 +480,38 @@ __global__ __launch_bounds__((ConvGldsCfg<BM, BN>::THREADS)) void conv_igemm_gld
 }
 
 // split-K reduce for conv outputs: fixed summation order s = 0..splits-1
+// VEC: four consecutive pixels per thread with 16-byte loads / stores (N and the plane size multiples of 4: a group never straddles
+// two output channels or two images); same additions in the same order per element as the scalar form.
+template <bool VEC>
 __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float *__restrict__ ws, const int splits,
                                                                  const int M, const int N, const Div dPHW,
                                                                  const float *__restrict__ bias, const int act,
                                                                  const float slope, float *__restrict__ out,
                                                                  const float *__restrict__ mask_src, const float mask_slope) {
     const long long total = (long long)M * N;
+    if (VEC) {
+        typedef float f32x4_t __attribute__((ext_vector_type(4)));
+        const long long quads = total >> 2;
+        for (long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x; q < quads; q += (long long)blockDim.x * gridDim.x) {
+            const long long idx = q << 2;
+            const int m = (int)(idx / N), n = (int)(idx - (long long)m * N);
+            f32x4_t v = {0.f, 0.f, 0.f, 0.f};
+            for (int s = 0; s < splits; ++s) v += *reinterpret_cast<const f32x4_t *>(ws + (size_t)s * total + idx);
+            if (bias) v += bias[m];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = apply_act(v[k], act, slope);
+            int img, pix;
+            dPHW.divmod(n, img, pix);
+            const size_t o = ((size_t)img * M + m) * dPHW.d + pix;
+            if (mask_src) {
+                const f32x4_t ms = *reinterpret_cast<const f32x4_t *>(mask_src + o);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = ms[k] > 0.f ? v[k] : v[k] * mask_slope;
+            }
+            *reinterpret_cast<f32x4_t *>(out + o) = v;
+        }
+        return;
+    }
     for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
          idx += (long long)blockDim.x * gridDim.x) {
         const int m = (int)(idx / N), n = (int)(idx - (long long)m * N);
@@ -899,7 +925,10 @@ __global__ __launch_bounds__((WgradGldsCfg<BM, BN>::THREADS)) void conv_wgrad_gl
 // G = split groups per element: a workgroup covers 256/G consecutive elements, thread (g, e) adds the slabs s = g, g+G, ...
 // (independent, pipelined loads), the G partial sums are combined in fixed order through LDS.  With one thread per element
 // (G = 1) a 150-way split of a small weight matrix was 150 dependent loads on 144 workgroups: 0.8 TB/s, 2.2 ms/iteration.
-template <int G>
+// VEC: a thread owns FOUR consecutive elements (16-byte loads of every slab, 16-byte read-modify-write of the destination; total %
+// 4 == 0, no bias): the same additions in the same order per element, a quarter of the memory instructions -- the weight-gradient
+// reduces (14 - 100 slabs of a 0.1 - 2.4 M-element matrix) ran at 1.4 TB/s in the scalar form.
+template <int G, bool VEC>
 __global__ __launch_bounds__(256) void dense_splitk_reduce_kernel(const float *__restrict__ ws, const int splits,
                                                                   const long long total, const int N,
                                                                   const float *__restrict__ bias, const int bias_on_n,
@@ -908,28 +937,54 @@ __global__ __launch_bounds__(256) void dense_splitk_reduce_kernel(const float *_
                                                                   const float *__restrict__ db_ws, float *__restrict__ db,
                                                                   const int db_n, const int db_accumulate) {
     constexpr int E = 256 / G;
-    __shared__ float part[G][E + 1];
+    constexpr int W = VEC ? 4 : 1;
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    __shared__ float part[G][W * E + 1];
     const int e = threadIdx.x % E, g = threadIdx.x / E;
-    for (long long base = (long long)blockIdx.x * E; base < total; base += (long long)gridDim.x * E) {
-        const long long idx = base + e;
-        float v = 0.f;
+    for (long long base = (long long)blockIdx.x * (E * W); base < total; base += (long long)gridDim.x * (E * W)) {
+        const long long idx = base + (long long)e * W;
+        float v[W];
+#pragma unroll
+        for (int k = 0; k < W; ++k) v[k] = 0.f;
         if (idx < total) {
+            if (VEC) {
+                f32x4_t a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
-            for (int s = g; s < splits; s += G) v += ws[(size_t)s * total + idx];
+                for (int s = g; s < splits; s += G) a += *reinterpret_cast<const f32x4_t *>(ws + (size_t)s * total + idx);
+#pragma unroll
+                for (int k = 0; k < W; ++k) v[k] = a[k];
+            } else {
+#pragma unroll 4
+                for (int s = g; s < splits; s += G) v[0] += ws[(size_t)s * total + idx];
+            }
         }
         if (G > 1) {
-            part[g][e] = v;
+#pragma unroll
+            for (int k = 0; k < W; ++k) part[g][e * W + k] = v[k];
             __syncthreads();
             if (g == 0) {
-                v = 0.f;
 #pragma unroll
-                for (int i = 0; i < G; ++i) v += part[i][e];
+                for (int k = 0; k < W; ++k) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int i = 0; i < G; ++i) t += part[i][e * W + k];
+                    v[k] = t;
+                }
             }
         }
         if (g == 0 && idx < total) {
-            if (bias) v += bias_on_n ? bias[idx % N] : bias[idx / N];
-            v = apply_act(v, act, slope);
-            out[idx] = accumulate ? out[idx] + v : v;
+            if (VEC) {
+                f32x4_t o = {v[0], v[1], v[2], v[3]};
+#pragma unroll
+                for (int k = 0; k < W; ++k) o[k] = apply_act(o[k], act, slope);
+                f32x4_t *dst = reinterpret_cast<f32x4_t *>(out + idx);
+                *dst = accumulate ? *dst + o : o;
+            } else {
+                float t = v[0];
+                if (bias) t += bias_on_n ? bias[idx % N] : bias[idx / N];
+                t = apply_act(t, act, slope);
+                out[idx] = accumulate ? out[idx] + t : t;
+            }
         }
         if (G > 1) __syncthreads();
     }
@@ -956,9 +1011,16 @@ __global__ __launch_bounds__(256) void dense_splitk_reduce_kernel(const float *_
 static int launch_dense_reduce(const float *ws, int splits, long long total, int N, const float *bias, int bias_on_n, int act,
                                float slope, int accumulate, float *out, const float *db_ws, float *db, int db_n,
                                int db_accumulate, hipStream_t st) {
+    const bool vec = !bias && (total & 3) == 0 && ((((uintptr_t)ws) | ((uintptr_t)out)) & 15) == 0;
 #define DENSE_REDUCE(G_)                                                                                                 \
-    hipLaunchKernelGGL(dense_splitk_reduce_kernel<G_>, dim3(ew_grid(total * G_)), dim3(256), 0, st, ws, splits, total, N, bias, \
-                       bias_on_n, act, slope, accumulate, out, db_ws, db, db_n, db_accumulate)
+    do {                                                                                                                 \
+        if (vec)                                                                                                         \
+            hipLaunchKernelGGL((dense_splitk_reduce_kernel<G_, true>), dim3(ew_grid(total / 4 * G_)), dim3(256), 0, st, ws, splits, total, N, bias, \
+                               bias_on_n, act, slope, accumulate, out, db_ws, db, db_n, db_accumulate);                    \
+        else                                                                                                             \
+            hipLaunchKernelGGL((dense_splitk_reduce_kernel<G_, false>), dim3(ew_grid(total * G_)), dim3(256), 0, st, ws, splits, total, N, bias, \
+                               bias_on_n, act, slope, accumulate, out, db_ws, db, db_n, db_accumulate);                    \
+    } while (0)
     if (splits >= 32) DENSE_REDUCE(8);
     else if (splits >= 8) DENSE_REDUCE(4);
     else DENSE_REDUCE(1);
@@ -1599,8 +1661,13 @@ static int launch_conv(const float *Wm, const float *X, const ConvGeom &g0, Epi 
     prof_end(st);
     int rc = launch_status("conv_igemm_kernel");
     if (rc || splits == 1) return rc;
-    hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(ew_grid((long long)g.M * g.N)), dim3(256), 0, st, ws, splits, g.M,
-                       g.N, g.dPHW, e.bias, e.act, e.slope, e.out, e.mask_src, e.mask_slope);
+    const bool vec = (g.N & 3) == 0 && (g.dPHW.d & 3) == 0 && ((((uintptr_t)ws) | ((uintptr_t)e.out) | ((uintptr_t)e.mask_src)) & 15) == 0;
+    if (vec)
+        hipLaunchKernelGGL(conv_splitk_reduce_kernel<true>, dim3(ew_grid(((long long)g.M * g.N) >> 2)), dim3(256), 0, st, ws, splits, g.M,
+                           g.N, g.dPHW, e.bias, e.act, e.slope, e.out, e.mask_src, e.mask_slope);
+    else
+        hipLaunchKernelGGL(conv_splitk_reduce_kernel<false>, dim3(ew_grid((long long)g.M * g.N)), dim3(256), 0, st, ws, splits, g.M,
+                           g.N, g.dPHW, e.bias, e.act, e.slope, e.out, e.mask_src, e.mask_slope);
     return launch_status("conv_splitk_reduce_kernel");
 }
 
