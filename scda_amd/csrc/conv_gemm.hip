@@ -73,7 +73,34 @@ struct ConvGeom {
                       // tested on py % row_period against row_period instead of py against the image height.  0: plain image.
     const float *zp;  // zero page: source of every out-of-range gather lane
     Div dPHW, dPW, dCB;
+    // Stride-2 data gradient, PARITY classes (direct-to-LDS kernel, even PH / PW).  Tap (kh, kw) contributes to input pixel (py, px)
+    // only where py + pad - kh and px + pad - kw are even: with the pixels in their natural order every tile holds all four
+    // (py & 1, px & 1) classes, so every one of the KH x KW taps has to be walked although three quarters of the products are zero.
+    // parity = 1 renumbers the N axis class by class -- n = cls * ncp + (index inside the class, padded to whole tiles), cls =
+    // (py & 1) * 2 + (px & 1) -- so that a tile belongs to ONE class and its K loop visits only that class's taps (1 + 2 + 2 + 4
+    // of the 9 for 3x3: a quarter of the slabs).  Same products, same order per output element.
+    int parity, nc, ncp;   // pixels per class (batch * PH/2 * PW/2), the same rounded up to whole tiles
+    Div dNCP, dPQ, dPQW;   // ncp; PH/2 * PW/2; PW/2
 };
+
+// pixel of logical N index n: false if n is padding
+__device__ __forceinline__ bool conv_n_to_pixel(const ConvGeom &g, const int n, int &img, int &py, int &px) {
+    if (!g.parity) {
+        if (n >= g.N) { img = py = px = 0; return false; }
+        int pix;
+        g.dPHW.divmod(n, img, pix);
+        g.dPW.divmod(pix, py, px);
+        return true;
+    }
+    int cls, c, rem, i, j;
+    g.dNCP.divmod(n, cls, c);
+    if (c >= g.nc) { img = py = px = 0; return false; }
+    g.dPQ.divmod(c, img, rem);
+    g.dPQW.divmod(rem, i, j);
+    py = 2 * i + (cls >> 1);
+    px = 2 * j + (cls & 1);
+    return true;
+}
 
 struct Epi {
     float *out;          // final destination (when splits == 1)
@@ -124,10 +151,11 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[WM / 32][WN / 32], c
     const int lr = lane & 31;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * WN + j * 32 + lr;
-        if (n >= g.N) continue;
-        int oimg, opix;
-        g.dPHW.divmod(n, oimg, opix);
+        int n = n0 + wn * WN + j * 32 + lr;
+        int oimg, opix, opy, opx;
+        if (!conv_n_to_pixel(g, n, oimg, opy, opx)) continue;
+        opix = opy * g.PW + opx;
+        n = oimg * g.dPHW.d + opix;          // natural index of the pixel (== the logical one unless the N axis is class-major)
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -343,8 +371,20 @@ __global__ __launch_bounds__((ConvGldsCfg<BM, BN>::THREADS)) void conv_igemm_gld
     int tx, ty, tz;
     tile_coords(g.nx, g.ny, g.swz, tx, ty, tz);
     const int m0 = ty * BM, n0 = tx * BN;
-    const int s_begin = tz * (g.k_per_split / BK);
-    const int s_end = min(g.K, (tz + 1) * g.k_per_split) / BK;
+    // parity classes (ConvGeom::parity): this tile's class and its taps kh = k0h + 2 i, kw = k0w + 2 j; its K loop has
+    // CB/16 * nt slabs, split evenly.  Otherwise the K-slab range of this split.
+    int k0h = 0, k0w = 0, ntw = KW, nt = KH * KW;
+    int s_begin = tz * (g.k_per_split / BK);
+    int s_end = min(g.K, (tz + 1) * g.k_per_split) / BK;
+    if (S == 2 && DGRAD && g.parity) {
+        const int cls = __builtin_amdgcn_readfirstlane(g.dNCP.div(n0));
+        k0h = ((cls >> 1) + g.pad) & 1; k0w = ((cls & 1) + g.pad) & 1;
+        ntw = (KW - k0w + 1) >> 1;
+        nt = ((KH - k0h + 1) >> 1) * ntw;
+        const int slabs = (g.CB / BK) * nt, per = (slabs + e.splits - 1) / e.splits;
+        s_begin = min(slabs, tz * per);
+        s_end = min(slabs, s_begin + per);
+    }
 
     if (wave >= NWC) {
         // ---- staging wave p: A instructions [p*A_PP, (p+1)*A_PP), B rows [p*ROWS_PP, (p+1)*ROWS_PP) of every slab ----------
@@ -366,18 +406,21 @@ __global__ __launch_bounds__((ConvGldsCfg<BM, BN>::THREADS)) void conv_igemm_gld
         // lane's offset, two divisions included, for every slab: the discriminators' stride-2 data gradients ran at 11-25 TFLOP/s.)
         constexpr bool FAST = KH * KW <= 32 && S <= 2;
         const int plane = g.HB * g.WB;
-        const int img_first = __builtin_amdgcn_readfirstlane(g.dPHW.div(n0));
+        int img_first;
+        {
+            int fy, fx;
+            conv_n_to_pixel(g, n0, img_first, fy, fx);     // a tile's first pixel is never padding
+            img_first = __builtin_amdgcn_readfirstlane(img_first);
+        }
         const char *xbase = reinterpret_cast<const char *>(X + ((size_t)img_first * g.CB + p * C::ROWS_PP) * plane);
         int lane_img[HALVES], lane_base[HALVES], py[HALVES], px[HALVES];
         unsigned off_taps[HALVES];   // bit r set: tap r of the lane's pixel reads padding (or the pixel is beyond N)
         bool n_ok[HALVES];
 #pragma unroll
         for (int h = 0; h < HALVES; ++h) {
-            const int n_glob = n0 + h * 64 + lane;
-            n_ok[h] = n_glob < g.N;
-            int img, pix;
-            g.dPHW.divmod(n_ok[h] ? n_glob : 0, img, pix);
-            g.dPW.divmod(pix, py[h], px[h]);
+            int img;
+            n_ok[h] = conv_n_to_pixel(g, n0 + h * 64 + lane, img, py[h], px[h]);
+            if (!n_ok[h]) img = img_first;
             lane_img[h] = (img - img_first) * g.CB * plane;
             lane_base[h] = 0; off_taps[h] = 0;
             if (FAST) {
@@ -397,13 +440,21 @@ __global__ __launch_bounds__((ConvGldsCfg<BM, BN>::THREADS)) void conv_igemm_gld
         auto issue = [&](int s, int buf) {
             float *Ab = lds + buf * STAGE + a_first * BM;
             float *Bb = lds + buf * STAGE + BK * BM + (p * C::ROWS_PP) * BN;
-            const char *wa = wbase + (size_t)s * BK * g.mpad * 4;
+            int cb, r, kh, kw;
+            if (S == 2 && DGRAD && g.parity) {      // slab s of this class: channel block s / nt, its (s % nt)-th tap
+                cb = s / nt;
+                const int ti = s - cb * nt, th = ti / ntw;
+                kh = k0h + 2 * th; kw = k0w + 2 * (ti - th * ntw);
+                r = kh * KW + kw;
+            } else {
+                cb = s / (KH * KW); r = s - cb * (KH * KW);
+                kh = r / KW; kw = r - kh * KW;
+            }
+            const char *wa = wbase + (size_t)(cb * (KH * KW) + r) * BK * g.mpad * 4;
             if (!C::A_P0 || p == 0) {
 #pragma unroll
                 for (int i = 0; i < C::A_PP; ++i) buffer_load_lds_b128(wa, a_voff, Ab + i * A_RPI * BM, i * A_RPI * g.mpad * 4);
             }
-            const int cb = s / (KH * KW), r = s - cb * (KH * KW);
-            const int kh = r / KW, kw = r - kh * KW;
             const char *xs = xbase + (size_t)cb * BK * plane * 4;
 #pragma unroll
             for (int h = 0; h < HALVES; ++h) {
@@ -1596,8 +1647,12 @@ template <int KH, int KW, int S, bool DGRAD>
 static int launch_conv(const float *Wm, const float *X, const ConvGeom &g0, Epi e, float *ws, size_t ws_bytes,
                        hipStream_t st) {
     ConvGeom g = g0;
+    // stride-2 data gradient on the direct-to-LDS kernel: class-major N axis, a quarter of the K-slabs per tile (ConvGeom::parity)
+    static const bool no_parity = getenv("SCDA_CONV_NO_PARITY") != nullptr;   // A/B knob
+    const bool parity = S == 2 && DGRAD && g.slab_aligned && (g.PH % 2) == 0 && (g.PW % 2) == 0 && KH * KW <= 32 && !no_parity;
+    g.parity = 0; g.nc = g.ncp = 0;
     if (g.slab_aligned) {   // the LDS-DMA kernel addresses the images one tile touches with 32-bit lane offsets
-        const long long phw = (long long)g.PH * g.PW, per_image = (long long)g.CB * g.HB * g.WB * 4;
+        const long long phw = (long long)g.PH * g.PW / (parity ? 4 : 1), per_image = (long long)g.CB * g.HB * g.WB * 4;
         const long long images = std::min<long long>(g.batch, (256 + phw - 1) / phw + 1);
         if (images * per_image >= (1LL << 31)) {
             set_error("conv: %lld x %lld bytes of gathered tensor under one tile exceed the 2 GB a buffer descriptor addresses", images, per_image);
@@ -1611,7 +1666,9 @@ static int launch_conv(const float *Wm, const float *X, const ConvGeom &g0, Epi 
     const char *fbm = getenv("SCDA_CONV_BM");            // experiment / test knob: 256 forces the 8-wave tile where legal
     const bool bm256_ok = g.slab_aligned && (g.M % 256) == 0 && !fbn;
     static const bool no_one_tap = getenv("SCDA_PLAN_NO_ONE_TAP") != nullptr;   // A/B knob
-    LaunchPlan plan = plan_launch(g.M, g.N, g.K, BMv, fbn != 128, fbn != 64, false, ws_bytes, BK,
+    // parity classes: a launch is four GEMMs of N / 4 pixels and (on average) K / 4 each
+    const int planN = parity ? g.N / 4 : g.N, planK = parity ? std::max(BK, g.K / 4 / BK * BK) : g.K;
+    LaunchPlan plan = plan_launch(g.M, planN, planK, BMv, fbn != 128, fbn != 64, false, ws_bytes / (parity ? 4 : 1), BK,
                                   small_m && g.slab_aligned && !fbn, bm256_ok && !(fbm && atoi(fbm) != 256),
                                   KH * KW == 1 && g.slab_aligned && !no_one_tap);
     if (bm256_ok && fbm && atoi(fbm) == 256 && plan.bm != 256) {
@@ -1627,16 +1684,26 @@ static int launch_conv(const float *Wm, const float *X, const ConvGeom &g0, Epi 
         int fb = 0, fnn = 0, fs = 0;
         const bool forced = f && sscanf(f, "%d,%d,%d", &fb, &fnn, &fs) == 3;
         const bool legal = g.M <= 32 && g.slab_aligned && !fbn;
-        if (legal && (forced ? (fb == 32 && fnn == 256 && fs == 1) : (!no_bm32 && g.N >= 256 * 256))) plan = LaunchPlan{256, 1, 32};
+        if (legal && (forced ? (fb == 32 && fnn == 256 && fs == 1) : (!no_bm32 && planN >= (parity ? 64 * 256 : 256 * 256)))) plan = LaunchPlan{256, 1, 32};
     }
     const int BNv = plan.bn;
     const int BMt = plan.bm;                             // tile rows of this launch (BMv unless the 8-wave tile was chosen)
     int splits = plan.splits;
     g.k_per_split = round_k_per_split(g.K, splits);
     splits = cdiv(g.K, g.k_per_split);
+    g.nx = cdiv(g.N, BNv); g.ny = cdiv(g.M, BMt); g.swz = xcd_swizzle_enabled();
+    if (parity) {
+        const int pq = (g.PH / 2) * (g.PW / 2);
+        g.parity = 1;
+        g.nc = g.batch * pq;
+        g.ncp = cdiv(g.nc, BNv) * BNv;
+        g.dNCP = Div(g.ncp); g.dPQ = Div(pq); g.dPQW = Div(g.PW / 2);
+        g.nx = 4 * (g.ncp / BNv);
+        splits = std::max(1, std::min(plan.splits, (g.CB / BK) * KH * KW));   // the kernel divides each class's slabs evenly
+        while (splits > 1 && (size_t)splits * g.M * g.N * sizeof(float) > ws_bytes) --splits;
+    }
     e.splits = splits;
     e.ws = ws;
-    g.nx = cdiv(g.N, BNv); g.ny = cdiv(g.M, BMt); g.swz = xcd_swizzle_enabled();
     dim3 grid((unsigned)g.nx * g.ny * splits);
     note_plan(BMt, BNv, splits, g.slab_aligned);
     prof_begin(g.slab_aligned ? PK_CONV + ((DGRAD ? 2 : 0) + (BMt <= 64 ? 1 : 0)) * 3 + prof_shape(KH, S) : (int)PK_CONV_GATHER,

@@ -39,6 +39,8 @@ CONV_CASES = [
     (1, 256, 10, 14, 256, 3, 1, 1),
     (1, 32, 36, 26, 48, 3, 2, 1),     # output 18 x 13 = 234: not a multiple of 4 -> register-staged weight gradient
     (1, 32, 20, 28, 48, 3, 2, 1),     # output 10 x 14 = 140 = 8 slabs + 12 pixels
+    (3, 32, 20, 28, 48, 3, 2, 1),     # stride-2 data gradient by parity classes: 3 images x 140 pixels per class (ragged last tile, image seams inside tiles)
+    (2, 64, 12, 36, 512, 3, 2, 1),    # ... with a K long enough for split-K inside each class
 ]
 
 
