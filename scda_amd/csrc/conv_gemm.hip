@@ -737,18 +737,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
 // 32-bit offset is  A: a constant per instruction (row base + 16-byte chunk after the swizzle, or OOB for rows >= M)
 //                   B: pixel offset of the slab (cursor advanced by 16 pixels per slab, no division) + the row's (ci, tap)
 //                      constant, with bit 31 set from the tap-validity mask
+// The 32-row tile (<= 32 output channels: the decoders' 64 -> 32 stage, whose 64-row tile multiplied 32 rows of padding over 262144
+// pixels): compute waves 1 x 4; its dY tile is two LDS-DMA instructions per slab, issued by staging wave 0 alone (A_P0, as in
+// ConvGldsCfg).
 template <int BM, int BN>
 struct WgradGldsCfg {
-    static constexpr int NWC = BM == 256 ? 8 : 4;          // compute waves: WGM x 2
-    static constexpr int WGM = NWC / 2;
-    static constexpr int WM = BM / WGM, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    static constexpr int NWC = BM == 256 ? 8 : 4;          // compute waves: WGM x WGN
+    static constexpr int WGN = BM == 32 ? 4 : 2, WGM = NWC / WGN;
+    static constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
     static constexpr int A_TOTAL = BM / 16, GROUPS = BN / 4;   // LDS-DMA instructions per slab: dY (16 rows each), X (4 rows each)
     static constexpr int L_TOTAL = A_TOTAL + GROUPS;
     static constexpr int NP = 4;   // one swizzle class per staging wave (measured: 2 waves with two classes each lose 5-15 %)
-    static constexpr int A_PP = A_TOTAL / NP, CLS_PP = 4 / NP, G_PC = GROUPS / 4;   // per staging wave: A instr, classes; groups per class
-    static constexpr int L = A_PP + CLS_PP * G_PC;
+    static constexpr bool A_P0 = (A_TOTAL % NP) != 0;
+    static constexpr int A_PP = A_P0 ? A_TOTAL : A_TOTAL / NP, CLS_PP = 4 / NP, G_PC = GROUPS / 4;   // per staging wave: A instr, classes; groups per class
+    static constexpr int LB = CLS_PP * G_PC;
+    static constexpr int L = A_PP + LB;
     static constexpr int THREADS = (NWC + NP) * 64;
-    static_assert(A_TOTAL % NP == 0 && 2 * L <= 63, "staging split");
+    static_assert(2 * L <= 63 && WM >= 32 && WN >= 32, "staging split");
 };
 
 template <int BM, int BN, int KH, int KW, int S>
@@ -777,10 +782,11 @@ __global__ __launch_bounds__((WgradGldsCfg<BM, BN>::THREADS)) void conv_wgrad_gl
         const int p = wave - NWC;
         __builtin_amdgcn_s_setprio(3);
         constexpr unsigned OOB = 0x80000000u;
+        const int a_first = C::A_P0 ? 0 : p * C::A_PP;     // first dY instruction of the slab this wave issues
         unsigned a_voff[C::A_PP];
 #pragma unroll
         for (int i = 0; i < C::A_PP; ++i) {
-            const int row = (p * C::A_PP + i) * 16 + (lane >> 2);
+            const int row = (a_first + i) * 16 + (lane >> 2);
             const int c = (lane & 3) ^ ((row >> 2) & 3);
             a_voff[i] = m0 + row < g.M ? (unsigned)(((m0 + row) * ohw + 4 * c) * 4) : OOB;
         }
@@ -826,8 +832,10 @@ __global__ __launch_bounds__((WgradGldsCfg<BM, BN>::THREADS)) void conv_wgrad_gl
         auto issue = [&](int buf) {
             float *st = lds + buf * STAGE;
             const char *a_slab = a_img + (size_t)pix0 * 4;
+            if (!C::A_P0 || p == 0) {
 #pragma unroll
-            for (int i = 0; i < C::A_PP; ++i) buffer_load_lds_b128(a_slab, a_voff[i], st + (p * C::A_PP + i) * 16 * 16);
+                for (int i = 0; i < C::A_PP; ++i) buffer_load_lds_b128(a_slab, a_voff[i], st + (a_first + i) * 16 * 16);
+            }
             float *Bb = st + BK * BM;
             const bool wrap = pix0 + BK >= ohw;
             if (row_slab) {
@@ -887,9 +895,9 @@ __global__ __launch_bounds__((WgradGldsCfg<BM, BN>::THREADS)) void conv_wgrad_gl
         for (int s = s_begin; s < s_end; ++s) {
             if (s + 2 < s_end) {
                 issue(nbuf);
-                SCDA_WAIT_VMCNT(2 * L);
+                if (C::A_P0 && p != 0) SCDA_WAIT_VMCNT(2 * C::LB); else SCDA_WAIT_VMCNT(2 * L);
             } else if (s + 1 < s_end) {
-                SCDA_WAIT_VMCNT(L);
+                if (C::A_P0 && p != 0) SCDA_WAIT_VMCNT(C::LB); else SCDA_WAIT_VMCNT(L);
             } else {
                 SCDA_WAIT_VMCNT(0);
             }
@@ -900,7 +908,7 @@ __global__ __launch_bounds__((WgradGldsCfg<BM, BN>::THREADS)) void conv_wgrad_gl
     }
 
     // ---- compute waves ------------------------------------------------------------------------------------------------------
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / C::WGN, wn = wave % C::WGN;
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -1760,6 +1768,19 @@ static int launch_wgrad(const float *dY, const float *X, WgradGeom g, float *dW,
     LaunchPlan plan = plan_launch(g.M, g.N, g.K, small ? 64 : 128, BNv == 64, BNv == 128, true, ws_bytes, 32, false,
                                   bm256_ok && !(fbm && atoi(fbm) != 256));
     if (bm256_ok && fbm && atoi(fbm) == 256) plan.bm = 256;
+    // <= 32 output channels on the direct-to-LDS kernel: the 32 x 128 tile, same split count (SCDA_PLAN_FORCE=32,128,s forces it where
+    // legal; any other forced plan, or SCDA_WGRAD_NO_BM32, keeps it out)
+    {
+        static const bool no_bm32 = getenv("SCDA_WGRAD_NO_BM32") != nullptr;
+        const char *f = getenv("SCDA_PLAN_FORCE");
+        int fb = 0, fnn = 0, fs = 0;
+        const bool forced = f && sscanf(f, "%d,%d,%d", &fb, &fnn, &fs) == 3;
+        const bool legal = glds && g.M <= 32 && BNv == 128;
+        if (legal && (forced ? (fb == 32 && fnn == 128) : !no_bm32)) {
+            plan.bm = 32;
+            if (forced && fs >= 1 && (size_t)fs * g.M * g.N * sizeof(float) <= ws_bytes) plan.splits = fs;
+        }
+    }
     const int BMv = plan.bm;
     int splits = plan.splits;
     if ((size_t)splits * g.M * g.N * sizeof(float) > ws_bytes) { set_error("conv wgrad: workspace too small"); return SCDA_EINVAL; }
@@ -1783,6 +1804,8 @@ static int launch_wgrad(const float *dY, const float *X, WgradGeom g, float *dW,
 #define WGRAD_GLDS_LAUNCH(BM_, BN_) hipLaunchKernelGGL((conv_wgrad_glds_kernel<BM_, BN_, KH, KW, S>), grid, dim3(WgradGldsCfg<BM_, BN_>::THREADS), 0, st, dY, X, g, ws, db_ws)
     if (glds && BMv == 256) {
         hipLaunchKernelGGL((conv_wgrad_glds_kernel<256, 128, KH, KW, S>), grid, dim3(WgradGldsCfg<256, 128>::THREADS), 0, st, dY, X, g, ws, db_ws);
+    } else if (glds && BMv == 32) {
+        WGRAD_GLDS_LAUNCH(32, 128);
     } else if (glds) {
         if (small && BNv == 64) WGRAD_GLDS_LAUNCH(64, 64);
         else if (small) WGRAD_GLDS_LAUNCH(64, 128);

@@ -138,6 +138,9 @@ WGRAD = [
     (CONV4_1, (256, 128, 3)), (CONV4_1, (128, 128, 2)),
     (DIS_S2, (64, 128, 2)), (PATCH_S2, (256, 128, 2)), (PATCH_S2, (128, 128, 4)),
     (RPN_1x1, (64, 128, 2)), ((4, 32, 32, 32, 3, 1, 1, 0), (64, 64, 2)), (DEC_1x1, (128, 64, 4)),
+    # the 32-row tile: the decoders' 64 -> 32 stage, 24 output channels on a ragged map, stride 2
+    ((4, 64, 32, 32, 32, 3, 1, 1), (32, 128, 4)), ((4, 64, 32, 32, 32, 3, 1, 1), (32, 128, 1)), ((2, 32, 24, 40, 24, 3, 1, 1), (32, 128, 3)),
+    ((4, 32, 32, 32, 32, 3, 2, 1), (32, 128, 2)),
 ]
 
 
