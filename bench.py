@@ -255,6 +255,9 @@ def main():
     native.prof_enable(False)
     prof = native.prof_collect()
     template = None
+    if os.environ.get("SCDA_BENCH_NO_TEMPLATE_PASS"):     # profile collection: keep the trace to the warm-up + timed iterations
+        in_region = False
+        template = None
     if in_region and rank == 0:
         # the same kernel TEMPLATE over every tile shape it is launched with (the 64-row instantiations of the 64-channel layers and
         # of the GAN nets included): ~3x the launches, so its event pairs go into a pass of their own after the timed region

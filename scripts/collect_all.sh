@@ -20,6 +20,10 @@ if [ "${1:-}" = "--install" ]; then
   cp $S/resnet50/kernel_categories.md $D/${TAG}_resnet50_kernel_categories.md
   cp $S/resnet50_bench.json $D/${TAG}_resnet50_bench_1gpu.json
   cp $S/resnet50/exposed_time.md $D/${TAG}_resnet50_exposed_time.md
+  for f in device_phase_times.txt host_cpu.txt resnet50_plan_search.txt plan_search.txt s2_conv_layers.txt; do
+    [ -s $S/$f ] && cp $S/$f $D/${TAG}_$f
+  done
+  for f in $D/${TAG}_*; do [ -s $f ] || echo "WARNING: $f is empty"; done
   exit 0
 fi
 TAG=${1:-r02}
@@ -28,13 +32,17 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd $R
 bash scripts/collect_profiles.sh $TAG > $OUT/collect.log 2>&1
+export SCDA_BENCH_NO_TEMPLATE_PASS=1
 python scripts/kernel_categories.py $OUT/kernel_stats.md 13 > $OUT/kernel_categories.md
 ( cd /tmp; export TMPDIR=/tmp
   rocprofv3 --kernel-trace --output-format csv -d $OUT/kt_csv -o kt -- python $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline > $OUT/kt_csv.log 2>&1 )
 python scripts/exposed_time.py "$OUT/kt_csv/*kernel_trace.csv" 6 > $OUT/exposed_time.md
 rm -rf $OUT/kt_csv
-python scripts/shape_budget.py > $OUT/shape_budget.txt 2>/dev/null
-python scripts/bench_conv_layers.py > $OUT/conv_layers.txt 2>/dev/null
+python scripts/shape_budget.py > $OUT/shape_budget.txt 2> $OUT/shape_budget.err
+python scripts/bench_conv_layers.py > $OUT/conv_layers.txt 2> $OUT/conv_layers.err
+python scripts/device_phase_times.py > $OUT/device_phase_times.txt 2>/dev/null
+python scripts/time_s2_dgrad.py > $OUT/s2_conv_layers.txt 2>/dev/null
+( python scripts/host_cpu_use.py spin; python scripts/host_cpu_use.py block ) > $OUT/host_cpu.txt 2>/dev/null
 python bench.py --config resnet50 --steps 10 --warmup 4 --no-cpu-baseline > $OUT/resnet50_bench.json 2>/dev/null
 mkdir -p $OUT/resnet50
 bash scripts/kt.sh $TAG/resnet50 "--config resnet50" > $OUT/resnet50/kernel_categories.md 2>/dev/null
@@ -42,4 +50,8 @@ bash scripts/kt.sh $TAG/resnet50 "--config resnet50" > $OUT/resnet50/kernel_cate
   rocprofv3 --kernel-trace --output-format csv -d $OUT/kt_csv -o kt -- python $R/bench.py --config resnet50 --steps 6 --warmup 3 --no-cpu-baseline > $OUT/kt_csv.log 2>&1 )
 python scripts/exposed_time.py "$OUT/kt_csv/*kernel_trace.csv" 6 > $OUT/resnet50/exposed_time.md
 rm -rf $OUT/kt_csv
+if [ "${2:-}" = "full" ]; then
+  python scripts/tune_plans.py resnet > $OUT/resnet50_plan_search.txt 2>/dev/null
+  python scripts/tune_plans.py > $OUT/plan_search.txt 2>/dev/null
+fi
 cat $OUT/bench_1gpu.json

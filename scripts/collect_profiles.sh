@@ -11,6 +11,7 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 python $R/bench.py --steps 30 --warmup 8 > $OUT/bench_1gpu.json 2> $OUT/bench_1gpu.err
+export SCDA_BENCH_NO_TEMPLATE_PASS=1   # the traces below hold exactly warm-up + timed iterations
 rocprofv3 --kernel-trace --stats -d $OUT/kt -o prof -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/kt.log 2>&1
 grep '^{' $OUT/kt.log > $OUT/bench_under_rocprof.json
 for c in FETCH_SIZE WRITE_SIZE; do
