@@ -83,9 +83,12 @@ struct ConvGeom {
     Div dNCP, dPQ, dPQW;   // ncp; PH/2 * PW/2; PW/2
 };
 
-// pixel of logical N index n: false if n is padding
+// pixel of logical N index n: false if n is padding.  PP: the instantiation can run class-major at all (stride-2 data gradient);
+// every other instantiation keeps exactly the natural-order code (the 50-us decoder launches are sensitive to every extra
+// instruction of their prologue / staging stream: +11 % when this was a run-time branch for all of them).
+template <bool PP>
 __device__ __forceinline__ bool conv_n_to_pixel(const ConvGeom &g, const int n, int &img, int &py, int &px) {
-    if (!g.parity) {
+    if (!PP || !g.parity) {
         if (n >= g.N) { img = py = px = 0; return false; }
         int pix;
         g.dPHW.divmod(n, img, pix);
@@ -144,7 +147,7 @@ __device__ __forceinline__ int conv_tap_offset(const ConvGeom &g, const bool n_o
 }
 
 // accumulators -> split-K slab, or (+bias) -> activation -> NCHW output; lanes run along N (pixels): 128-byte row segments
-template <int WM, int WN>
+template <int WM, int WN, bool PP = false>
 __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[WM / 32][WN / 32], const ConvGeom &g, const Epi &e, const int m0,
                                               const int n0, const int tz, const int wm, const int wn, const int lane) {
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -152,10 +155,16 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[WM / 32][WN / 32], c
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         int n = n0 + wn * WN + j * 32 + lr;
-        int oimg, opix, opy, opx;
-        if (!conv_n_to_pixel(g, n, oimg, opy, opx)) continue;
-        opix = opy * g.PW + opx;
-        n = oimg * g.dPHW.d + opix;          // natural index of the pixel (== the logical one unless the N axis is class-major)
+        int oimg, opix;
+        if (PP && g.parity) {
+            int opy, opx;
+            if (!conv_n_to_pixel<true>(g, n, oimg, opy, opx)) continue;
+            opix = opy * g.PW + opx;
+            n = oimg * g.dPHW.d + opix;          // natural index of the pixel (the logical one is class-major)
+        } else {
+            if (n >= g.N) continue;
+            g.dPHW.divmod(n, oimg, opix);
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -406,11 +415,14 @@ __global__ __launch_bounds__((ConvGldsCfg<BM, BN>::THREADS)) void conv_igemm_gld
         // lane's offset, two divisions included, for every slab: the discriminators' stride-2 data gradients ran at 11-25 TFLOP/s.)
         constexpr bool FAST = KH * KW <= 32 && S <= 2;
         const int plane = g.HB * g.WB;
+        constexpr bool PP = S == 2 && DGRAD;
         int img_first;
-        {
+        if (PP && g.parity) {
             int fy, fx;
-            conv_n_to_pixel(g, n0, img_first, fy, fx);     // a tile's first pixel is never padding
+            conv_n_to_pixel<true>(g, n0, img_first, fy, fx);     // a tile's first pixel is never padding
             img_first = __builtin_amdgcn_readfirstlane(img_first);
+        } else {
+            img_first = __builtin_amdgcn_readfirstlane(g.dPHW.div(n0));
         }
         const char *xbase = reinterpret_cast<const char *>(X + ((size_t)img_first * g.CB + p * C::ROWS_PP) * plane);
         int lane_img[HALVES], lane_base[HALVES], py[HALVES], px[HALVES];
@@ -419,8 +431,16 @@ __global__ __launch_bounds__((ConvGldsCfg<BM, BN>::THREADS)) void conv_igemm_gld
 #pragma unroll
         for (int h = 0; h < HALVES; ++h) {
             int img;
-            n_ok[h] = conv_n_to_pixel(g, n0 + h * 64 + lane, img, py[h], px[h]);
-            if (!n_ok[h]) img = img_first;
+            if (PP && g.parity) {
+                n_ok[h] = conv_n_to_pixel<true>(g, n0 + h * 64 + lane, img, py[h], px[h]);
+                if (!n_ok[h]) img = img_first;
+            } else {
+                const int n_glob = n0 + h * 64 + lane;
+                n_ok[h] = n_glob < g.N;
+                int pix;
+                g.dPHW.divmod(n_ok[h] ? n_glob : 0, img, pix);
+                g.dPW.divmod(pix, py[h], px[h]);
+            }
             lane_img[h] = (img - img_first) * g.CB * plane;
             lane_base[h] = 0; off_taps[h] = 0;
             if (FAST) {
@@ -441,19 +461,22 @@ __global__ __launch_bounds__((ConvGldsCfg<BM, BN>::THREADS)) void conv_igemm_gld
             float *Ab = lds + buf * STAGE + a_first * BM;
             float *Bb = lds + buf * STAGE + BK * BM + (p * C::ROWS_PP) * BN;
             int cb, r, kh, kw;
+            auto issue_a = [&](const char *wa) {
+                if (!C::A_P0 || p == 0) {
+#pragma unroll
+                    for (int i = 0; i < C::A_PP; ++i) buffer_load_lds_b128(wa, a_voff, Ab + i * A_RPI * BM, i * A_RPI * g.mpad * 4);
+                }
+            };
             if (S == 2 && DGRAD && g.parity) {      // slab s of this class: channel block s / nt, its (s % nt)-th tap
                 cb = s / nt;
                 const int ti = s - cb * nt, th = ti / ntw;
                 kh = k0h + 2 * th; kw = k0w + 2 * (ti - th * ntw);
                 r = kh * KW + kw;
-            } else {
+                issue_a(wbase + (size_t)(cb * (KH * KW) + r) * BK * g.mpad * 4);
+            } else {                                 // weights first: their address needs no division
+                issue_a(wbase + (size_t)s * BK * g.mpad * 4);
                 cb = s / (KH * KW); r = s - cb * (KH * KW);
                 kh = r / KW; kw = r - kh * KW;
-            }
-            const char *wa = wbase + (size_t)(cb * (KH * KW) + r) * BK * g.mpad * 4;
-            if (!C::A_P0 || p == 0) {
-#pragma unroll
-                for (int i = 0; i < C::A_PP; ++i) buffer_load_lds_b128(wa, a_voff, Ab + i * A_RPI * BM, i * A_RPI * g.mpad * 4);
             }
             const char *xs = xbase + (size_t)cb * BK * plane * 4;
 #pragma unroll
@@ -527,7 +550,7 @@ __global__ __launch_bounds__((ConvGldsCfg<BM, BN>::THREADS)) void conv_igemm_gld
         }
         buf = (buf + 1) & (NST - 1);
     }
-    conv_epilogue<WM, WN>(acc, g, e, m0, n0, tz, wm, wn, lane);
+    conv_epilogue<WM, WN, (S == 2 && DGRAD)>(acc, g, e, m0, n0, tz, wm, wn, lane);
 }
 
 // split-K reduce for conv outputs: fixed summation order s = 0..splits-1

@@ -39,32 +39,32 @@ def conv_flops(xs, ws, ys):
     return 2.0 * ws[0] * ws[1] * ws[2] * ws[3] * ys[0] * ys[2] * ys[3]
 
 
-def p_fwd(x, w, bias, stride, pad, act=0, slope=0.01):
-    y = orig["conv2d_fwd"](x, w, bias, stride, pad, act, slope)
+def p_fwd(x, w, bias, stride, pad, act=0, slope=0.01, row_period=0):
+    y = orig["conv2d_fwd"](x, w, bias, stride, pad, act, slope, row_period=row_period)
     xs, ws = tuple(x.shape), tuple(w.shape)
     rec(("fwd", xs, ws, stride, pad), conv_flops(xs, ws, y.shape),
         lambda a=torch.randn(xs, device=dev), b=torch.randn(ws, device=dev) * .05: orig["conv2d_fwd"](a, b, None, stride, pad, act, slope))
     return y
 
 
-def p_dgrad(dy, w, x_shape, stride, pad, act_src=None, act_slope=0.0):
-    r = orig["conv2d_dgrad"](dy, w, x_shape, stride, pad, act_src, act_slope)
+def p_dgrad(dy, w, x_shape, stride, pad, act_src=None, act_slope=0.0, row_period=0):
+    r = orig["conv2d_dgrad"](dy, w, x_shape, stride, pad, act_src, act_slope, row_period=row_period)
     ys, ws, xs = tuple(dy.shape), tuple(w.shape), tuple(x_shape)
     rec(("dgrad", xs, ws, stride, pad), conv_flops(xs, ws, ys),
         lambda a=torch.randn(ys, device=dev), b=torch.randn(ws, device=dev) * .05: orig["conv2d_dgrad"](a, b, xs, stride, pad))
     return r
 
 
-def p_wgrad(dy, x, w_shape, stride, pad, out=None):
-    r = orig["conv2d_wgrad"](dy, x, w_shape, stride, pad, out)
+def p_wgrad(dy, x, w_shape, stride, pad, out=None, **kw):
+    r = orig["conv2d_wgrad"](dy, x, w_shape, stride, pad, out, **kw)
     ys, ws, xs = tuple(dy.shape), tuple(w_shape), tuple(x.shape)
     rec(("wgrad", xs, ws, stride, pad), conv_flops(xs, ws, ys),
         lambda a=torch.randn(ys, device=dev), b=torch.randn(xs, device=dev): orig["conv2d_wgrad"](a, b, ws, stride, pad))
     return r
 
 
-def p_wgrad_bias(dy, x, w_shape, stride, pad, out=None, db_out=None):
-    r = orig["conv2d_wgrad_bias"](dy, x, w_shape, stride, pad, out, db_out)
+def p_wgrad_bias(dy, x, w_shape, stride, pad, out=None, db_out=None, **kw):
+    r = orig["conv2d_wgrad_bias"](dy, x, w_shape, stride, pad, out, db_out, **kw)
     ys, ws, xs = tuple(dy.shape), tuple(w_shape), tuple(x.shape)
     rec(("wgrad+b", xs, ws, stride, pad), conv_flops(xs, ws, ys),
         lambda a=torch.randn(ys, device=dev), b=torch.randn(xs, device=dev): orig["conv2d_wgrad_bias"](a, b, ws, stride, pad))
