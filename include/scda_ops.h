@@ -311,6 +311,11 @@ int scda_instnorm_drop_add_fwd_hip(const float *x, const float *residual, float 
                                    float eps, float p, uint64_t seed, float scale /* 1 / (1 - p) */, void *stream);
 int scda_instnorm_drop_bwd_hip(const float *dy, const float *x, const float *mean, const float *rstd, float *dx, int planes, int HW,
                                float p, uint64_t seed, float scale, void *stream);
+/* ... with the seed read from DEVICE memory (one uint64): a launch recorded in a hipGraph draws fresh keep decisions on every replay */
+int scda_instnorm_drop_add_fwd_dev_hip(const float *x, const float *residual, float *y, float *mean, float *rstd, int planes, int HW,
+                                       float eps, float p, const uint64_t *seed_dev, float scale, void *stream);
+int scda_instnorm_drop_bwd_dev_hip(const float *dy, const float *x, const float *mean, const float *rstd, float *dx, int planes, int HW,
+                                   float p, const uint64_t *seed_dev, float scale, void *stream);
 /* nn.BatchNorm2d, training mode, with optional fused activation : common_net.py:214-223 */
 size_t scda_batchnorm_workspace_bytes(int B, int C, int HW);   /* 0: the one-workgroup-per-channel form needs none (ws may be NULL) */
 int scda_batchnorm_fwd_hip(const float *x, float *y, const float *gamma, const float *beta, float *running_mean,

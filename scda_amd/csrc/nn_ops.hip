@@ -428,6 +428,8 @@ struct DropTail {
     unsigned long long seed;
     float scale;             // 1 / (1 - p)
     int on;                  // backward: mask dy
+    const unsigned long long *seed_ptr;   // non-null: the seed is read from device memory (a launch recorded in a hipGraph gets a new
+                                          // seed on every replay without being re-recorded)
 };
 
 template <int VPT>
@@ -438,9 +440,10 @@ __global__ __launch_bounds__(1024) void instnorm_fwd_kernel(const float *__restr
     __shared__ float red[16];
     const size_t base = (size_t)blockIdx.x * HW;
     float mean, rstd;
+    const unsigned long long dseed = dt.seed_ptr ? *dt.seed_ptr : dt.seed;
     auto tail = [&](float o, const size_t i) -> float {      // i: flat index into the tensor
         if (!dt.residual) return o;
-        const float d = mix_hash(dt.seed, (uint64_t)i) >= dt.thr ? o * dt.scale : 0.f;
+        const float d = mix_hash(dseed, (uint64_t)i) >= dt.thr ? o * dt.scale : 0.f;
         return d + dt.residual[i];
     };
     if (VPT > 0) {
@@ -494,9 +497,10 @@ __global__ __launch_bounds__(1024) void instnorm_bwd_kernel(const float *__restr
     __shared__ float red[16];
     const size_t base = (size_t)blockIdx.x * HW;
     const float mean = mean_in[blockIdx.x], rstd = rstd_in[blockIdx.x];
+    const unsigned long long dseed = dt.seed_ptr ? *dt.seed_ptr : dt.seed;
     auto drop = [&](float g, const size_t i) -> float {      // the fused dropout's gradient (see DropTail)
         if (!dt.on) return g;
-        return mix_hash(dt.seed, (uint64_t)i) >= dt.thr ? g * dt.scale : 0.f;
+        return mix_hash(dseed, (uint64_t)i) >= dt.thr ? g * dt.scale : 0.f;
     };
     auto gate = [&](float g, float xh) -> float {
         if (act == 1) return xh > 0.f ? g : 0.f;
@@ -1352,27 +1356,42 @@ static int instnorm_bwd_launch(const float *dy, const float *x, const float *mea
 SCDA_API int scda_instnorm_fwd_hip(const float *x, float *y, float *mean, float *rstd, int planes, int HW, float eps,
                                    int act, float slope, void *stream) {
     NN_CHECK(x && y && mean && rstd && planes > 0 && HW > 0, "scda_instnorm_fwd_hip")
-    return instnorm_fwd_launch(x, y, mean, rstd, planes, HW, eps, act, slope, DropTail{nullptr, 0u, 0ull, 1.f, 0}, stream);
+    return instnorm_fwd_launch(x, y, mean, rstd, planes, HW, eps, act, slope, DropTail{nullptr, 0u, 0ull, 1.f, 0, nullptr}, stream);
 }
 
 SCDA_API int scda_instnorm_bwd_hip(const float *dy, const float *x, const float *mean, const float *rstd, float *dx,
                                    int planes, int HW, int act, float slope, void *stream) {
     NN_CHECK(dy && x && mean && rstd && dx && planes > 0 && HW > 0, "scda_instnorm_bwd_hip")
-    return instnorm_bwd_launch(dy, x, mean, rstd, dx, planes, HW, act, slope, DropTail{nullptr, 0u, 0ull, 1.f, 0}, stream);
+    return instnorm_bwd_launch(dy, x, mean, rstd, dx, planes, HW, act, slope, DropTail{nullptr, 0u, 0ull, 1.f, 0, nullptr}, stream);
 }
 
 // y = residual + dropout_p,seed(instance_norm(x)): the tail of a residual block in one launch (see DropTail)
 SCDA_API int scda_instnorm_drop_add_fwd_hip(const float *x, const float *residual, float *y, float *mean, float *rstd, int planes,
                                             int HW, float eps, float p, uint64_t seed, float scale, void *stream) {
     NN_CHECK(x && residual && y && mean && rstd && planes > 0 && HW > 0 && p >= 0.f && p < 1.f, "scda_instnorm_drop_add_fwd_hip")
-    return instnorm_fwd_launch(x, y, mean, rstd, planes, HW, eps, 0, 0.f, DropTail{residual, drop_threshold(p), seed, scale, 1}, stream);
+    return instnorm_fwd_launch(x, y, mean, rstd, planes, HW, eps, 0, 0.f, DropTail{residual, drop_threshold(p), seed, scale, 1, nullptr}, stream);
+}
+
+// ... with the seed in DEVICE memory (seed_dev: one uint64): the form a hipGraph records
+SCDA_API int scda_instnorm_drop_add_fwd_dev_hip(const float *x, const float *residual, float *y, float *mean, float *rstd, int planes,
+                                                int HW, float eps, float p, const uint64_t *seed_dev, float scale, void *stream) {
+    NN_CHECK(x && residual && y && mean && rstd && seed_dev && planes > 0 && HW > 0 && p >= 0.f && p < 1.f, "scda_instnorm_drop_add_fwd_dev_hip")
+    return instnorm_fwd_launch(x, y, mean, rstd, planes, HW, eps, 0, 0.f,
+                               DropTail{residual, drop_threshold(p), 0ull, scale, 1, (const unsigned long long *)seed_dev}, stream);
 }
 
 // dx of the same: the dropout's mask (recomputed from the seed) applied to dy, then the norm's gradient
 SCDA_API int scda_instnorm_drop_bwd_hip(const float *dy, const float *x, const float *mean, const float *rstd, float *dx, int planes,
                                         int HW, float p, uint64_t seed, float scale, void *stream) {
     NN_CHECK(dy && x && mean && rstd && dx && planes > 0 && HW > 0 && p >= 0.f && p < 1.f, "scda_instnorm_drop_bwd_hip")
-    return instnorm_bwd_launch(dy, x, mean, rstd, dx, planes, HW, 0, 0.f, DropTail{nullptr, drop_threshold(p), seed, scale, 1}, stream);
+    return instnorm_bwd_launch(dy, x, mean, rstd, dx, planes, HW, 0, 0.f, DropTail{nullptr, drop_threshold(p), seed, scale, 1, nullptr}, stream);
+}
+
+SCDA_API int scda_instnorm_drop_bwd_dev_hip(const float *dy, const float *x, const float *mean, const float *rstd, float *dx, int planes,
+                                            int HW, float p, const uint64_t *seed_dev, float scale, void *stream) {
+    NN_CHECK(dy && x && mean && rstd && dx && seed_dev && planes > 0 && HW > 0 && p >= 0.f && p < 1.f, "scda_instnorm_drop_bwd_dev_hip")
+    return instnorm_bwd_launch(dy, x, mean, rstd, dx, planes, HW, 0, 0.f,
+                               DropTail{nullptr, drop_threshold(p), 0ull, scale, 1, (const unsigned long long *)seed_dev}, stream);
 }
 
 SCDA_API size_t scda_batchnorm_workspace_bytes(int B, int C, int HW) {

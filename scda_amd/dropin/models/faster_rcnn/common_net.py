@@ -9,6 +9,7 @@ import torch
 import torch.nn as nn
 
 from scda_amd import layers as L
+from scda_amd import seeds
 from scda_amd.autograd_ops import ACT_LEAKY, ACT_NONE, ACT_RELU, AddFn, InstNormDropAddFn
 from scda_amd.dropin.models.faster_rcnn.init import gaussian_weights_init, xavier_weights_init  # noqa: F401
 
@@ -36,7 +37,7 @@ class INSResBlock(nn.Module):
             # IN -> Dropout -> (+ x) in one launch each way (autograd_ops.InstNormDropAddFn); the seed is drawn where the un-fused
             # Dropout module draws it, so the torch generator is consumed identically
             h = self.model[:-2](x)
-            seed = int(torch.randint(0, 1 << 62, (1,), dtype=torch.int64))
+            seed = seeds.draw()      # an int, or a device slot while the trainer records a hipGraph (scda_amd/seeds.py)
             return InstNormDropAddFn.apply(h, x, tail[0].eps, tail[1].p, seed)
         return AddFn.apply(self.model(x), x)
 

@@ -738,6 +738,11 @@ def instnorm_drop_add_fwd(x, residual, eps, p, seed):
     y = torch.empty_like(x)
     mean = torch.empty(B * C, dtype=torch.float32, device=x.device)
     rstd = torch.empty(B * C, dtype=torch.float32, device=x.device)
+    if torch.is_tensor(seed):     # a slot of a scda_amd.seeds.SeedArena: the kernel reads the seed from device memory
+        _req(seed, "seed", torch.int64)
+        _check(lib().scda_instnorm_drop_add_fwd_dev_hip(_p(x), _p(residual), _p(y), _p(mean), _p(rstd), i32(B * C), i32(H * W), f32(eps),
+                                                        f32(p), _p(seed), f32(1.0 / (1.0 - p)), _stream()), "scda_instnorm_drop_add_fwd_dev_hip")
+        return y, mean, rstd
     _check(lib().scda_instnorm_drop_add_fwd_hip(_p(x), _p(residual), _p(y), _p(mean), _p(rstd), i32(B * C), i32(H * W), f32(eps), f32(p),
                                                 u64(seed & 0xFFFFFFFFFFFFFFFF), f32(1.0 / (1.0 - p)), _stream()), "scda_instnorm_drop_add_fwd_hip")
     return y, mean, rstd
@@ -747,8 +752,12 @@ def instnorm_drop_bwd(dy, x, mean, rstd, p, seed):
     _req(dy, "dy"); _req(x, "x")
     B, C, H, W = x.shape
     dx = torch.empty_like(x)
+    if torch.is_tensor(seed):
+        _check(lib().scda_instnorm_drop_bwd_dev_hip(_p(dy), _p(x), _p(mean), _p(rstd), _p(dx), i32(B * C), i32(H * W), f32(p), _p(seed),
+                                                    f32(1.0 / (1.0 - p)), _stream()), "scda_instnorm_drop_bwd_dev_hip")
+        return dx
     _check(lib().scda_instnorm_drop_bwd_hip(_p(dy), _p(x), _p(mean), _p(rstd), _p(dx), i32(B * C), i32(H * W), f32(p),
-                                            u64(seed & 0xFFFFFFFFFFFFFFFF), f32(1.0 / (1.0 - p)), _stream()), "scda_instnorm_drop_bwd_hip")
+                                            u64(seed & 0xFFFFFFFFFFFFFFFF), f32(1.0 / (1.0 - p)), _stream()), "scda_instnorm_drop_bwd_dev_hip")
     return dx
 
 

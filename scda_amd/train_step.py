@@ -119,6 +119,117 @@ def active_test_hooks(fail=False):
     return on
 
 
+class _GanGraphs:
+    """hipGraphs of the three GAN regions of ScdaTrainer.step (A, B, C).  Two eager iterations first (planner caches, workspaces, packed
+    weights, BN state), the third records each region -- `torch.cuda.graph` records the library's ctypes-launched kernels, the A / B
+    fork-join on the branch stream and the autograd backward inside a region -- and replays it at once (recording does not execute);
+    every later iteration copies the region's inputs into the recorded tensors, draws the dropout seeds of the region on the host in the
+    eager modules' order (scda_amd/seeds.py) and replays.  All regions share one memory pool: B differentiates through the autograd graph
+    region A's recording built, whose saved activations live in that pool."""
+    KEYS = {'a': ('src_patch', 'tgt_patch', 'x_small', 't_small', 'score1', 'score0', 'score0p', 'score1p'),
+            'b': ('x_small', 't_small', 'tgt_patch', 'one_t', 'zero_t', 'one_s', 'zero_s'),
+            'c': ('src_patch', 'tgt_patch', 'ones_all', 'ones_row')}
+
+    def __init__(self, trainer):
+        from . import seeds
+        self.tr, self.calls, self.reg, self.static = trainer, 0, {}, {}
+        self.arena = seeds.SeedArena(trainer.device)
+        self.pool = None
+
+    def ready(self, name):
+        return name in self.reg
+
+    def recording(self):
+        return self.calls >= 3
+
+    def _bns(self):
+        from . import layers as L
+        return [m for m in self.tr.dis_patch.modules() if isinstance(m, L.BatchNorm2d)]
+
+    def _load(self, name, t):
+        """this iteration's inputs of region `name` into the recorded tensors -- each ONCE per iteration: B and C read what A loaded
+        (and while B is being recorded, autograd still holds A's inputs as saved tensors: an in-place copy would invalidate them)"""
+        if name == 'a':
+            self._loaded = set()
+        for k in self.KEYS[name]:
+            if k in self._loaded:
+                continue
+            self._loaded.add(k)
+            dst = self.static.get(k)
+            if dst is None:
+                self.static[k] = t[k].detach().clone()
+            elif dst.data_ptr() != t[k].data_ptr():
+                if dst.shape != t[k].shape:
+                    raise RuntimeError("GAN hipGraph: input %s changed shape %s -> %s" % (k, tuple(dst.shape), tuple(t[k].shape)))
+                dst.copy_(t[k], non_blocking=True)
+        return {k: self.static[k] for k in self.KEYS[name]}
+
+    def record(self, name, t, fn):
+        """record region `name` (fn(static inputs) -> tuple of tensors / None) and run it once by replaying"""
+        from . import seeds
+        st = self._load(name, t)
+        bns = self._bns()
+        before = [getattr(m, "_nbt_pending", 0) for m in bns]
+        lo = self.arena.n
+        seeds.active = self.arena
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=self.pool):
+                out = fn(st)
+        finally:
+            seeds.active = None
+        if self.pool is None:
+            self.pool = g.pool()
+        inc = [(m, getattr(m, "_nbt_pending", 0) - b0) for m, b0 in zip(bns, before)]
+        for m, b0 in zip(bns, before):         # the recording launched nothing: undo its host-side counting
+            m._nbt_pending = b0
+        self.reg[name] = {"graph": g, "out": out, "bn_inc": inc, "seeds": (lo, self.arena.n)}
+        return self._replay(name, redraw=False)
+
+    def _replay(self, name, redraw=True):
+        r = self.reg[name]
+        lo, hi = r["seeds"]
+        if redraw:
+            self.arena.redraw(lo, hi)
+        self.arena.upload(lo, hi)
+        r["graph"].replay()
+        for m, inc in r["bn_inc"]:
+            m._nbt_pending = getattr(m, "_nbt_pending", 0) + inc
+        return r["out"]
+
+    def run(self, name, t):
+        self._load(name, t)
+        out = self._replay(name)
+        if name == 'a':
+            return out[0], out[1], out[2].clone(), out[3].clone()
+        if name == 'b':
+            return out[0].clone(), out[1].clone(), out[2]
+        return out[0].clone(), out[1].clone()
+
+
+class _recording:
+    """`with _recording(graphs, name, t) as rec: outs = rec(fn)`: run fn eagerly, or -- from the third iteration of a trainer with
+    hipGraphs enabled -- record it as region `name` and replay it"""
+
+    def __init__(self, graphs, name, t):
+        self.g, self.name, self.t = graphs, name, t
+
+    def __enter__(self):
+        def rec(fn):
+            if self.g is not None and self.g.recording():
+                out = self.g.record(self.name, self.t, fn)
+                if self.name == 'a':
+                    return out[0], out[1], out[2].clone(), out[3].clone(), None, None
+                if self.name == 'b':
+                    return out[0].clone(), out[1].clone(), out[2], None
+                return out[0].clone(), out[1].clone()
+            return fn(self.t)
+        return rec
+
+    def __exit__(self, *a):
+        return False
+
+
 class ScdaTrainer:
     def __init__(self, cfg, device, lr=1.25e-5, cluster_num=4, threshold=128, recon_size=256, new_w=1024, new_h=512,
                  weight_decay=1e-4, world_size=1, models=None, recon_hw=None, reference_style=False, collectives=None):
@@ -269,41 +380,62 @@ class ScdaTrainer:
         w2 = self._reduce(self.dis_patch, async_op=True)
         return adloss.detach(), dis_patch_loss.detach(), w1, w2
 
-    def _gan_graph_ok(self):
-        """SCDA_GAN_GRAPH=1: replay phases 1 + 2 (about 170 launches, fixed shapes, no dropout, no host decision) as ONE hipGraph.
-        Not with collectives inside the region, gradient capture, the reference-style schedule or the parity tests' replay hooks."""
-        return (os.environ.get("SCDA_GAN_GRAPH") == "1" and self.device.type == "cuda" and not self.collectives and not self.capture
-                and self.early_backward and A.replay is None)
+    # ---- the GAN part of the iteration as three regions without a host decision inside --------------------------------------
+    # A: decoder forward + phases 1 and 2        B: phase 3 (forward, losses, backward into the decoders)
+    # C: the forward-only part of phase 4 (the logged adversarial term of the detector loss)
+    # Between them sit the optimiser steps (and, data-parallel, the waits for the all-reduces).  The eager iteration calls them as
+    # plain functions; with SCDA_GAN_GRAPH=1 each is recorded ONCE as a hipGraph and replayed (_GanGraphs below).
+    def _region_a(self, t):
+        src_recon, tgt_recon = self.dec(t['src_patch'], t['tgt_patch'])        # [C, 3, recon, recon]
+        mark('crops+dec_fwd_enqueued')
+        adloss, dis_patch_loss, w1, w2 = self._phase12((src_recon.detach(), tgt_recon.detach(), t['x_small'], t['t_small'], t['tgt_patch'],
+                                                        t['src_patch'], t['score1'], t['score0'], t['score0p'], t['score1p']))
+        return src_recon, tgt_recon, adloss, dis_patch_loss, w1, w2
 
-    def _phase12_graph(self, dev_in):
-        st = getattr(self, "_g12", None)
-        if st is None:
-            st = self._g12 = {"calls": 0}
-        st["calls"] += 1
-        if st["calls"] <= 2:                       # two eager iterations first: planner caches, workspaces, packed weights, BN state
-            out = self._phase12(dev_in)
-            return out[0], out[1]
-        if "graph" not in st:
-            from . import layers as L
-            st["static"] = [t.detach().clone() for t in dev_in]
-            bns = [m for m in self.dis_patch.modules() if isinstance(m, L.BatchNorm2d)]
-            before = [getattr(m, "_nbt_pending", 0) for m in bns]
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                a, b, _, _ = self._phase12(tuple(st["static"]))
-            st["graph"], st["out"] = g, (a, b)
-            st["bn_inc"] = [(m, getattr(m, "_nbt_pending", 0) - b0) for m, b0 in zip(bns, before)]
-            for m, b0 in zip(bns, before):         # the capture recorded kernels, it did not run them: undo its host-side counting
-                m._nbt_pending = b0
-        if any(d.shape != t.shape for d, t in zip(st["static"], dev_in)):   # never on the SCDA path (all shapes follow from the
-            out = self._phase12(dev_in)                                      # configuration); a graph is for ONE set of shapes
-            return out[0], out[1]
-        for dst, src in zip(st["static"], dev_in):
-            dst.copy_(src)
-        st["graph"].replay()
-        for m, inc in st["bn_inc"]:
-            m._nbt_pending = getattr(m, "_nbt_pending", 0) + inc
-        return st["out"][0].clone(), st["out"][1].clone()
+    def _region_b(self, src_recon, tgt_recon, t):
+        ws = float(self.world_size)
+        adv = A.adversarial_loss
+        self.opt['dec'].zero_grad()
+        with _Frozen(self.dis):
+            d_src_fake, d_tgt_fake = self.dis(src_recon, tgt_recon)   # gradient flows to the decoders only
+            with torch.no_grad():
+                d_src_real, d_tgt_real = self.dis(t['x_small'], t['t_small'])
+                w_tgt2 = N.row_mean(self.dis_patch(t['tgt_patch']).contiguous())
+            fake1_tgt = adv([(d_tgt_fake, t['one_t'], w_tgt2), (d_tgt_real, t['zero_t'], w_tgt2)])       # :675-681
+            fake1_src = adv([(d_src_fake, t['one_s'], None), (d_src_real, t['zero_s'], None)])           # :683-687
+            recon_loss = (fake1_src + fake1_tgt) / ws
+            recon_loss.backward()
+        w3 = self._reduce(self.dec, async_op=True)
+        return recon_loss.detach(), fake1_src.detach(), w_tgt2, w3
+
+    def _region_c(self, t, w_tgt2):
+        adv = A.adversarial_loss
+        with torch.no_grad():
+            swap_src, swap_tgt = self.dec(t['tgt_patch'], t['src_patch'])
+            q_src, q_tgt = self.dis(swap_src, swap_tgt)
+            fake_loss_source = adv([(q_tgt, t['ones_all'], None)], scale=1.0 / q_tgt.shape[0])      # mean over all elements (:723)
+            fake_loss_target = adv([(q_src, t['ones_row'], w_tgt2)])                                 # :725-732
+        return fake_loss_source, fake_loss_target
+
+    def _gan_graph_ok(self):
+        """SCDA_GAN_GRAPH=1: the three regions above as hipGraphs (~330 of the iteration's ~700 launches, fixed shapes).  Not with
+        collectives inside the regions, gradient capture, the reference-style schedule or the parity tests' hooks."""
+        from . import layers as L
+        return (os.environ.get("SCDA_GAN_GRAPH") == "1" and self.device.type == "cuda" and not self.collectives and not self.capture
+                and self.early_backward and A.replay is None and L.Dropout.mask_source is None)
+
+    def _ones_row(self, row):
+        c = getattr(self, "_ones_row_cache", None)
+        if c is None or tuple(c.shape) != tuple(row):
+            c = self._ones_row_cache = torch.ones(row, dtype=torch.float32, device=self.device)
+        return c
+
+    def _gan_graphs(self):
+        g = getattr(self, "_gg", None)
+        if g is None:
+            g = self._gg = _GanGraphs(self)
+        g.calls += 1
+        return g
 
     def step(self, image, gts, image_info, target):
         """image/target [1,3,H,W] on the device; gts [1,G,5]; image_info [1,3] -> dict of 0-dim loss tensors"""
@@ -330,31 +462,29 @@ class ScdaTrainer:
         mark('step_begin')
         outputs = self.model(x, target)
         ctr_s, ctr_t = outputs['cluster_centers']
-        x_small = _crops(image, get_corner_from_center(ctr_s, self.recon, self.new_w, self.new_h), self.recon)
-        t_small = _crops(target, get_corner_from_center(ctr_t, self.recon, self.new_w, self.new_h), self.recon)
         src_patch, tgt_patch = outputs['cluster_features']          # [C, threshold, 4096] leaves
-        src_recon, tgt_recon = self.dec(src_patch, tgt_patch)        # [C, 3, recon, recon]
-
-        bce, adv = A.binary_cross_entropy, A.adversarial_loss
-        mark('crops+dec_fwd_enqueued')
+        t = {'x_small': _crops(image, get_corner_from_center(ctr_s, self.recon, self.new_w, self.new_h), self.recon),
+             't_small': _crops(target, get_corner_from_center(ctr_t, self.recon, self.new_w, self.new_h), self.recon),
+             'src_patch': src_patch, 'tgt_patch': tgt_patch}
+        graphs = self._gan_graphs() if self._gan_graph_ok() else None
 
         # The adversarial terms below are the reference's sums over clusters of F.binary_cross_entropy(torch.sigmoid(d)[c], label)
         # (one mean per cluster row), each group evaluated by ONE fused kernel (A.adversarial_loss) on the logits.
-        # ---------------- (1) image discriminators, (2) patch discriminator ----------------
+        # ---------------- decoder forward, (1) image discriminators, (2) patch discriminator ----------------
         # host side first: the four label draws in the reference's order (nothing else consumes numpy's RNG in between)
-        n_dis = self._dis_out_len(x_small)
+        n_dis = self._dis_out_len(t['x_small'])
         row = (1, n_dis)
-        score1 = _soft(1, row, dev)
-        score0 = _soft(0, row, dev)
         pro_shape = (src_patch.shape[0], self._dis_patch_out_len())
-        score0p = _soft(0, pro_shape, dev)
-        score1p = _soft(1, pro_shape, dev)
-        dev_in = (src_recon.detach(), tgt_recon.detach(), x_small, t_small, tgt_patch, src_patch, score1, score0, score0p, score1p)
-        if self._gan_graph_ok():
-            adloss, dis_patch_loss = self._phase12_graph(dev_in)
+        t['score1'] = _soft(1, row, dev)
+        t['score0'] = _soft(0, row, dev)
+        t['score0p'] = _soft(0, pro_shape, dev)
+        t['score1p'] = _soft(1, pro_shape, dev)
+        if graphs is not None and graphs.ready('a'):
+            src_recon, tgt_recon, adloss, dis_patch_loss = graphs.run('a', t)
             w1 = w2 = None
         else:
-            adloss, dis_patch_loss, w1, w2 = self._phase12(dev_in)
+            with _recording(graphs, 'a', t) as rec:
+                src_recon, tgt_recon, adloss, dis_patch_loss, w1, w2 = rec(lambda tt: self._region_a(tt))
         mark('phase2')
         if w1 is not None:
             w1.wait()
@@ -366,29 +496,24 @@ class ScdaTrainer:
         self.opt['dis_patch'].step()
 
         # ---------------- (3) decoders ----------------
-        self.opt['dec'].zero_grad()
-        with _Frozen(self.dis):
-            d_src_fake, d_tgt_fake = self.dis(src_recon, tgt_recon)   # gradient flows to the decoders only
-            with torch.no_grad():
-                d_src_real, d_tgt_real = self.dis(x_small, t_small)
-                w_tgt2 = N.row_mean(self.dis_patch(tgt_patch).contiguous())
-            one_t = _hard(1, row, dev)
-            zero_t = _hard(0, row, dev)
-            fake1_tgt = adv([(d_tgt_fake, one_t, w_tgt2), (d_tgt_real, zero_t, w_tgt2)])       # :675-681
-            one_s = _hard(1, row, dev)
-            zero_s = _hard(0, row, dev)
-            fake1_src = adv([(d_src_fake, one_s, None), (d_src_real, zero_s, None)])           # :683-687
-            recon_loss = (fake1_src + fake1_tgt) / ws
-            recon_loss.backward()
-        w3 = self._reduce(self.dec, async_op=True)
+        t['one_t'] = _hard(1, row, dev)
+        t['zero_t'] = _hard(0, row, dev)
+        t['one_s'] = _hard(1, row, dev)
+        t['zero_s'] = _hard(0, row, dev)
+        if graphs is not None and graphs.ready('b'):
+            recon_loss, fake1_src, w_tgt2 = graphs.run('b', t)
+            w3 = None
+        else:
+            with _recording(graphs, 'b', t) as rec:
+                recon_loss, fake1_src, w_tgt2, w3 = rec(lambda tt: self._region_b(src_recon, tgt_recon, tt))
         mark('phase3')
 
         # ---------------- (4) detector ----------------
         # The swapped reconstruction of the reference's phase 4 only feeds the LOGGED loss: the cluster features are
         # leaves, so the 0.1*(fake_loss_source + fake_loss_target) term carries no gradient into the detector
-        # (SURVEY.md 3.1).  The detector backward therefore starts right away and overlaps the decoder all-reduce;
-        # the logged term is evaluated afterwards, without a graph, with the freshly stepped decoder as in the
-        # reference (dec_optimizer.step() precedes it, :704 vs :716).
+        # (SURVEY.md 3.1).  The detector backward therefore started long ago (early backward) and overlaps the decoder
+        # all-reduce; the logged term is evaluated afterwards, without an autograd graph, with the freshly stepped decoder as in
+        # the reference (dec_optimizer.step() precedes it, :704 vs :716).
         rpn_cls, rpn_loc, rcnn_cls, rcnn_loc = outputs['losses']
         if not self.early_backward:
             detector_backward(outputs['losses'])
@@ -397,13 +522,13 @@ class ScdaTrainer:
             w3.wait()
             self._grab_reduced('dec', self.dec)
         self.opt['dec'].step()
-        with torch.no_grad():
-            swap_src, swap_tgt = self.dec(tgt_patch, src_patch)
-            q_src, q_tgt = self.dis(swap_src, swap_tgt)
-            ones_all = _hard(1, q_tgt.shape, dev)
-            fake_loss_source = adv([(q_tgt, ones_all, None)], scale=1.0 / q_tgt.shape[0])      # mean over all elements (:723)
-            ones_row = torch.ones(row, dtype=torch.float32, device=dev)
-            fake_loss_target = adv([(q_src, ones_row, w_tgt2)])                                 # :725-732
+        t['ones_all'] = _hard(1, (src_patch.shape[0], n_dis), dev)
+        t['ones_row'] = self._ones_row(row)
+        if graphs is not None and graphs.ready('c'):
+            fake_loss_source, fake_loss_target = graphs.run('c', t)
+        else:
+            with _recording(graphs, 'c', t) as rec:
+                fake_loss_source, fake_loss_target = rec(lambda tt: self._region_c(tt, w_tgt2))
         loss = det_loss + 0.1 * (fake_loss_source + fake_loss_target) / ws
         if w4 is not None:
             w4.wait()

@@ -284,10 +284,11 @@ def test_vgg16_bn_detector_trains(cuda):
 
 
 def test_gan_phases_as_hipgraph_match_eager(cuda, monkeypatch):
-    """SCDA_GAN_GRAPH=1: phases 1 + 2 (image discriminators + patch discriminator: forward, losses, both backward passes, ~170
-    launches on two streams) recorded once as a hipGraph and replayed from the third iteration on.  Same kernels, same order,
-    same inputs: every parameter bucket, the BN statistics / counters and the logged losses must be BIT-identical to the eager
-    step after five iterations."""
+    """SCDA_GAN_GRAPH=1: the GAN part of the iteration -- decoder forward + phases 1 and 2, phase 3 (backward into the decoders
+    included), the forward-only part of phase 4: ~330 launches on two streams -- recorded once as three hipGraphs and replayed from
+    the third iteration on, the decoders' dropout seeds read from device memory.  Same kernels, same order, same inputs, same random
+    draws: every parameter bucket, the BN statistics / counters and ALL logged losses must be BIT-identical to the eager step after six
+    iterations."""
     from scda_amd.train_step import ScdaTrainer
     res = {}
     for name in ("eager", "graph"):
@@ -299,16 +300,19 @@ def test_gan_phases_as_hipgraph_match_eager(cuda, monkeypatch):
         tr = ScdaTrainer(mc.CFG, cuda, lr=1e-3, new_w=512, new_h=256, models=mc.seeded_models(build_product))
         np.random.seed(5)
         losses = []
-        for it in range(5):
+        for it in range(6):
             src, tgt, gts, info = mc.seeded_inputs(256, 512, sample=it % 3)
             out = tr.step(src.to(cuda), gts, info, tgt.to(cuda))
-            losses.append([float(out[k]) for k in ('loss', 'adloss', 'dis_patch_loss', 'recon_loss')])
+            losses.append([float(out[k]) for k in ('loss', 'adloss', 'dis_patch_loss', 'recon_loss', 'fake_loss_source', 'fake_loss_target',
+                                                   'fake_loss1_source')])
         torch.cuda.synchronize()
         if name == "graph":
-            assert "graph" in tr._g12 and tr._g12["calls"] == 5
+            assert sorted(tr._gg.reg) == ['a', 'b', 'c'] and tr._gg.calls == 6 and tr._gg.arena.n == 12     # 2 x 6 dropout launches
+        res_rng = (torch.rand(1).item(), np.random.rand())          # both generators end in the same state
         sd = tr.dis_patch.state_dict()
-        res[name] = dict(losses=losses, sums={k: (float(f.data.double().sum()), float(f.data.double().abs().sum())) for k, f in tr.flat.items()},
+        res[name] = dict(losses=losses, rng=res_rng, sums={k: (float(f.data.double().sum()), float(f.data.double().abs().sum())) for k, f in tr.flat.items()},
                          bn={k: v.double().sum().item() for k, v in sd.items() if 'running' in k or 'num_batches' in k})
     assert res["graph"]["losses"] == res["eager"]["losses"]
+    assert res["graph"]["rng"] == res["eager"]["rng"]
     assert res["graph"]["sums"] == res["eager"]["sums"]
     assert res["graph"]["bn"] == res["eager"]["bn"]
