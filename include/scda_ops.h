@@ -346,6 +346,9 @@ int scda_row_mean_hip(const float *x, float *y, int R, int C, void *stream);
 /* torch.optim.Adam step on one flat bucket (tools/faster_rcnn_train_val.py:305-316); step counts from 1 */
 int scda_adam_hip(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long long n, float lr,
                   float beta1, float beta2, float eps, float weight_decay, int step, void *stream);
+/* the same step with the cap of the (grid-stride) launch given explicitly; 0 = the library's choice (512 workgroups) */
+int scda_adam_limited_hip(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long long n, float lr,
+                          float beta1, float beta2, float eps, float weight_decay, int step, int max_blocks, void *stream);
 
 #ifdef __cplusplus
 }

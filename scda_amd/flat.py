@@ -7,6 +7,7 @@ contiguous fp32 buffer, and their gradients into a second one; every nn.Paramete
     messages, not 99 small ones),
   * 16-byte aligned segments so the optimiser kernel can use dwordx4 accesses.
 """
+import os
 import torch
 
 from . import native as N
@@ -137,6 +138,7 @@ class FlatAdam(torch.optim.Optimizer):
         if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1 or weight_decay < 0:
             raise ValueError("FlatAdam: invalid hyper-parameters")
         self.flat = flat
+        self.max_blocks = int(os.environ.get('SCDA_ADAM_BLOCKS', '0'))     # > 0: explicit cap of the Adam launch (scripts/time_adam.py)
         self.bucket = torch.nn.Parameter(flat.data, requires_grad=True)   # aliases flat.data (no copy)
         self.bucket.grad = flat.grad
         super().__init__([self.bucket], dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
@@ -193,7 +195,7 @@ class FlatAdam(torch.optim.Optimizer):
         n = int(st["step"]) + 1
         st["step"] = torch.tensor(float(n), dtype=torch.float32)
         N.adam_step(self.flat.data, self.flat.grad, st["exp_avg"], st["exp_avg_sq"], float(g["lr"]), g["betas"][0], g["betas"][1],
-                    g["eps"], g["weight_decay"], n)
+                    g["eps"], g["weight_decay"], n, max_blocks=self.max_blocks)
         self.flat.epoch += 1   # the kernel wrote through raw pointers: packed-weight caches of this bucket are stale
         N.conv2d_pack_all(self.flat)   # ... and are rebuilt right here, all layers and both directions in one launch
         return loss

@@ -876,10 +876,10 @@ def row_mean(x):
     return y
 
 
-def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step):
+def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, max_blocks=0):
     _req(param, "param"); _req(grad, "grad"); _req(exp_avg, "exp_avg"); _req(exp_avg_sq, "exp_avg_sq")
-    _check(lib().scda_adam_hip(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), i64(param.numel()), f32(lr), f32(beta1), f32(beta2),
-                               f32(eps), f32(weight_decay), i32(step), _stream()), "scda_adam_hip")
+    _check(lib().scda_adam_limited_hip(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), i64(param.numel()), f32(lr), f32(beta1),
+                                       f32(beta2), f32(eps), f32(weight_decay), i32(step), i32(max_blocks), _stream()), "scda_adam_hip")
 
 
 def last_plan():

@@ -16,7 +16,7 @@ def short(n):
     n = n.replace("scda::", "").replace("void ", "")
     return re.sub(r"\(.*", "", n)[:60]
 start_key = sys.argv[2] if len(sys.argv) > 2 else "upsample2_fwd"
-i0 = next(i for i, r in enumerate(it) if start_key in r[2])
+i0 = 0 if start_key == "all" else next(i for i, r in enumerate(it) if start_key in r[2])
 # back up to the decoder's first kernel: the first conv_igemm <64,64> before the first upsample
 t0 = it[0][0]
 qs = sorted(set(r[3] for r in it))
