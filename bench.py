@@ -168,7 +168,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--config", choices=["vgg16", "resnet50"], default="vgg16",
+    ap.add_argument("--config", choices=["vgg16", "resnet50", "maskrcnn"], default="vgg16",
                     help="vgg16 = BASELINE.json configs[1] (the metric's configuration, default); resnet50 = configs[3]'s detector "
                          "(ResNet-50 C4 + SCDA at 800x1344, performance-only: the reference has no runnable model for it)")
     a = ap.parse_args()
@@ -203,10 +203,13 @@ def main():
     torch.manual_seed(0)          # identical initial weights on every rank (then broadcast, as the reference does)
     np.random.seed(100 + rank)    # per-rank sampling / soft-label stream
     bh, bw, f_iter, dominant = H, W, F_ITER_TFLOP, DOMINANT
-    if a.config == "resnet50":
+    step_kw = {}
+    if a.config in ("resnet50", "maskrcnn"):
         from scda_amd import resnet_config as RC
         bh, bw, f_iter, dominant = RC.H, RC.W, RC.f_iter_tflop(), RC.DOMINANT
-        tr = RC.make_trainer(CFG, dev, lr=1.25e-5, world_size=world)
+        if a.config == "maskrcnn":      # configs[4]: + mask branch and mask loss (upper bound of its work: the full RoI quota)
+            f_iter += RC.mask_branch_tflop()
+        tr = RC.make_trainer(CFG, dev, lr=1.25e-5, world_size=world, with_mask=a.config == "maskrcnn")
     else:
         tr = ScdaTrainer(CFG, dev, lr=1.25e-5, new_w=W, new_h=H, world_size=world)
     if world > 1:
@@ -214,11 +217,13 @@ def main():
             broadcast_params(m)
     src, tgt, gts, info = synth_batch(rank, bh, bw)
     src, tgt = src.to(dev), tgt.to(dev)
+    if a.config == "maskrcnn":
+        step_kw["gt_masks"] = RC.synth_masks(gts, bh, bw)
 
     quota = CFG["train_rpn_proposal_cfg"]["post_nms_top_n"]
     precond = 0
     for _ in range(a.warmup):
-        tr.step(src, gts, info, tgt)
+        tr.step(src, gts, info, tgt, **step_kw)
     def short_of_quota():
         """any rank still below the post-NMS quota?  (decided collectively: every step contains all-reduces, so all ranks must
         run the same number of pre-conditioning steps)"""
@@ -228,7 +233,7 @@ def main():
         return bool(flag.item())
 
     while precond < 40 and short_of_quota():   # realistic proposal sets before timing
-        tr.step(src, gts, info, tgt)
+        tr.step(src, gts, info, tgt, **step_kw)
         precond += 1
     torch.cuda.synchronize()
     if world > 1:
@@ -241,7 +246,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        out = tr.step(src, gts, info, tgt)
+        out = tr.step(src, gts, info, tgt, **step_kw)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -250,7 +255,7 @@ def main():
     if not in_region:
         native.prof_enable([dominant])
         for _ in range(3):
-            tr.step(src, gts, info, tgt)
+            tr.step(src, gts, info, tgt, **step_kw)
         torch.cuda.synchronize()
     native.prof_enable(False)
     prof = native.prof_collect()
@@ -264,7 +269,7 @@ def main():
         native.prof_enable([DOMINANT, DOMINANT_SMALL_TILES])
     if in_region:
         for _ in range(3):
-            tr.step(src, gts, info, tgt)
+            tr.step(src, gts, info, tgt, **step_kw)
         torch.cuda.synchronize()
         native.prof_enable(False)
         p2 = native.prof_collect()
@@ -303,7 +308,9 @@ def main():
                                   "definition": "F_iter (%.3f TFLOP of necessary conv/FC work per iteration) x iterations/s" % f_iter}}
         res = {
             "metric": "images/sec (fwd+bwd) VGG16 Faster-RCNN+SCDA 512x1024" if a.config == "vgg16" else
-                      "images/sec (fwd+bwd) ResNet-50-C4 Faster-RCNN+SCDA 800x1344 (performance-only configuration)",
+                      "images/sec (fwd+bwd) ResNet-50-C4 Faster-RCNN+SCDA 800x1344 (performance-only configuration)"
+                      if a.config == "resnet50" else
+                      "images/sec (fwd+bwd) ResNet-50-C4 Mask-RCNN+SCDA 800x1344 (performance-only configuration)",
             "value": round(value, 3), "unit": "images/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -314,7 +321,11 @@ def main():
                                     "(BASELINE.json configs[1]); 1 step = 1 source + 1 target image, 4 optimiser phases")
                        if a.config == "vgg16" else
                        ("resnet50_FasterRCNN (C4, RoIAlignAvg, layer4 head) + 4-cluster SCDA, synthetic 800x1344, batch=1/GPU "
-                        "(BASELINE.json configs[3]'s detector; no reference implementation exists: performance only)"),
+                        "(BASELINE.json configs[3]'s detector; no reference implementation exists: performance only)")
+                       if a.config == "resnet50" else
+                       ("mask_rcnn: the configs[3] detector + mask branch (RoIAlignAvg 14x14, 4 convs, 2x2/2 deconvolution, per-class "
+                        "28x28 masks, <= 64 positive RoIs) + SCDA losses, synthetic 800x1344 + elliptical instance masks, batch=1/GPU "
+                        "(BASELINE.json configs[4]; the reference's model file is missing: performance only)"),
                        "image": [bh, bw], "gt_boxes": G, "rois": 512, "clusters": 4, "recon": tr.recon, "parallelism": "dp%d" % world,
                        "iters_per_s": round(world * a.steps / dt, 3), "final_loss": round(float(out["loss"]), 4),
                        "images_per_step": "1 source (forward + backward) + 1 target (forward only: it carries no loss), per GPU",

@@ -192,6 +192,9 @@ class RefDetector(nn.Module):
         fea = self.classifier(x.view(x.size(0), -1))
         return fea, self.fc_rcnn_cls(fea), self.fc_rcnn_loc(fea)
 
+    def extra_source_losses(self, inp, feat, proposals):
+        return []
+
     def forward(self, inp, target=None):
         from scda_amd.dropin.functions.anchor_target import compute_anchor_targets
         from scda_amd.dropin.functions.mask import compute_cluster_targets
@@ -223,6 +226,7 @@ class RefDetector(nn.Module):
         props = compute_rpn_proposals(objectness(rpn_cls).data, rpn_loc.data, cfg['train_rpn_proposal_cfg'], info)
         rois, cls_t, loc_t, loc_w = compute_proposal_targets(props, cfg['train_proposal_target_cfg'], gts, info, None)
         fea, cls, loc = self.rcnn(x, rois)
+        extra = self.extra_source_losses(inp, x, props)     # the mask branch of oracle/resnet_ref.py; [] otherwise
         clu, ctr = compute_cluster_targets(rois, fea, N_cluster=inp['cluster_num'], threshold=inp['threshold'])
         # target image (graph is built, as in the reference, although nothing differentiates through it)
         xg = self.features(target)
@@ -234,7 +238,7 @@ class RefDetector(nn.Module):
         rcnn_loss_cls = F.cross_entropy(cls, cls_t)
         rcnn_loss_loc = smooth_l1_sum(loc * loc_w, loc_t) / cls_t.shape[0]
         rcnn_acc = top1(cls, cls_t)
-        out['losses'] = [rpn_loss_cls, rpn_loss_loc, rcnn_loss_cls, rcnn_loss_loc]
+        out['losses'] = [rpn_loss_cls, rpn_loss_loc, rcnn_loss_cls, rcnn_loss_loc] + extra
         out['accuracy'] = [rpn_acc, rcnn_acc]
         out['predict'] = [props]
         if fea_g.size(0) != 512:

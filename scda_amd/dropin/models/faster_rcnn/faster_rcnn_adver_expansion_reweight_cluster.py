@@ -121,6 +121,10 @@ class FasterRCNN_AdEx(nn.Module):
                                                       cfg=cfg['test_predict_bbox_cfg'])
         return fn
 
+    def _extra_source_losses(self, input, feat, proposals):
+        """further losses on the source image's features (branches beyond RPN + RCNN); none in the Faster R-CNN detectors"""
+        return []
+
     def forward(self, input, target=None):
         """input: dict(cfg, image [b,3,h,w], ground_truth_bboxes [b,G,5]|None, image_info [b,3], ignore_regions,
         cluster_num, threshold); target: target-domain image batch (training only)."""
@@ -171,6 +175,7 @@ class FasterRCNN_AdEx(nn.Module):
         mark('src_rcnn_enqueued')
         rcnn_loss_cls, rcnn_loss_loc, rcnn_acc = self._add_rcnn_loss(rcnn_cls, rcnn_loc, cls_targets, loc_targets, loc_weights)
         losses = [rpn_loss_cls, rpn_loss_loc, rcnn_loss_cls, rcnn_loss_loc]
+        losses += self._extra_source_losses(input, feat, proposals)     # e.g. the mask branch of models/mask_rcnn/resnet.py
 
         # Optional scheduling hooks of this repository's own training step (absent when the reference's driver calls us):
         #  '_after_source_losses': called as soon as the four detector losses exist -- the step uses it to enqueue the

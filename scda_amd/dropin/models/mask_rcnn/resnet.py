@@ -97,6 +97,13 @@ class ResNet(FasterRCNN_AdEx):
         self.avgpool = L.GlobalAvgPool()                                     # AvgPool2d(7) on 7x7 maps
         self.fc_rcnn_cls = L.Linear(512 * block.expansion, cfg['num_classes'])
         self.fc_rcnn_loc = L.Linear(512 * block.expansion, cfg['num_classes'] * 4)
+        if cfg.get('with_keypoint'):
+            raise NotImplementedError("the keypoint branch (:141-144) is not part of any BASELINE configuration")
+        self.with_mask = bool(cfg.get('with_mask'))
+        if self.with_mask:                                                   # mask branch (:146-149), BASELINE configs[4]
+            self.mask_roipooling = RoIAlignAvg(14, 14, 1.0 / cfg['anchor_stride'])
+            self.mask_head = self._make_branch(1024, 256, cfg['num_classes'], 4, upscaling=False)
+            self.mask_target_cfg = dict(cfg.get('train_mask_target') or DEFAULT_MASK_TARGET, num_classes=cfg['num_classes'])
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
                 n = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
@@ -112,6 +119,19 @@ class ResNet(FasterRCNN_AdEx):
         self._fix_layer(self.fix_layer_num)
         self.tall_head = True
         self._head_convs3x3 = [m for m in self.layer4.modules() if isinstance(m, L.Conv2d) and m.kernel_size == (3, 3)]
+
+    def _make_branch(self, inplanes, midplanes, outplanes, depth, upscaling=False):
+        """FCN branch (:168-193): depth x (3x3 conv + ReLU), 2x2/2 transposed conv + ReLU, 1x1 conv to `outplanes` maps"""
+        if upscaling:
+            raise NotImplementedError("bilinear x2 behind the deconvolution: keypoint branch only")
+        seq, cin = [], inplanes
+        for _ in range(depth):
+            seq.append(nn.Sequential(L.Conv2d(cin, midplanes, kernel_size=3, stride=1, padding=1, fused_act=ACT_RELU),
+                                     L.FusedAct("ReLU")))
+            cin = midplanes
+        seq.append(nn.Sequential(L.ConvTranspose2x2s2(midplanes, midplanes), L.Activation("relu")))
+        seq.append(L.Conv2d(midplanes, outplanes, kernel_size=1))
+        return nn.Sequential(*seq)
 
     def _make_layer(self, block, planes, blocks, stride=1):
         downsample = None
@@ -174,6 +194,37 @@ class ResNet(FasterRCNN_AdEx):
             x = self.layer4(x.view(1, C, R * 7, 7))           # [1, 2048, R*7, 7]
             x_fea = self.avgpool(x.view(x.shape[1], R, 7, 7)).t().contiguous()   # [2048, R] -> [R, 2048]
         return x_fea, self.fc_rcnn_cls(x_fea), self.fc_rcnn_loc(x_fea)
+
+
+    def mask_predictor(self, x, rois):
+        """:266-270: [R, 5] RoIs -> per-class mask logits [R, num_classes, 28, 28]"""
+        assert rois.shape[1] == 5
+        self.mask_roipooling.channel_major = False
+        return self.mask_head(self.mask_roipooling(x, rois))
+
+    def _extra_source_losses(self, input, feat, proposals):
+        """The mask loss of the source image.  The reference's loss code for this branch is in the missing
+        models/mask_rcnn/mask_rcnn.py; what exists is the target contract (functions/mask.py:73-179: labels are -1 = ignore on
+        every class plane but the RoI's own).  Used here: the Mask R-CNN definition -- the mean binary cross-entropy of
+        sigmoid(logits) on each positive RoI's own class plane, averaged over the RoIs."""
+        if not (self.with_mask and self.training) or input.get('ground_truth_masks') is None:
+            return []
+        from scda_amd.dropin.functions.mask import compute_mask_targets
+        rois, labels = compute_mask_targets(proposals, self.mask_target_cfg, input['ground_truth_bboxes'],
+                                            input['ground_truth_masks'], input['image_info'], input.get('ignore_regions'))
+        dev = feat.device
+        if rois.shape[1] < 6:                        # the all-ignore placeholder row: no positive RoI in this image
+            return [feat.new_zeros(())]
+        cls = rois[:, 5].long()
+        r = torch.arange(rois.shape[0])
+        own = labels[r, cls].reshape(rois.shape[0], -1).to(dev)            # [R, 28*28] in {0, 1}
+        logits = self.mask_predictor(feat, rois[:, :5].contiguous().to(dev))
+        sel = logits[r.to(dev), cls.to(dev)].reshape(rois.shape[0], -1)
+        self.last_mask_rois = int(rois.shape[0])
+        return [A.adversarial_loss([(sel, own, None)], scale=1.0 / rois.shape[0])]
+
+
+DEFAULT_MASK_TARGET = {'positive_iou_thresh': 0.5, 'batch_size_per_image': 64, 'label_h': 28, 'label_w': 28, 'append_gts': True}
 
 
 def resnet50(pretrained=False, **kwargs):

@@ -51,6 +51,25 @@ class ConvTranspose1x1(nn.ConvTranspose2d):
         return A.conv2d(x, w, self.bias, 1, 0)
 
 
+class ConvTranspose2x2s2(nn.ConvTranspose2d):
+    """nn.ConvTranspose2d(kernel_size=2, stride=2, padding=0) -- the up-sampling layer of the mask / keypoint branches
+    (models/mask_rcnn/resnet.py:183-185).  Stride = kernel: every output pixel (2h+a, 2w+b) has exactly ONE tap,
+    y[n, o, 2h+a, 2w+b] = sum_c x[n, c, h, w] W[c, o, a, b] + bias[o] -- a 1x1 convolution to 4*out channels on the MFMA kernel
+    (channel o*4 + a*2 + b), then a pixel shuffle.  A ReLU behind it commutes with the shuffle and is fused into the conv."""
+
+    def __init__(self, cin, cout, fused_act=A.ACT_NONE, slope=0.01, **kw):
+        super().__init__(cin, cout, kernel_size=2, stride=2, padding=0, **kw)
+        self.fused_act, self.slope = fused_act, slope
+
+    def forward(self, x):
+        cin, cout = self.weight.shape[0], self.weight.shape[1]
+        w = self.weight.permute(1, 2, 3, 0).reshape(cout * 4, cin, 1, 1).contiguous()      # [o*4 + a*2 + b, c]
+        b = self.bias.repeat_interleave(4) if self.bias is not None else None
+        y = A.conv2d(x, w, b, 1, 0, self.fused_act, self.slope)                              # [n, 4*out, h, w]
+        n, _, h, wd = y.shape
+        return y.view(n, cout, 2, 2, h, wd).permute(0, 1, 4, 2, 5, 3).reshape(n, cout, 2 * h, 2 * wd)
+
+
 class FusedAct(nn.Module):
     """Placeholder that keeps nn.Sequential indices where the reference has nn.ReLU(inplace=True) /
     nn.LeakyReLU(inplace=True) directly after a conv/linear/norm whose kernel already applied it."""

@@ -21,18 +21,46 @@ FEAT_HW = (32, 64)            # view of the 2048-d RoI feature (h, w)
 RECON_HW = (128, 256)
 
 
-def build_models(cfg, cluster_num=4, threshold=128):
+MASK_ROIS = 64                # positive RoIs per image the mask branch trains on (train_mask_target.batch_size_per_image)
+MASK_TARGET = {'positive_iou_thresh': 0.5, 'batch_size_per_image': MASK_ROIS, 'label_h': 28, 'label_w': 28, 'append_gts': True}
+
+
+def build_models(cfg, cluster_num=4, threshold=128, with_mask=False):
+    """with_mask: BASELINE.json configs[4] -- the same detector with the mask branch of models/mask_rcnn/resnet.py:146-149
+    (RoIAlignAvg(14, 14), four 3x3 convs 1024 -> 256, 2x2/2 transposed conv, 1x1 conv to per-class 28 x 28 masks) and its loss added
+    to the detector's; the step takes ground-truth masks (`ScdaTrainer.step(..., gt_masks=)`)"""
     from scda_amd.dropin.models.mask_rcnn.resnet import resnet50
     from scda_amd.train_step import builder_gan
     shared = dict(cfg['shared'], roi_align=True, gan_model_flag=2)
+    if with_mask:
+        shared.update(with_mask=True, train_mask_target=dict(MASK_TARGET))
     det = resnet50(cfg=shared)
     dis, dec, dis_patch = builder_gan(cluster_num, threshold, 256, neww=FEAT_HW[0], newh=FEAT_HW[1])
     return det, dec, dis, dis_patch
 
 
-def make_trainer(cfg, device, lr=1.25e-5, world_size=1):
+def make_trainer(cfg, device, lr=1.25e-5, world_size=1, with_mask=False):
     from scda_amd.train_step import ScdaTrainer
-    return ScdaTrainer(cfg, device, lr=lr, new_w=W, new_h=H, world_size=world_size, models=build_models(cfg), recon_hw=RECON_HW)
+    return ScdaTrainer(cfg, device, lr=lr, new_w=W, new_h=H, world_size=world_size, models=build_models(cfg, with_mask=with_mask),
+                       recon_hw=RECON_HW)
+
+
+def synth_masks(gts, h=H, w=W):
+    """[1, G, h, w] uint8: the ellipse inscribed in every ground-truth box (synthetic instance masks)"""
+    import numpy as np
+    g = gts[0].numpy() if torch.is_tensor(gts) else gts[0]
+    yy, xx = np.mgrid[0:h, 0:w]
+    out = np.zeros((1, g.shape[0], h, w), dtype=np.uint8)
+    for i, (x1, y1, x2, y2) in enumerate(g[:, :4]):
+        if x2 > x1 and y2 > y1:
+            out[0, i] = ((((xx - (x1 + x2) / 2.0) / ((x2 - x1) / 2.0)) ** 2 + ((yy - (y1 + y2) / 2.0) / ((y2 - y1) / 2.0)) ** 2) <= 1.0)
+    return torch.from_numpy(out)
+
+
+def mask_branch_tflop(rois=MASK_ROIS):
+    """forward + backward (dgrad + wgrad) of the mask head on `rois` RoIs, TFLOP (2 FLOP / MAC)"""
+    macs = rois * (196 * 9 * (1024 * 256 + 3 * 256 * 256) + 196 * 256 * 256 * 4 + 784 * 256 * 9)
+    return 2.0 * 3 * macs / 1e12
 
 
 def _bottleneck_macs(cin, planes, hw_in, stride, first):

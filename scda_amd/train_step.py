@@ -437,11 +437,14 @@ class ScdaTrainer:
         g.calls += 1
         return g
 
-    def step(self, image, gts, image_info, target):
-        """image/target [1,3,H,W] on the device; gts [1,G,5]; image_info [1,3] -> dict of 0-dim loss tensors"""
+    def step(self, image, gts, image_info, target, gt_masks=None):
+        """image/target [1,3,H,W] on the device; gts [1,G,5]; image_info [1,3]; gt_masks [1,G,H,W] binary (detectors with a mask
+        branch, BASELINE configs[4]) -> dict of 0-dim loss tensors"""
         dev, ws, C = self.device, float(self.world_size), self.cluster_num
         x = {'cfg': self.cfg, 'image': image, 'image_info': image_info, 'ground_truth_bboxes': gts,
              'ignore_regions': None, 'cluster_num': self.cluster_num, 'threshold': self.threshold}
+        if gt_masks is not None:
+            x['ground_truth_masks'] = gt_masks
         pending = {}
         for sch in self._warmup or ():     # :510-514 -- the warm-up schedulers step at the top of the iteration
             sch.step()
@@ -450,7 +453,10 @@ class ScdaTrainer:
             # Phase (4)'s gradient depends only on the four detector losses (the adversarial term of the reference's
             # detector loss carries no gradient into the detector), so its backward -- and, multi-GPU,
             # the 547 MB all-reduce -- starts here and runs underneath the rest of the iteration.
-            det_loss = (losses[0] + losses[1] + losses[2] + losses[3]) / ws
+            total = losses[0] + losses[1] + losses[2] + losses[3]
+            for extra in losses[4:]:          # branches beyond RPN + RCNN (the mask loss of configs[4])
+                total = total + extra
+            det_loss = total / ws
             self.opt['det'].zero_grad()
             det_loss.backward()
             pending['det_loss'] = det_loss.detach()
@@ -514,7 +520,7 @@ class ScdaTrainer:
         # (SURVEY.md 3.1).  The detector backward therefore started long ago (early backward) and overlaps the decoder
         # all-reduce; the logged term is evaluated afterwards, without an autograd graph, with the freshly stepped decoder as in
         # the reference (dec_optimizer.step() precedes it, :704 vs :716).
-        rpn_cls, rpn_loc, rcnn_cls, rcnn_loc = outputs['losses']
+        rpn_cls, rpn_loc, rcnn_cls, rcnn_loc = outputs['losses'][:4]
         if not self.early_backward:
             detector_backward(outputs['losses'])
         det_loss, w4 = pending['det_loss'], pending['w4']
@@ -537,8 +543,9 @@ class ScdaTrainer:
         mark('phase4+det_step')
 
         self.last_num_proposals = outputs.get('num_proposals')     # post-NMS proposal counts (source, target) of this iteration
+        extra_logged = {'mask_loss': outputs['losses'][4].detach()} if len(outputs['losses']) > 4 else {}
         return {'loss': loss.detach() * ws, 'rpn_cls': rpn_cls.detach(), 'rpn_loc': rpn_loc.detach(),
                 'rcnn_cls': rcnn_cls.detach(), 'rcnn_loc': rcnn_loc.detach(), 'rpn_acc': outputs['accuracy'][0],
                 'rcnn_acc': outputs['accuracy'][1], 'fake_loss_target': fake_loss_target, 'fake_loss_source': fake_loss_source,
                 'recon_loss': recon_loss.detach(), 'adloss': adloss.detach(), 'dis_patch_loss': dis_patch_loss.detach(),
-                'fake_loss1_source': fake1_src.detach()}
+                'fake_loss1_source': fake1_src.detach(), **extra_logged}
