@@ -207,9 +207,11 @@ def main():
     if a.config in ("resnet50", "maskrcnn"):
         from scda_amd import resnet_config as RC
         bh, bw, f_iter, dominant = RC.H, RC.W, RC.f_iter_tflop(), RC.DOMINANT
-        if a.config == "maskrcnn":      # configs[4]: + mask branch and mask loss (upper bound of its work: the full RoI quota)
-            f_iter += RC.mask_branch_tflop()
-        tr = RC.make_trainer(CFG, dev, lr=1.25e-5, world_size=world, with_mask=a.config == "maskrcnn")
+        # configs[4]: + mask branch and mask loss.  The untrained RPN of a synthetic run puts almost no proposal on an object at
+        # IoU > 0.5, so the branch would see the 12 appended ground-truth boxes only: IoU > 0.2 fills its quota of 64 RoIs (the work
+        # a trained model does); F_iter below counts the RoIs the branch actually ran on.
+        tr = RC.make_trainer(CFG, dev, lr=1.25e-5, world_size=world, with_mask=a.config == "maskrcnn",
+                             mask_iou=0.2 if a.config == "maskrcnn" else None)
     else:
         tr = ScdaTrainer(CFG, dev, lr=1.25e-5, new_w=W, new_h=H, world_size=world)
     if world > 1:
@@ -252,6 +254,9 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    mask_rois = getattr(tr.model, "last_mask_rois", None) if a.config == "maskrcnn" else None
+    if mask_rois is not None:
+        f_iter += RC.mask_branch_tflop(mask_rois)
     if not in_region:
         native.prof_enable([dominant])
         for _ in range(3):
@@ -326,7 +331,7 @@ def main():
                        ("mask_rcnn: the configs[3] detector + mask branch (RoIAlignAvg 14x14, 4 convs, 2x2/2 deconvolution, per-class "
                         "28x28 masks, <= 64 positive RoIs) + SCDA losses, synthetic 800x1344 + elliptical instance masks, batch=1/GPU "
                         "(BASELINE.json configs[4]; the reference's model file is missing: performance only)"),
-                       "image": [bh, bw], "gt_boxes": G, "rois": 512, "clusters": 4, "recon": tr.recon, "parallelism": "dp%d" % world,
+                       "image": [bh, bw], "gt_boxes": G, "rois": 512, **({"mask_rois": mask_rois} if mask_rois is not None else {}), "clusters": 4, "recon": tr.recon, "parallelism": "dp%d" % world,
                        "iters_per_s": round(world * a.steps / dt, 3), "final_loss": round(float(out["loss"]), 4),
                        "images_per_step": "1 source (forward + backward) + 1 target (forward only: it carries no loss), per GPU",
                        "proposals_post_nms": {"source": tr.last_num_proposals[0], "target": tr.last_num_proposals[1], "quota": quota},

@@ -149,6 +149,7 @@ class RefResNetDetector(RefDetector):
         if rois.shape[1] < 6:
             return [feat.new_zeros(())]
         r, cls = torch.arange(rois.shape[0]), rois[:, 5].long()
+        self.last_mask_rois = int(rois.shape[0])
         logits = self.mask_head(self.mask_roipooling(feat, rois[:, :5].contiguous()))
         return [F.binary_cross_entropy(torch.sigmoid(logits[r, cls]), labels[r, cls])]
 

@@ -197,10 +197,24 @@ class ResNet(FasterRCNN_AdEx):
 
 
     def mask_predictor(self, x, rois):
-        """:266-270: [R, 5] RoIs -> per-class mask logits [R, num_classes, 28, 28]"""
+        """:266-270: [R, 5] RoIs -> per-class mask logits [R, num_classes, 28, 28].  Like `rcnn()` the branch runs CHANNEL-MAJOR when
+        it can (R * 196 pixels a multiple of 16, i.e. R % 4 == 0): pooled maps [C, R, 14, 14] seen as one [1, C, R*14, 14] image whose
+        3x3 convolutions know the 14-row period; the 2x2/2 transposed convolution's pixel shuffle maps row r*14 + h to r*28 + 2h + a,
+        so the stack stays a stack.  On [R, C, 14, 14] maps of 196 pixels none of the direct-to-LDS weight-gradient kernels applies
+        (measured: the branch on 64 RoIs cost 10 ms of a 55 ms iteration that way).  The returned tensor is a view in the reference's
+        index order either way."""
         assert rois.shape[1] == 5
-        self.mask_roipooling.channel_major = False
-        return self.mask_head(self.mask_roipooling(x, rois))
+        R = rois.shape[0]
+        tall = self.tall_head and R > 0 and R % 4 == 0 and not os.environ.get("SCDA_RESNET_HEAD_NCHW")
+        self.mask_roipooling.channel_major = tall
+        for m in self.mask_head.modules():
+            if isinstance(m, L.Conv2d) and m.kernel_size == (3, 3):
+                m.row_period = 14 if tall else 0
+        x = self.mask_roipooling(x, rois)
+        if not tall:
+            return self.mask_head(x)
+        y = self.mask_head(x.view(1, x.shape[0], R * 14, 14))               # [1, classes, R*28, 28]
+        return y.view(y.shape[1], R, 28, 28).transpose(0, 1)
 
     def _extra_source_losses(self, input, feat, proposals):
         """The mask loss of the source image.  The reference's loss code for this branch is in the missing

@@ -25,7 +25,7 @@ MASK_ROIS = 64                # positive RoIs per image the mask branch trains o
 MASK_TARGET = {'positive_iou_thresh': 0.5, 'batch_size_per_image': MASK_ROIS, 'label_h': 28, 'label_w': 28, 'append_gts': True}
 
 
-def build_models(cfg, cluster_num=4, threshold=128, with_mask=False):
+def build_models(cfg, cluster_num=4, threshold=128, with_mask=False, mask_iou=None):
     """with_mask: BASELINE.json configs[4] -- the same detector with the mask branch of models/mask_rcnn/resnet.py:146-149
     (RoIAlignAvg(14, 14), four 3x3 convs 1024 -> 256, 2x2/2 transposed conv, 1x1 conv to per-class 28 x 28 masks) and its loss added
     to the detector's; the step takes ground-truth masks (`ScdaTrainer.step(..., gt_masks=)`)"""
@@ -34,15 +34,17 @@ def build_models(cfg, cluster_num=4, threshold=128, with_mask=False):
     shared = dict(cfg['shared'], roi_align=True, gan_model_flag=2)
     if with_mask:
         shared.update(with_mask=True, train_mask_target=dict(MASK_TARGET))
+        if mask_iou is not None:      # synthetic runs: an untrained RPN puts few proposals on the objects (bench.py says what it used)
+            shared['train_mask_target']['positive_iou_thresh'] = mask_iou
     det = resnet50(cfg=shared)
     dis, dec, dis_patch = builder_gan(cluster_num, threshold, 256, neww=FEAT_HW[0], newh=FEAT_HW[1])
     return det, dec, dis, dis_patch
 
 
-def make_trainer(cfg, device, lr=1.25e-5, world_size=1, with_mask=False):
+def make_trainer(cfg, device, lr=1.25e-5, world_size=1, with_mask=False, mask_iou=None):
     from scda_amd.train_step import ScdaTrainer
-    return ScdaTrainer(cfg, device, lr=lr, new_w=W, new_h=H, world_size=world_size, models=build_models(cfg, with_mask=with_mask),
-                       recon_hw=RECON_HW)
+    return ScdaTrainer(cfg, device, lr=lr, new_w=W, new_h=H, world_size=world_size,
+                       models=build_models(cfg, with_mask=with_mask, mask_iou=mask_iou), recon_hw=RECON_HW)
 
 
 def synth_masks(gts, h=H, w=W):

@@ -1,2 +1,3 @@
-for b in 4096 512 4096 512 384 768; do echo "== SCDA_ADAM_BLOCKS=$b"; SCDA_ADAM_BLOCKS=$b python scripts/device_phase_times.py 2>/dev/null | tail -5; done
-for b in 320 384 448 512 640 768; do SCDA_ADAM_BLOCKS=$b python scripts/time_adam.py 2>/dev/null | tail -1; done
+timeout 1200 python -m pytest tests/test_maskrcnn_gpu.py -x -q -m gpu 2>&1 | tail -2
+for c in maskrcnn resnet50; do python bench.py --config $c --steps 10 --warmup 4 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('$c', d['value'], d['ms_per_step'], d['config'].get('mask_rois'), d['roofline']['iteration'])"; done

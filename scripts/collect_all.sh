@@ -19,6 +19,8 @@ if [ "${1:-}" = "--install" ]; then
   cp $S/resnet50/kernel_stats.md $D/${TAG}_resnet50_kernel_stats.md
   cp $S/resnet50/kernel_categories.md $D/${TAG}_resnet50_kernel_categories.md
   cp $S/resnet50_bench.json $D/${TAG}_resnet50_bench_1gpu.json
+  [ -s $S/maskrcnn_bench.json ] && cp $S/maskrcnn_bench.json $D/${TAG}_maskrcnn_bench_1gpu.json
+  [ -s $S/maskrcnn/kernel_categories.md ] && cp $S/maskrcnn/kernel_categories.md $D/${TAG}_maskrcnn_kernel_categories.md
   cp $S/resnet50/exposed_time.md $D/${TAG}_resnet50_exposed_time.md
   for f in device_phase_times.txt host_cpu.txt resnet50_plan_search.txt plan_search.txt s2_conv_layers.txt; do
     [ -s $S/$f ] && cp $S/$f $D/${TAG}_$f
@@ -44,6 +46,9 @@ python scripts/device_phase_times.py > $OUT/device_phase_times.txt 2>/dev/null
 python scripts/time_s2_dgrad.py > $OUT/s2_conv_layers.txt 2>/dev/null
 ( python scripts/host_cpu_use.py spin; python scripts/host_cpu_use.py block ) > $OUT/host_cpu.txt 2>/dev/null
 python bench.py --config resnet50 --steps 10 --warmup 4 --no-cpu-baseline > $OUT/resnet50_bench.json 2>/dev/null
+python bench.py --config maskrcnn --steps 10 --warmup 4 --no-cpu-baseline > $OUT/maskrcnn_bench.json 2>/dev/null
+mkdir -p $OUT/maskrcnn
+bash scripts/kt.sh $TAG/maskrcnn "--config maskrcnn" > $OUT/maskrcnn/kernel_categories.md 2>/dev/null
 mkdir -p $OUT/resnet50
 bash scripts/kt.sh $TAG/resnet50 "--config resnet50" > $OUT/resnet50/kernel_categories.md 2>/dev/null
 ( cd /tmp; export TMPDIR=/tmp

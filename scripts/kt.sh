@@ -11,7 +11,7 @@ timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/kt -o prof -- python $R/ben
 grep '^{' $OUT/kt.log > $OUT/bench_under_rocprof.json
 cd $R
 # iterations in the trace: 3 warm-up + 10 timed; the ResNet configuration adds 3 (its dominant class is timed in a separate pass)
-ITERS=13; case "$EXTRA" in *resnet50*) ITERS=16;; esac
+ITERS=13; case "$EXTRA" in *resnet50*|*maskrcnn*) ITERS=16;; esac
 python scripts/rocprof_summary.py $(ls $OUT/kt/*.db | head -1) $OUT/kernel_stats.md "python bench.py --steps 10 --warmup 3 --no-cpu-baseline $EXTRA under rocprofv3 --kernel-trace --stats ($ITERS iterations incl. warm-up)" > /dev/null
 rm -rf $OUT/kt/*.db
 python scripts/kernel_categories.py $OUT/kernel_stats.md $ITERS

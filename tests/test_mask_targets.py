@@ -109,3 +109,21 @@ def test_conv_transpose_2x2_s2_index_mapping(monkeypatch):
     for a, b in zip(gg, gw):
         assert torch.allclose(a, b, atol=1e-5)
     assert list(layer.state_dict()) == ["weight", "bias"] and tuple(layer.weight.shape) == (6, 5, 2, 2)
+
+
+def test_generate_mask_labels_equals_per_window_resize():
+    """the all-RoIs-at-once gather against `resize_linear_u8` on each RoI's window (what the reference's loop over cv2.resize does)"""
+    from scda_amd.dropin.functions.mask import generate_mask_labels, resize_linear_u8
+    rng = np.random.RandomState(9)
+    masks = (rng.rand(5, 90, 130) > 0.4).astype(np.uint8) * rng.randint(1, 255, size=(5, 1, 1)).astype(np.uint8)
+    x1 = rng.randint(0, 100, 40); y1 = rng.randint(0, 60, 40)
+    rois = np.stack([x1, y1, x1 + rng.randint(1, 30, 40), y1 + rng.randint(1, 30, 40)], 1).astype(np.float32)
+    rois[0] = [3, 4, 4, 5]                                     # a one-pixel window
+    rois[1] = [0, 0, 130, 90]                                  # the whole plane
+    index = rng.randint(0, 5, 40)
+    for mh, mw in ((28, 28), (7, 20)):
+        got = generate_mask_labels(rois, masks, mh, mw, index=index)
+        assert got.dtype == np.int32 and got.shape == (40, mh, mw)
+        for i, (a, b, c, d) in enumerate(rois.astype(np.int32)):
+            assert np.array_equal(got[i], resize_linear_u8(masks[index[i]][b:d, a:c], mw, mh)), i
+    assert np.array_equal(generate_mask_labels(rois[:5], masks, 14, 14), generate_mask_labels(rois[:5], masks, 14, 14, index=np.arange(5)))
