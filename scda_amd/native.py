@@ -12,7 +12,7 @@ import weakref
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libscda_ops.so")
+LIB_PATH = os.environ.get("SCDA_OPS_LIB") or os.path.join(_HERE, "libscda_ops.so")   # (the env override: A/B builds of the library)
 
 _lib = None
 
