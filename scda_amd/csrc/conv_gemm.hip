@@ -50,6 +50,18 @@ __device__ __forceinline__ void tile_coords(const int nx, const int ny, const in
         const unsigned q = nwg >> 3, r = nwg & 7, xcd = id & 7;
         L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
     }
+    if (swz & 2) {
+        // grouped order (dense GEMM with many M-tiles, the FC weight gradients): groups of 8 M-tiles, inside a group N-tile major,
+        // M-tile fastest -- an XCD's run of ids walks ONE group's 8 A panels (2 MB, L2-resident) across the N-tiles, so that the B
+        // panel of a column is fetched once per group instead of all of A once per column (FC6: 32 M-tiles = 8 MB of dY re-read for
+        // each of 196 columns)
+        const unsigned per = (unsigned)nx * ny, z = L / per, r = L - z * per;
+        const unsigned grp = r / (8u * nx), first = grp * 8u, gsz = min((unsigned)ny - first, 8u), rr = r - grp * 8u * nx;
+        tz = (int)z;
+        tx = (int)(rr / gsz);
+        ty = (int)(first + rr - (unsigned)tx * gsz);
+        return;
+    }
     const unsigned t = L / (unsigned)ny;
     ty = (int)(L - t * ny);
     tz = (int)(t / (unsigned)nx);
@@ -2060,8 +2072,8 @@ SCDA_API int scda_gemm_hip(const float *A, const float *B, float *C, int M, int 
     if (!g.zp) { set_error("scda_gemm_hip: could not allocate the zero page"); return SCDA_ELAUNCH; }
     splits = cdiv(K, g.k_per_split);
     static const bool no_mpart = getenv("SCDA_GEMM_NO_MPART") != nullptr;   // A/B knob
-    // the A operand does not fit one XCD's L2 but an eighth of it does: partition the M-tiles over the XCDs (see tile_coords)
-    if (!no_mpart && g.swz && splits == 1 && (g.ny % 8) == 0 && (long long)g.nx * g.ny >= 2048 && (double)M * K * sizeof(float) > 4e6)
+    // the A operand does not fit one XCD's L2 but a quarter of it does: grouped tile order (see tile_coords)
+    if (!no_mpart && g.swz && g.ny >= 16 && (long long)g.nx * g.ny >= 1024 && (double)M * K * sizeof(float) > 4e6)
         g.swz |= 2;
     Epi e{C, (float *)ws, bias, bias_on_n, act, slope, splits, accumulate, nullptr, 0.f};
     dim3 grid((unsigned)g.nx * g.ny * splits);

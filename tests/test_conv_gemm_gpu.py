@@ -118,7 +118,8 @@ def test_conv_identity_asymmetric(cuda):
 
 @pytest.mark.parametrize("M,N,K", [(512, 4096, 1024), (512, 9, 4096), (512, 36, 4096), (37, 50, 70), (128, 128, 16),
                                    (512, 4096, 25088 // 8),
-                                   (512, 4096, 8192)])     # weight gradient 4096 x 8192: the XCD-partitioned tile order (tile_coords)
+                                   (512, 4096, 8192),      # weight gradient 4096 x 8192: the grouped tile order (tile_coords)
+                                   (512, 2560, 8192)])     # ... with a ragged last group (20 M-tiles = 8 + 8 + 4)
 def test_linear_fwd_bwd(cuda, M, N, K):
     from scda_amd import native
     g = torch.Generator().manual_seed(M + N + K)
