@@ -158,41 +158,85 @@ __device__ __forceinline__ int conv_tap_offset(const ConvGeom &g, const bool n_o
     }
 }
 
-// accumulators -> split-K slab, or (+bias) -> activation -> NCHW output; lanes run along N (pixels): 128-byte row segments
+// accumulators -> split-K slab, or (+bias) -> activation -> NCHW output; lanes run along N (pixels): 128-byte row segments.
+// Two passes per 32 x 32 block -- first every load the block needs (its 16 bias values once per row block, its 16 mask values),
+// then arithmetic and stores.  Written element by element ("load bias, add, activate, load mask, store") the compiler cannot
+// batch anything: the stores may alias the loads as far as it knows, so every element waited for its own loads with vmcnt(0) --
+// 64 round trips to L2 per wave at the end of every workgroup, with the matrix pipes idle (conv1_2 forward: 66 of 369 us).
 template <int WM, int WN, bool PP = false>
 __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[WM / 32][WN / 32], const ConvGeom &g, const Epi &e, const int m0,
                                               const int n0, const int tz, const int wm, const int wn, const int lane) {
     constexpr int TM = WM / 32, TN = WN / 32;
     const int lr = lane & 31;
+    const float *__restrict__ bias = e.bias;
+    const float *__restrict__ msk = e.mask_src;
+    float *__restrict__ out = e.out;
+    float *__restrict__ ws = e.ws;
+    const size_t plane = (size_t)g.dPHW.d;
+    bool ok[TN];
+    int nn[TN];
+    size_t pbase[TN];      // offset of (image, channel 0, pixel) in the NCHW output
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         int n = n0 + wn * WN + j * 32 + lr;
-        int oimg, opix;
+        int oimg = 0, opix = 0;
         if (PP && g.parity) {
             int opy, opx;
-            if (!conv_n_to_pixel<true>(g, n, oimg, opy, opx)) continue;
+            ok[j] = conv_n_to_pixel<true>(g, n, oimg, opy, opx);
             opix = opy * g.PW + opx;
             n = oimg * g.dPHW.d + opix;          // natural index of the pixel (the logical one is class-major)
         } else {
-            if (n >= g.N) continue;
-            g.dPHW.divmod(n, oimg, opix);
+            ok[j] = n < g.N;
+            g.dPHW.divmod(ok[j] ? n : 0, oimg, opix);
+        }
+        nn[j] = n;
+        pbase[j] = (size_t)oimg * g.M * plane + opix;
+    }
+    const int mrow = m0 + wm * WM + 4 * (lane >> 5);     // frag_row(r, lane) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    if (e.splits > 1) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            if (!ok[j]) continue;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mrow + i * 32 + (r & 3) + 8 * (r >> 2);
+                    if (m >= g.M) continue;
+                    ws[((size_t)tz * g.M + m) * g.N + nn[j]] = acc[i][j][r];
+                }
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        float bv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bv[r] = 0.f;
+        if (bias) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bv[r] = bias[min(mrow + i * 32 + (r & 3) + 8 * (r >> 2), g.M - 1)];
         }
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+        for (int j = 0; j < TN; ++j) {
+            if (!ok[j]) continue;
+            float mv[16];
+            if (msk) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = min(mrow + i * 32 + (r & 3) + 8 * (r >> 2), g.M - 1);
+                    mv[r] = msk[pbase[j] + (size_t)m * plane];
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * WM + i * 32 + frag_row(r, lane);
+                const int m = mrow + i * 32 + (r & 3) + 8 * (r >> 2);
                 if (m >= g.M) continue;
                 float v = acc[i][j][r];
-                if (e.splits > 1) {
-                    e.ws[((size_t)tz * g.M + m) * g.N + n] = v;
-                } else {
-                    if (e.bias) v += e.bias[m];
-                    v = apply_act(v, e.act, e.slope);
-                    const size_t o = ((size_t)oimg * g.M + m) * g.dPHW.d + opix;
-                    if (e.mask_src) v = e.mask_src[o] > 0.f ? v : v * e.mask_slope;
-                    e.out[o] = v;
-                }
+                if (bias) v += bv[r];
+                v = apply_act(v, e.act, e.slope);
+                if (msk) v = mv[r] > 0.f ? v : v * e.mask_slope;
+                out[pbase[j] + (size_t)m * plane] = v;
             }
         }
     }
@@ -374,11 +418,14 @@ struct ConvGldsCfg {
     static constexpr int LB = ROWS_PP * HALVES;                     // pixel-operand LDS-DMA instructions per staging wave per slab
     static constexpr int L = A_PP + LB;                             // ... all of them (with A_P0: staging wave 0's count)
     static constexpr int THREADS = (NWC + NP) * 64;
+    // waves per SIMD the register allocation must leave room for: the 64 x 256 tile is 8 waves and two workgroups share a CU
+    // (80 KB of LDS each) -- 4 per SIMD, 128 registers (the batched epilogue loads would otherwise take it to 132 and one workgroup)
+    static constexpr int WAVES_PER_EU = (BM == 64 && BN == 256) ? 4 : 1;
     static_assert(BK % NP == 0 && 2 * L <= 63 && WM >= 32 && WN >= 32, "staging split");
 };
 
 template <int BM, int BN, int KH, int KW, int S, bool DGRAD>
-__global__ __launch_bounds__((ConvGldsCfg<BM, BN>::THREADS)) void conv_igemm_glds_kernel(const float *__restrict__ Wt,
+__global__ __launch_bounds__((ConvGldsCfg<BM, BN>::THREADS), (ConvGldsCfg<BM, BN>::WAVES_PER_EU)) void conv_igemm_glds_kernel(const float *__restrict__ Wt,
                                                                                      const float *__restrict__ X,
                                                                                      const ConvGeom g, const Epi e) {
     using C = ConvGldsCfg<BM, BN>;
