@@ -1,2 +1,2 @@
-python scripts/bench_conv_layers.py 2>/dev/null | grep -E "fc6|fc7"
-for i in 1 2; do python scripts/device_phase_times.py 2>/dev/null | grep -E "det_backward|step_begin"; done
+echo "== glds"; python scripts/bench_conv_layers.py 2>/dev/null | cut -c1-12,68-110
+echo "== SCDA_WGRAD_NO_GLDS=1"; SCDA_WGRAD_NO_GLDS=1 python scripts/bench_conv_layers.py 2>/dev/null | cut -c1-12,68-110
