@@ -81,6 +81,28 @@ def _hard(flag, shape, device):
     return N.upload(np.random.uniform(v, v, size=tuple(shape)), device, torch.float32)
 
 
+def _labels(specs, device):
+    """several label tensors in ONE host-to-device copy: specs = [(kind, flag, shape)], kind 's' (generate_soft_label) or 'h'
+    (generate_hard_label), drawn in this order from numpy's global RNG exactly as the separate calls would (the reference's order of
+    draws, :442-458).  Each upload is a tiny copy on the compute stream, and the GAN phases are a chain of tiny launches."""
+    draws = []
+    for kind, flag, shape in specs:
+        if kind == 's':
+            lo, hi = (0.8, 1.0) if flag == 1 else (0.0, 0.3)
+        else:
+            lo = hi = 1.0 if flag == 1 else 0.0
+        draws.append(np.random.uniform(lo, hi, size=tuple(shape)).astype(np.float32))
+    offs, total = [], 0
+    for d in draws:
+        offs.append(total)
+        total += (d.size + 3) // 4 * 4              # 16-byte aligned slices
+    host = np.zeros(total, dtype=np.float32)
+    for d, o in zip(draws, offs):
+        host[o:o + d.size] = d.ravel()
+    flat = N.upload(host, device, torch.float32)
+    return [flat[o:o + d.size].view(d.shape) for d, o in zip(draws, offs)]
+
+
 def _crops(img, corners, recon):
     rh, rw = (recon, recon) if np.isscalar(recon) else recon
     out = []
@@ -481,10 +503,8 @@ class ScdaTrainer:
         n_dis = self._dis_out_len(t['x_small'])
         row = (1, n_dis)
         pro_shape = (src_patch.shape[0], self._dis_patch_out_len())
-        t['score1'] = _soft(1, row, dev)
-        t['score0'] = _soft(0, row, dev)
-        t['score0p'] = _soft(0, pro_shape, dev)
-        t['score1p'] = _soft(1, pro_shape, dev)
+        t['score1'], t['score0'], t['score0p'], t['score1p'] = _labels(
+            [('s', 1, row), ('s', 0, row), ('s', 0, pro_shape), ('s', 1, pro_shape)], dev)
         if graphs is not None and graphs.ready('a'):
             src_recon, tgt_recon, adloss, dis_patch_loss = graphs.run('a', t)
             w1 = w2 = None
@@ -502,10 +522,7 @@ class ScdaTrainer:
         self.opt['dis_patch'].step()
 
         # ---------------- (3) decoders ----------------
-        t['one_t'] = _hard(1, row, dev)
-        t['zero_t'] = _hard(0, row, dev)
-        t['one_s'] = _hard(1, row, dev)
-        t['zero_s'] = _hard(0, row, dev)
+        t['one_t'], t['zero_t'], t['one_s'], t['zero_s'] = _labels([('h', 1, row), ('h', 0, row), ('h', 1, row), ('h', 0, row)], dev)
         if graphs is not None and graphs.ready('b'):
             recon_loss, fake1_src, w_tgt2 = graphs.run('b', t)
             w3 = None
