@@ -349,23 +349,23 @@ class RefDis(nn.Module):
 
 
 class _ResDis(nn.Module):
-    def __init__(self, n_in, n_out, clusters):
+    def __init__(self, n_in, n_out, clusters, w=64, h=64):
         super().__init__()
-        self.clusters, self.n_in = clusters, n_in
+        self.clusters, self.n_in, self.w, self.h = clusters, n_in, w, h
         self.model = nn.Sequential(
             nn.Conv2d(n_in, n_out, 3, 2, 1, bias=False), nn.BatchNorm2d(n_out), nn.LeakyReLU(inplace=True),
             nn.Conv2d(n_in * 2, n_out * 2, 3, 2, 1, bias=False), nn.BatchNorm2d(n_out * 2), nn.LeakyReLU(inplace=True),
             nn.Conv2d(n_out * 2, n_out * 2, 3, 2, 1, bias=False))
 
     def forward(self, x):
-        t = self.model(x.view(self.clusters, self.n_in, 64, 64))
+        t = self.model(x.view(self.clusters, self.n_in, self.w, self.h))   # the reference hard-codes 64 x 64 (VGG's 4096-d feature)
         return torch.squeeze(nn.AvgPool2d(t.size()[2:])(t))
 
 
 class RefDisPatch(nn.Module):
-    def __init__(self, n_in=128, n_out=256, clusters=4):
+    def __init__(self, n_in=128, n_out=256, clusters=4, w=64, h=64):
         super().__init__()
-        self.model_A_patch = nn.Sequential(_ResDis(n_in, n_out, clusters))
+        self.model_A_patch = nn.Sequential(_ResDis(n_in, n_out, clusters, w, h))
         self.apply(gaussian_weights_init)
 
     def forward(self, x):
