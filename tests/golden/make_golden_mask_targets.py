@@ -37,6 +37,11 @@ def main():
         assert np.array_equal(out[name + "_labels"].astype(np.float32), labels.numpy())
         out[name + "_rng_after"] = np.array(np.random.randint(1 << 30))  # the RNG stream position after the call
         print(name, tuple(rois.shape), tuple(labels.shape))
+    # predict_masks (functions/mask.py:21-49; PIL is present here, so this one runs entirely on the reference's own code)
+    rois, heat, info = mcases.predict_case()
+    pm = ns.mask.predict_masks(torch.from_numpy(rois), torch.from_numpy(heat), info)
+    out["predict_masks"] = np.stack(pm).astype(np.float32)
+    print("predict_masks", out["predict_masks"].shape)
     np.savez_compressed(os.path.join(HERE, "mask_targets_ref.npz"), **out)
 
 

@@ -54,3 +54,13 @@ def make(name):
     props = np.concatenate(props).astype(np.float32)
     info = np.tile(np.array([[H, W, 1.0]], dtype=np.float32), (B, 1))
     return props, gts, masks, info, dict(cfg)
+
+
+def predict_case():
+    """rois [R, 7] (b, x1, y1, x2, y2, score, class) inside a 60 x 80 image, heat maps [R, 4, 14, 14], image_info [[60, 80, 1]]"""
+    rng = np.random.RandomState(17)
+    R = 6
+    x1 = rng.randint(0, 40, R); y1 = rng.randint(0, 30, R)
+    rois = np.stack([np.zeros(R), x1, y1, x1 + rng.randint(2, 39, R), y1 + rng.randint(2, 29, R), rng.rand(R), rng.randint(0, 4, R)], 1)
+    heat = rng.rand(R, 4, 14, 14).astype(np.float32)
+    return rois.astype(np.float32), heat, np.array([[60, 80, 1.0]], dtype=np.float32)

@@ -127,3 +127,13 @@ def test_generate_mask_labels_equals_per_window_resize():
         for i, (a, b, c, d) in enumerate(rois.astype(np.int32)):
             assert np.array_equal(got[i], resize_linear_u8(masks[index[i]][b:d, a:c], mw, mh)), i
     assert np.array_equal(generate_mask_labels(rois[:5], masks, 14, 14), generate_mask_labels(rois[:5], masks, 14, 14, index=np.arange(5)))
+
+
+def test_predict_masks_equals_reference():
+    """functions/mask.py:21-49 -- each RoI's class plane resized to the RoI with PIL and pasted into the image (the reference's own
+    code produced the fixture: PIL is available in the build container)"""
+    from scda_amd.dropin.functions.mask import predict_masks
+    rois, heat, info = mcases.predict_case()
+    got = predict_masks(torch.from_numpy(rois), torch.from_numpy(heat), info)
+    assert len(got) == rois.shape[0] and all(m.shape == (60, 80) and m.dtype == np.float32 for m in got)
+    assert np.array_equal(np.stack(got), GOLD["predict_masks"])
