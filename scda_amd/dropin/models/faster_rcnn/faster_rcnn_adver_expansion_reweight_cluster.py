@@ -9,6 +9,7 @@ back-propagates: reweight_cluster.py:171-186), so its activations are not retain
 import functools
 import logging
 
+import os
 import torch
 import torch.nn as nn
 
@@ -142,6 +143,25 @@ class FasterRCNN_AdEx(nn.Module):
         feat = self.feature_extractor(image)
         rpn_cls, rpn_loc = self.rpn(feat)
         src_host = _rpn_outputs(_objectness(rpn_cls), rpn_loc.detach()) if self.training else None
+        # With the step's side stream: the target image's backbone + RPN go onto THAT stream, behind the source's, instead of into
+        # the compute stream in front of the source's RCNN work.  The device still has them to work through while the host ranks
+        # the source proposals, but the source RCNN forward and the detector backward no longer queue behind them, and where the
+        # two streams overlap one launch's workgroups store while the other's multiply (24.1 -> 23.8 ms, same-box A/B; starting
+        # the target backbone EARLIER, beside the source's, finishes the pair sooner -- 5.65 instead of 6.0 ms -- but then nothing
+        # covers the host's 1.6 ms of proposal work: 25.7 ms).  The event sits behind the source's LAST layer: every layer is used
+        # first on the compute stream, so a weight re-pack a first use triggers is ordered before the side stream reads it.
+        # SCDA_BACKBONE_SIDE=0: as before, on the compute stream.
+        side0 = input.get('_side_stream') if self.training else None
+        if side0 is not None and os.environ.get("SCDA_BACKBONE_SIDE", "1") == "0":
+            side0 = None
+        if side0 is not None:
+            ev_src = torch.cuda.Event()
+            ev_src.record()
+            side0.wait_event(ev_src)
+            with torch.cuda.stream(side0), torch.no_grad():
+                feat_t = self.feature_extractor(target)
+                rpn_cls_t, rpn_loc_t = self.rpn(feat_t)
+                tgt_host = _rpn_outputs(_objectness(rpn_cls_t), rpn_loc_t)
 
         if not self.training:
             proposals = fn['rpn_proposal_fn'](_objectness(rpn_cls), rpn_loc.detach())
@@ -155,10 +175,11 @@ class FasterRCNN_AdEx(nn.Module):
         # The target image's backbone + RPN are enqueued NOW, before any host-side box logic: the MI355X works through
         # them while the host labels anchors / sorts proposals for the source image.  Results are unaffected (no RNG in
         # these layers); every RNG-consuming call below keeps the reference's order.
-        with torch.no_grad():
-            feat_t = self.feature_extractor(target)
-            rpn_cls_t, rpn_loc_t = self.rpn(feat_t)
-            tgt_host = _rpn_outputs(_objectness(rpn_cls_t), rpn_loc_t)
+        if side0 is None:
+            with torch.no_grad():
+                feat_t = self.feature_extractor(target)
+                rpn_cls_t, rpn_loc_t = self.rpn(feat_t)
+                tgt_host = _rpn_outputs(_objectness(rpn_cls_t), rpn_loc_t)
         ev_backbones = torch.cuda.Event()
         ev_backbones.record()
         mark('backbones_enqueued')
