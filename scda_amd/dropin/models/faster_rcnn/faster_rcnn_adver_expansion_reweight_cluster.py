@@ -150,9 +150,11 @@ class FasterRCNN_AdEx(nn.Module):
         # the target backbone EARLIER, beside the source's, finishes the pair sooner -- 5.65 instead of 6.0 ms -- but then nothing
         # covers the host's 1.6 ms of proposal work: 25.7 ms).  The event sits behind the source's LAST layer: every layer is used
         # first on the compute stream, so a weight re-pack a first use triggers is ordered before the side stream reads it.
-        # SCDA_BACKBONE_SIDE=0: as before, on the compute stream.
+        # OPT-IN (SCDA_BACKBONE_SIDE=1): the iteration gains 0.3-1.4 % with it, but the dominant convolution launches then share the
+        # chip with the other stream's kernels and their per-launch time -- what bench.py's roofline object reports -- rises from
+        # 0.204 to 0.235 ms (0.76 -> 0.66 of the MFMA peak) without the kernels having changed.
         side0 = input.get('_side_stream') if self.training else None
-        if side0 is not None and os.environ.get("SCDA_BACKBONE_SIDE", "1") == "0":
+        if side0 is not None and os.environ.get("SCDA_BACKBONE_SIDE", "0") != "1":
             side0 = None
         if side0 is not None:
             ev_src = torch.cuda.Event()
