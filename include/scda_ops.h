@@ -104,7 +104,7 @@ int scda_roi_align_bwd_hip(const float *top_grad, const float *rois, int R, int 
 /* the same operator with the pooled maps stored CHANNEL-MAJOR: out / top_grad are [C,R,AH,AW].  No reference counterpart: it is
  * the layout the ResNet-C4 RoI head (models/mask_rcnn/resnet.py:140-146, layer4 on R x 7 x 7 maps) runs in here -- viewed as
  * [1, C, R*AH', AW'] every 1x1 convolution and every batch-norm of the head sees one long contiguous row per channel instead of
- * R pieces of 49 floats (see scda_conv2d_next_row_period for the 3x3 convolutions). */
+ * R pieces of 49 floats (see the row_period argument of the conv entry points for the 3x3 convolutions). */
 int scda_roi_align_cmajor_fwd_hip(const float *features, const float *rois, int R, int B, int C, int H, int W, int AH, int AW,
                                   float spatial_scale, float *out, void *stream);
 int scda_roi_align_cmajor_bwd_hip(const float *top_grad, const float *rois, int R, int B, int C, int H, int W, int AH,
@@ -205,36 +205,35 @@ long long scda_conv2d_pack_tiles(int Cout, int Cin, int KH, int KW, int for_dgra
 int scda_conv2d_pack_weights_batched_hip(const float *base, float *out, const long long *desc, int n, long long n_tiles,
                                          void *stream);
 /* wp = pack(w, 0) */
+/* row_period (all conv entry points): 0 = plain image.  > 0: the image [batch, C, IH, IW] is a vertical STACK of independent
+ * maps of `row_period` rows each (IH % row_period == 0; stride 1, 2*P == K-1) and filter taps must not reach from one map into
+ * the next -- what a batch of R maps [R, C, period, IW] computes, on the channel-major layout [1, C, R*period, IW].  A call
+ * that cannot honour it fails with SCDA_EINVAL. */
 int scda_conv2d_fwd_hip(const float *x, const float *wp, const float *bias /*[Cout] or NULL*/, float *y, int batch,
-                        int Cin, int IH, int IW, int Cout, int KH, int KW, int S, int P, int act, float slope,
+                        int Cin, int IH, int IW, int Cout, int KH, int KW, int S, int P, int row_period, int act, float slope,
                         void *ws, size_t ws_bytes, void *stream);
 /* dx [batch,Cin,IH,IW] = conv-transpose of dy [batch,Cout,OH,OW] (fully overwritten); wt = pack(w, 1) */
 int scda_conv2d_dgrad_hip(const float *dy, const float *wt, float *dx, int batch, int Cin, int IH, int IW, int Cout,
-                          int KH, int KW, int S, int P, void *ws, size_t ws_bytes, void *stream);
+                          int KH, int KW, int S, int P, int row_period, void *ws, size_t ws_bytes, void *stream);
 /* ... with the gradient of the activation that PRODUCED this conv's input folded into the epilogue (replaces one elementwise
  * pass of the reference's autograd: ReLU / LeakyReLU backward of models/faster_rcnn/vgg_adver_expansion_cluster.py:108-111,
  * common_net.py:251-262): dx = dgrad(dy) * (act_src > 0 ? 1 : act_slope); act_src = the conv's input x, or NULL */
 int scda_conv2d_dgrad_act_hip(const float *dy, const float *wt, float *dx, int batch, int Cin, int IH, int IW, int Cout,
-                              int KH, int KW, int S, int P, const float *act_src, float act_slope, void *ws, size_t ws_bytes,
-                              void *stream);
+                              int KH, int KW, int S, int P, int row_period, const float *act_src, float act_slope, void *ws,
+                              size_t ws_bytes, void *stream);
 /* the same for a conv with <= 4 input channels (image-side layers), direct form, HBM-bound on dy; w = the UNPACKED weight */
 int scda_conv2d_dgrad_small_cin_hip(const float *dy, const float *w, float *dx, int batch, int Cin, int IH, int IW, int Cout,
                                     int KH, int KW, int S, int P, void *stream);
 /* dw [Cout,Cin,KH,KW] (+)= sum over batch and pixels; deterministic split-K (no atomics) */
 int scda_conv2d_wgrad_hip(const float *dy, const float *x, float *dw, int batch, int Cin, int IH, int IW, int Cout,
-                          int KH, int KW, int S, int P, int accumulate, void *ws, size_t ws_bytes, void *stream);
+                          int KH, int KW, int S, int P, int row_period, int accumulate, void *ws, size_t ws_bytes, void *stream);
 /* the same plus the bias gradient db[Cout] (+)= sum over batch and pixels of dy, fused: the row sums ride along on the
  * operand fragments of the weight-gradient GEMM and are finished by its split-K reduce (no extra launches, no second read
  * of dy).  Only when scda_conv2d_wgrad_bias_fusable(...) != 0 (OH*OW % 16 == 0, 16-byte aligned dy); otherwise call
  * scda_conv2d_wgrad_hip + scda_bias_grad_nchw_hip. */
 int scda_conv2d_wgrad_bias_fusable(int batch, int Cout, int OH, int OW, const float *dy);
-/* One-shot modifier of the calling thread's NEXT scda_conv2d_{fwd,dgrad,dgrad_act,wgrad,wgrad_bias}_hip call: the image
- * [batch, C, IH, IW] is a vertical STACK of independent maps of `period` rows each (IH % period == 0; stride 1, 2*P == K-1) and
- * filter taps must not reach from one map into the next -- what a batch of R maps [R, C, period, IW] computes, on the
- * channel-major layout [1, C, R*period, IW].  0 clears it.  A call it cannot honour fails with SCDA_EINVAL. */
-void scda_conv2d_next_row_period(int period);
 int scda_conv2d_wgrad_bias_hip(const float *dy, const float *x, float *dw, float *db, int batch, int Cin, int IH, int IW,
-                               int Cout, int KH, int KW, int S, int P, int accumulate, int db_accumulate, void *ws,
+                               int Cout, int KH, int KW, int S, int P, int row_period, int accumulate, int db_accumulate, void *ws,
                                size_t ws_bytes, void *stream);
 
 /* C[M,N] (row stride ldc) (+)= op(A) op(B) (+ bias) -> act

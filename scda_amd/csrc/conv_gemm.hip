@@ -1921,16 +1921,10 @@ using namespace scda;
 
 static int conv_out_dim(int in, int k, int s, int p) { return (in + 2 * p - k) / s + 1; }
 
-// scda_conv2d_next_row_period: one-shot, per-thread modifier of the NEXT conv entry point called on this thread (forward, data
-// gradient or weight gradient): the image is a stack of independent maps of `period` rows (ConvGeom::row_period).
-static thread_local int g_next_row_period = 0;
-SCDA_API void scda_conv2d_next_row_period(int period) { g_next_row_period = period > 0 ? period : 0; }
-
-// consumes the modifier; -1 = set but illegal for this convolution
-static int take_row_period(const char *who, int IH, int KH, int KW, int S, int P) {
-    const int period = g_next_row_period;
-    g_next_row_period = 0;
-    if (!period) return 0;
+// row_period argument of the conv entry points: the image is a stack of independent maps of `period` rows (ConvGeom::row_period).
+// validated period (0: plain image); -1 = illegal for this convolution
+static int take_row_period(const char *who, int period, int IH, int KH, int KW, int S, int P) {
+    if (period <= 0) return 0;
     if (S != 1 || KH != KW || 2 * P != KH - 1 || (IH % period) != 0) {
         set_error("%s: row period %d needs a stride-1 same-size convolution on an image whose height (%d) is a multiple of it", who, period, IH);
         return -1;
@@ -1954,9 +1948,9 @@ SCDA_API size_t scda_conv2d_workspace_bytes(int batch, int Cin, int IH, int IW, 
 }
 
 SCDA_API int scda_conv2d_fwd_hip(const float *x, const float *w, const float *bias, float *y, int batch, int Cin, int IH,
-                                 int IW, int Cout, int KH, int KW, int S, int P, int act, float slope, void *ws,
+                                 int IW, int Cout, int KH, int KW, int S, int P, int row_period_arg, int act, float slope, void *ws,
                                  size_t ws_bytes, void *stream) {
-    const int row_period = take_row_period("scda_conv2d_fwd_hip", IH, KH, KW, S, P);   // first: a rejected call must not leave it armed
+    const int row_period = take_row_period("scda_conv2d_fwd_hip", row_period_arg, IH, KH, KW, S, P);
     if (row_period < 0) return SCDA_EINVAL;
     if (!x || !w || !y || batch <= 0 || Cin <= 0 || Cout <= 0) { set_error("scda_conv2d_fwd_hip: bad arguments"); return SCDA_EINVAL; }
     if (!zero_page()) { set_error("scda_conv2d_fwd_hip: could not allocate the zero page"); return SCDA_ELAUNCH; }
@@ -1977,16 +1971,16 @@ SCDA_API int scda_conv2d_fwd_hip(const float *x, const float *w, const float *bi
 
 // dx = dgrad(dy, wt) where wt = pack(w, for_dgrad=1) is [Cin][KH*KW][Cout] (scda_conv2d_pack_weight_hip)
 SCDA_API int scda_conv2d_dgrad_hip(const float *dy, const float *wt, float *dx, int batch, int Cin, int IH, int IW,
-                                   int Cout, int KH, int KW, int S, int P, void *ws, size_t ws_bytes, void *stream) {
-    return scda_conv2d_dgrad_act_hip(dy, wt, dx, batch, Cin, IH, IW, Cout, KH, KW, S, P, nullptr, 0.f, ws, ws_bytes, stream);
+                                   int Cout, int KH, int KW, int S, int P, int row_period, void *ws, size_t ws_bytes, void *stream) {
+    return scda_conv2d_dgrad_act_hip(dy, wt, dx, batch, Cin, IH, IW, Cout, KH, KW, S, P, row_period, nullptr, 0.f, ws, ws_bytes, stream);
 }
 
 // ... with the activation gradient of the layer that PRODUCED this conv's input folded into the epilogue:
 // dx = dgrad(dy) * (act_src > 0 ? 1 : act_slope), act_src = the conv's input x [batch,Cin,IH,IW] (a ReLU / LeakyReLU output)
 SCDA_API int scda_conv2d_dgrad_act_hip(const float *dy, const float *wt, float *dx, int batch, int Cin, int IH, int IW,
-                                       int Cout, int KH, int KW, int S, int P, const float *act_src, float act_slope,
+                                       int Cout, int KH, int KW, int S, int P, int row_period_arg, const float *act_src, float act_slope,
                                        void *ws, size_t ws_bytes, void *stream) {
-    const int row_period = take_row_period("scda_conv2d_dgrad_hip", IH, KH, KW, S, P);   // first, as in the forward
+    const int row_period = take_row_period("scda_conv2d_dgrad_hip", row_period_arg, IH, KH, KW, S, P);
     if (row_period < 0) return SCDA_EINVAL;
     if (!dy || !wt || !dx || batch <= 0) { set_error("scda_conv2d_dgrad_hip: bad arguments"); return SCDA_EINVAL; }
     const int OH = conv_out_dim(IH, KH, S, P), OW = conv_out_dim(IW, KW, S, P);
@@ -2042,9 +2036,9 @@ SCDA_API int scda_conv2d_pack_weights_batched_hip(const float *base, float *out,
 }
 
 SCDA_API int scda_conv2d_wgrad_hip(const float *dy, const float *x, float *dw, int batch, int Cin, int IH, int IW,
-                                   int Cout, int KH, int KW, int S, int P, int accumulate, void *ws, size_t ws_bytes,
+                                   int Cout, int KH, int KW, int S, int P, int row_period_arg, int accumulate, void *ws, size_t ws_bytes,
                                    void *stream) {
-    const int row_period = take_row_period("scda_conv2d_wgrad_hip", IH, KH, KW, S, P);   // first, as in the forward
+    const int row_period = take_row_period("scda_conv2d_wgrad_hip", row_period_arg, IH, KH, KW, S, P);
     if (row_period < 0) return SCDA_EINVAL;
     if (!dy || !x || !dw || !ws) { set_error("scda_conv2d_wgrad_hip: bad arguments"); return SCDA_EINVAL; }
     const int OH = conv_out_dim(IH, KH, S, P), OW = conv_out_dim(IW, KW, S, P);
@@ -2065,9 +2059,9 @@ SCDA_API int scda_conv2d_wgrad_bias_fusable(int batch, int Cout, int OH, int OW,
 }
 
 SCDA_API int scda_conv2d_wgrad_bias_hip(const float *dy, const float *x, float *dw, float *db, int batch, int Cin, int IH,
-                                        int IW, int Cout, int KH, int KW, int S, int P, int accumulate, int db_accumulate,
+                                        int IW, int Cout, int KH, int KW, int S, int P, int row_period_arg, int accumulate, int db_accumulate,
                                         void *ws, size_t ws_bytes, void *stream) {
-    const int row_period = take_row_period("scda_conv2d_wgrad_bias_hip", IH, KH, KW, S, P);   // first, as in the forward
+    const int row_period = take_row_period("scda_conv2d_wgrad_bias_hip", row_period_arg, IH, KH, KW, S, P);
     if (row_period < 0) return SCDA_EINVAL;
     if (!dy || !x || !dw || !db || !ws) { set_error("scda_conv2d_wgrad_bias_hip: bad arguments"); return SCDA_EINVAL; }
     const int OH = conv_out_dim(IH, KH, S, P), OW = conv_out_dim(IW, KW, S, P);

@@ -9,19 +9,16 @@ import torch.nn as nn
 from scda_amd import layers as L
 from scda_amd.autograd_ops import ACT_RELU
 
-_HIDDEN = 512
-
 
 class NaiveRpnHead(nn.Module):
     def __init__(self, inplanes, num_classes, num_anchors):
         super().__init__()
         self.num_classes = num_classes
         self.num_anchors = num_anchors
-        siblings = {"conv_cls": num_anchors * num_classes, "conv_loc": num_anchors * 4}
-        self.conv3x3 = L.Conv2d(inplanes, _HIDDEN, kernel_size=3, stride=1, padding=1, fused_act=ACT_RELU)
+        self.conv3x3 = L.Conv2d(inplanes, 512, kernel_size=3, stride=1, padding=1, fused_act=ACT_RELU)
         self.relu3x3 = L.FusedAct("ReLU")
-        for name, width in siblings.items():            # registration order = state_dict order: cls, then loc
-            setattr(self, name, L.Conv2d(_HIDDEN, width, kernel_size=1, stride=1))
+        self.conv_cls = L.Conv2d(512, num_anchors * num_classes, kernel_size=1, stride=1)
+        self.conv_loc = L.Conv2d(512, num_anchors * 4, kernel_size=1, stride=1)
 
     def forward(self, x):
         hidden = self.relu3x3(self.conv3x3(x))

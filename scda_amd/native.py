@@ -372,12 +372,6 @@ def conv2d_pack_all(flat):
         _PACK_CACHE[(w.data_ptr(), d)] = ((w._version, flat.epoch, tuple(w.shape)), out[off:off + n], weakref.ref(w))
 
 
-def _row_period(period):
-    """one-shot modifier of the next conv entry point called on this thread (include/scda_ops.h: scda_conv2d_next_row_period)"""
-    if period:
-        lib().scda_conv2d_next_row_period(i32(period))
-
-
 def conv2d_fwd(x, w, bias, stride, pad, act=ACT_NONE, slope=0.01, row_period=0):
     _req(x, "x"); _req(w, "w")
     if bias is not None:
@@ -391,9 +385,8 @@ def conv2d_fwd(x, w, bias, stride, pad, act=ACT_NONE, slope=0.01, row_period=0):
     wp = conv2d_pack_weight(w, False)
     y = torch.empty(B, Cout, OH, OW, dtype=torch.float32, device=x.device)
     ws, n = _conv_ws(B, Cin, IH, IW, Cout, KH, KW, stride, pad, x.device)
-    _row_period(row_period)
     _check(lib().scda_conv2d_fwd_hip(_p(x), _p(wp), _p(bias), _p(y), i32(B), i32(Cin), i32(IH), i32(IW), i32(Cout), i32(KH),
-                                     i32(KW), i32(stride), i32(pad), i32(act), f32(slope), _p(ws), _sz(n), _stream()),
+                                     i32(KW), i32(stride), i32(pad), i32(row_period), i32(act), f32(slope), _p(ws), _sz(n), _stream()),
            "scda_conv2d_fwd_hip")
     return y
 
@@ -417,9 +410,8 @@ def conv2d_dgrad(dy, w, x_shape, stride, pad, act_src=None, act_slope=0.0, row_p
         return dx
     wt = conv2d_pack_weight(w, True)
     ws, n = _conv_ws(B, Cin, IH, IW, Cout, KH, KW, stride, pad, dy.device)
-    _row_period(row_period)
     _check(lib().scda_conv2d_dgrad_act_hip(_p(dy), _p(wt), _p(dx), i32(B), i32(Cin), i32(IH), i32(IW), i32(Cout), i32(KH),
-                                           i32(KW), i32(stride), i32(pad), _p(act_src), f32(act_slope), _p(ws), _sz(n), _stream()),
+                                           i32(KW), i32(stride), i32(pad), i32(row_period), _p(act_src), f32(act_slope), _p(ws), _sz(n), _stream()),
            "scda_conv2d_dgrad_act_hip")
     return dx
 
@@ -435,9 +427,8 @@ def conv2d_wgrad(dy, x, w_shape, stride, pad, out=None, row_period=0):
     else:
         _req(out, "out"); acc = 1
     ws, n = _conv_ws(B, Cin, IH, IW, Cout, KH, KW, stride, pad, x.device)
-    _row_period(row_period)
     _check(lib().scda_conv2d_wgrad_hip(_p(dy), _p(x), _p(out), i32(B), i32(Cin), i32(IH), i32(IW), i32(Cout), i32(KH),
-                                       i32(KW), i32(stride), i32(pad), i32(acc), _p(ws), _sz(n), _stream()),
+                                       i32(KW), i32(stride), i32(pad), i32(row_period), i32(acc), _p(ws), _sz(n), _stream()),
            "scda_conv2d_wgrad_hip")
     return out
 
@@ -462,9 +453,8 @@ def conv2d_wgrad_bias(dy, x, w_shape, stride, pad, out=None, db_out=None, row_pe
     else:
         _req(db_out, "db_out"); dbacc = 1
     ws, n = _conv_ws(B, Cin, IH, IW, Cout, KH, KW, stride, pad, x.device)
-    _row_period(row_period)
     _check(L.scda_conv2d_wgrad_bias_hip(_p(dy), _p(x), _p(out), _p(db_out), i32(B), i32(Cin), i32(IH), i32(IW), i32(Cout),
-                                        i32(KH), i32(KW), i32(stride), i32(pad), i32(acc), i32(dbacc), _p(ws), _sz(n),
+                                        i32(KH), i32(KW), i32(stride), i32(pad), i32(row_period), i32(acc), i32(dbacc), _p(ws), _sz(n),
                                         _stream()), "scda_conv2d_wgrad_bias_hip")
     return out, db_out
 

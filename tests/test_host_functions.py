@@ -137,6 +137,24 @@ def test_anchor_grid_matches_reference(golden_dir):
     np.testing.assert_array_equal(anchor_helper.get_anchors_over_plane(32, 64, [7.0], [2, 4, 8, 16, 32], 16), a)
 
 
+def test_crop_corners_match_reference(golden_dir):
+    """a9: the 256 x 256 crop window around each cluster centre, pushed inside the 1024 x 512 image, against the output of the
+    reference's own get_corner_from_center (tools/faster_rcnn_train_val.py:411-438) on 64 centres (tests/golden/make_golden.py:
+    gen_corners) -- both clamp edges ((0, 0), (1023.9, 511.9)), centres on .5 (int() truncation) and the x2 == new_w / y2 == new_h
+    branches that move the window's first corner"""
+    from scda_amd.train_step import get_corner_from_center
+    g = np.load(os.path.join(golden_dir, "corners.npz"))
+    got = np.array(get_corner_from_center(g["centres"], 256, 1024, 512), dtype=np.int32)
+    np.testing.assert_array_equal(got, g["corners"])
+    # every window is exactly recon x recon and inside the image (what _crops asserts before slicing)
+    assert np.all(got[:, 2] - got[:, 0] == 256) and np.all(got[:, 3] - got[:, 1] == 256)
+    assert got[:, :2].min() >= 0 and got[:, 2].max() <= 1024 and got[:, 3].max() <= 512
+    # the fixture exercises all four clamps
+    assert (got[:, 0] == 0).any() and (got[:, 1] == 0).any() and (got[:, 2] == 1024).any() and (got[:, 3] == 512).any()
+    # rectangular windows (the ResNet configuration's 128 x 256 reconstructions): the square case is the (s, s) special case
+    np.testing.assert_array_equal(np.array(get_corner_from_center(g["centres"], (256, 256), 1024, 512), dtype=np.int32), g["corners"])
+
+
 def test_proposal_targets_pad_by_resampling(cpu_backend):
     """fewer candidates than batch_size -> padded with replacement to exactly 512 (proposal_target.py:149-155)"""
     from scda_amd.dropin.functions.proposal_target import compute_proposal_targets
