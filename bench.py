@@ -195,6 +195,8 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        # the line printed below says n_gpus = world: refuse to print it for a group of any other size
+        assert dist.get_world_size() == a.gpus == world, (dist.get_world_size(), a.gpus, world)
 
     from scda_amd import native
     from scda_amd.train_step import ScdaTrainer

@@ -121,7 +121,7 @@ def test_resnet50_scda_iteration(cuda):
 
 @pytest.mark.parametrize("R,C,Co,k", [(32, 32, 48, 3), (48, 16, 16, 3), (16, 64, 32, 1), (5, 8, 8, 3)])
 def test_conv_on_stacked_maps_equals_batched_conv(cuda, R, C, Co, k):
-    """row_period (include/scda_ops.h: scda_conv2d_next_row_period): a 3x3 convolution of the channel-major view [1, C, R*7, 7]
+    """row_period (include/scda_ops.h: the row_period argument of the conv entry points): a 3x3 convolution of the channel-major view [1, C, R*7, 7]
     with row period 7 == the convolution of the batch [R, C, 7, 7], forward, data gradient and weight gradient (the direct-to-
     LDS kernels when R*49 % 16 == 0 and C % 16 == 0, the register-staged ones otherwise)"""
     from scda_amd import native
