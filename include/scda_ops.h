@@ -200,7 +200,9 @@ int scda_conv2d_pack_weight_hip(const float *w, float *out, int Cout, int Cin, i
 /* The same packing for MANY weights in one launch (all conv layers of an optimiser group, right after its Adam step), one
  * workgroup per tile, both sides coalesced through LDS: desc = n rows of 7 int64 {source offset in floats from `base`, destination
  * offset in floats from `out`, Cout, Cin, KH*KW, for_dgrad, first tile id}, destinations ascending and back to back, tile ids
- * consecutive: a row owns scda_conv2d_pack_tiles(...) of them; n_tiles = their sum. */
+ * consecutive: a row owns scda_conv2d_pack_tiles(...) of them; n_tiles = their sum.  for_dgrad 2 / 3 in a row (and in
+ * scda_conv2d_packed_elems / scda_conv2d_pack_tiles): the Winograd kernel's transformed filters for the forward / the data gradient
+ * (3x3 only; see scda_conv2d_wino_pack_hip below). */
 long long scda_conv2d_pack_tiles(int Cout, int Cin, int KH, int KW, int for_dgrad);
 int scda_conv2d_pack_weights_batched_hip(const float *base, float *out, const long long *desc, int n, long long n_tiles,
                                          void *stream);
@@ -235,6 +237,22 @@ int scda_conv2d_wgrad_bias_fusable(int batch, int Cout, int OH, int OW, const fl
 int scda_conv2d_wgrad_bias_hip(const float *dy, const float *x, float *dw, float *db, int batch, int Cin, int IH, int IW,
                                int Cout, int KH, int KW, int S, int P, int row_period, int accumulate, int db_accumulate, void *ws,
                                size_t ws_bytes, void *stream);
+
+/* Winograd F(2x2, 3x3) form of the stride-1, pad-1 3x3 convolution on the fp32 MFMA (csrc/conv_wino.hip): 2.25x fewer matrix
+ * operations than the implicit GEMM above, fp32 throughout (results differ from the direct form by rounding only: the transforms
+ * use the exact constants 0, +-1, +-1/2).  What cuDNN picks for the same nn.Conv2d layers of the reference
+ * (vgg_adver_expansion_cluster.py:101-114, head.py:13, common_net.py:59-80).
+ *   scda_conv2d_wino_supported: C % 8 == 0, H % 8 == 0, W % 32 == 0, per-image tensors below 2 GB
+ *   u = scda_conv2d_wino_pack_hip(w [Cout,Cin,3,3], for_dgrad): the transformed filters G g G^T in the kernel's MFMA fragment
+ *       order, scda_conv2d_wino_packed_elems floats; for_dgrad = 1: the data gradient's filters (rows = Cin, rotated by 180 degrees)
+ *   scda_conv2d_wino_hip: y [batch,M,H,W] = act(conv3x3(x [batch,C,H,W]) + bias), optionally * act'(mask_src) as
+ *       scda_conv2d_dgrad_act_hip does; forward: (C, M) = (Cin, Cout), u = pack(w, 0); data gradient: x = dy, (C, M) = (Cout, Cin),
+ *       u = pack(w, 1).  for_dgrad only labels the launch for scda_prof_*.  ws: split-K slabs (scda_conv2d_workspace_bytes). */
+int scda_conv2d_wino_supported(int batch, int C, int H, int W, int M);
+size_t scda_conv2d_wino_packed_elems(int Cout, int Cin, int for_dgrad);
+int scda_conv2d_wino_pack_hip(const float *w, float *out, int Cout, int Cin, int for_dgrad, void *stream);
+int scda_conv2d_wino_hip(const float *x, const float *u, const float *bias, float *y, int batch, int C, int H, int W, int M, int act,
+                         float slope, const float *mask_src, float mask_slope, int for_dgrad, void *ws, size_t ws_bytes, void *stream);
 
 /* C[M,N] (row stride ldc) (+)= op(A) op(B) (+ bias) -> act
  * trans_a = 0: A is [M,K] row-major (lda);  1: A is stored [K,M]

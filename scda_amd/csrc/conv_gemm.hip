@@ -34,6 +34,7 @@
 #include <vector>
 
 #include "mfma_tile.h"
+#include "wino_pack.h"
 
 namespace scda {
 
@@ -1590,6 +1591,7 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const float *
     const float *w = base + d[0];
     float *o = out + d[1];
     const int Cout = (int)d[2], Cin = (int)d[3], R = (int)d[4], for_dgrad = (int)d[5], t = (int)(id - d[6]);
+    if (for_dgrad >= 2) { pack_tile_wino(w, o, Cout, Cin, for_dgrad - 2, t, tile); return; }   // Winograd filters (modes 2 / 3)
     const int C = for_dgrad ? Cout : Cin, M = for_dgrad ? Cin : Cout;
     if ((C % BK) == 0 && R == 9) pack_tile_blocked<9>(w, o, Cout, Cin, for_dgrad, t, tile);
     else if ((C % BK) == 0 && R == 1) pack_tile_blocked<1>(w, o, Cout, Cin, for_dgrad, t, tile);
@@ -1603,6 +1605,7 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const float *
 
 // tiles of one layer in pack_weights_batched_kernel's numbering (the caller builds the descriptor table with it)
 SCDA_API long long scda_conv2d_pack_tiles(int Cout, int Cin, int KH, int KW, int for_dgrad) {
+    if (for_dgrad >= 2) return (KH == 3 && KW == 3) ? wino_pack_tiles(for_dgrad == 3 ? Cin : Cout, for_dgrad == 3 ? Cout : Cin) : 0;
     const int C = for_dgrad ? Cout : Cin, M = for_dgrad ? Cin : Cout, R = KH * KW;
     if ((C % BK) == 0 && (R == 9 || R == 1)) return (long long)(conv_packed_mpad(M) / 64) * (C / BK);
     const long long total = (long long)((C % BK) == 0 ? conv_packed_mpad(M) : M) * C * R;
@@ -1828,6 +1831,21 @@ static int launch_conv(const float *Wm, const float *X, const ConvGeom &g0, Epi 
     return launch_status("conv_splitk_reduce_kernel");
 }
 
+// the same combine for split-K slabs written by another translation unit (conv_wino.hip): ws [splits][M][N] in the natural
+// pixel order, N = batch * phw
+int launch_conv_reduce(const float *ws, int splits, int M, int N, int phw, const float *bias, int act, float slope, float *out,
+                       const float *mask_src, float mask_slope, hipStream_t st) {
+    const Div d(phw);
+    const bool vec = (N & 3) == 0 && (phw & 3) == 0 && ((((uintptr_t)ws) | ((uintptr_t)out) | ((uintptr_t)mask_src)) & 15) == 0;
+    if (vec)
+        hipLaunchKernelGGL(conv_splitk_reduce_kernel<true>, dim3(ew_grid(((long long)M * N) >> 2)), dim3(256), 0, st, ws, splits, M, N, d, bias,
+                           act, slope, out, mask_src, mask_slope);
+    else
+        hipLaunchKernelGGL(conv_splitk_reduce_kernel<false>, dim3(ew_grid((long long)M * N)), dim3(256), 0, st, ws, splits, M, N, d, bias, act,
+                           slope, out, mask_src, mask_slope);
+    return launch_status("conv_splitk_reduce_kernel");
+}
+
 template <int KH, int KW, int S>
 static int launch_wgrad(const float *dY, const float *X, WgradGeom g, float *dW, int accumulate, float *ws,
                         size_t ws_bytes, hipStream_t st, float *db = nullptr, int db_accumulate = 0) {
@@ -2014,6 +2032,7 @@ SCDA_API int scda_conv2d_dgrad_small_cin_hip(const float *dy, const float *w, fl
 }
 
 SCDA_API size_t scda_conv2d_packed_elems(int Cout, int Cin, int KH, int KW, int for_dgrad) {
+    if (for_dgrad >= 2) return (KH == 3 && KW == 3) ? (size_t)wino_packed_elems(for_dgrad == 3 ? Cin : Cout, for_dgrad == 3 ? Cout : Cin) : 0;
     const int C = for_dgrad ? Cout : Cin, M = for_dgrad ? Cin : Cout;
     const int mpad = (C % BK) == 0 ? conv_packed_mpad(M) : M;
     return (size_t)mpad * C * KH * KW;

@@ -1,0 +1,341 @@
+// conv_wino.hip -- Winograd F(2x2, 3x3) convolution on the fp32 MFMA (gfx950): forward and data gradient of the stride-1,
+// pad-1 3x3 layers (VGG conv1_2 .. conv5_3, the RPN's 3x3, the decoders' residual convolutions), behind scda_conv2d_wino_hip.
+// The reference reaches these layers through cuDNN (nn.Conv2d in models/faster_rcnn/vgg_adver_expansion_cluster.py:101-114,
+// models/head.py:13, models/faster_rcnn/common_net.py:59-80), which picks a Winograd algorithm for fp32 3x3 itself.
+//
+//   Y = A^T [ sum_c (G g_c G^T) .* (B^T d_c B) ] A         per 2x2 output tile, 4x4 input tile d, 3x3 filter g
+// 16 transform-domain positions xi = (a, b); per position a plain GEMM  M_xi[m][t] = sum_c U_xi[m][c] V_xi[c][t]  over tiles t:
+// 16 multiplies per 4 outputs instead of 36 -- 2.25x fewer MFMA operations than the direct implicit GEMM of conv_gemm.hip,
+// whose K loop already runs at the matrix pipe's sustained rate.
+//
+// One workgroup = 64 output channels x 64 tiles (4 tile rows x 16 tile columns = 8 x 32 output pixels of one image), all 16
+// positions, 8 waves.  Wave w owns TWO positions, xi = (a = w >> 1, b in {1, 2} or {0, 3}), and for them the whole 64 x 64
+// accumulator block (2 x 2 x 2 MFMA tiles = 128 accumulator registers).  Consequences:
+//   * U (the transformed weights) is needed by ONE wave only -> it never goes through LDS: scda_conv2d_pack_* lays it out in
+//     the MFMA A-fragment order, one global_load_dwordx4 per (position, 32-row block, 8-channel slab) and lane, prefetched one
+//     slab ahead into registers.  The m-tile is the fastest grid dimension, so XCD x mostly serves m-tile x % n_mt and its
+//     16 x 64 x C weights stay in that XCD's L2.
+//   * V is never materialised.  BT has two non-zeros per row, so V_ab[c][t] is a signed sum of FOUR raw input values; LDS holds
+//     only the raw (8 + 2) x (32 + 2) input patch of the slab's 8 channels (12.8 KB per stage, LDS-DMA, ring of 4), and every
+//     wave forms its own B fragments with 4 ds_read_b32 + 4 VALU per pair of positions (b in {1, 2} share their reads) or 8 + 6
+//     (b in {0, 3}).  Even and odd patch columns are stored apart (lane offsets chosen by the LDS-DMA's per-lane source address),
+//     so a half-wave's 32 tiles read 32 consecutive banks.
+//   * every wave also issues a share of the patch LDS-DMA (7 dword instructions per slab): dedicated staging waves would make it
+//     10 waves = 3 on some SIMDs = 168 registers per lane, less than the 128 accumulators + fragments need.
+// Ordering: vmcnt is in-order, a wave issues per slab [patch DMA for slab s+2][U loads for slab s+1] and waits for its U(s) before
+// the MFMAs of slab s -- which implies its DMA(s+1) has landed before barrier s+1.  One s_barrier per slab.
+// Epilogue: the 16 positions of an output tile live in 8 different waves: exchanged through LDS (32 rows at a time, 128 KB), then
+// every thread applies A^T . A to its (channel, tile) pairs and stores 2 x 2 pixels (+ bias, activation, the producer's act' mask
+// -- or a split-K slab in the natural pixel order, combined by conv_gemm.hip's reduce kernel).
+#include <stdlib.h>
+
+#include <algorithm>
+#include <type_traits>
+
+#include "mfma_tile.h"
+#include "wino_pack.h"
+
+namespace scda {
+
+int launch_conv_reduce(const float *ws, int splits, int M, int N, int phw, const float *bias, int act, float slope, float *out,
+                       const float *mask_src, float mask_slope, hipStream_t st);   // conv_gemm.hip
+
+typedef __attribute__((address_space(3))) void wino_lds_void_t;
+#if defined(__HIP_DEVICE_COMPILE__)
+// LDS-DMA through a buffer descriptor over [base, base + 2 GB): a lane offset with bit 31 set lands as 0.0 (see conv_gemm.hip)
+__device__ __forceinline__ void wino_dma_b32(const void *base, const unsigned voffset, float *lds_dst, const int soffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)0x80000000u, 0x00020000),
+                                             (wino_lds_void_t *)lds_dst, 4, voffset, soffset, 0, 0);
+}
+#else
+__device__ __forceinline__ void wino_dma_b32(const void *, const unsigned, float *, const int) {}
+#endif
+#define WINO_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+
+constexpr int WBK = WINO_BK;                    // channels per K-slab (8)
+constexpr int W_PR = 10, W_RS = 40;             // patch rows; row stride in floats: 17 even columns at 0.., 17 odd columns at 20..
+constexpr int W_CS = W_PR * W_RS;               // channel stride
+constexpr int W_DMA = 7;                        // LDS-DMA instructions per wave and slab: 8 x 7 x 64 slots >= 8 channels x 400
+constexpr int W_STAGE = 8 * W_DMA * 64;         // floats per ring stage (3584)
+constexpr int W_NST = 4;
+constexpr int W_MX = 16 * 32 * 64;              // epilogue exchange: [position][32 rows][64 tiles]
+static_assert(W_NST * W_STAGE <= W_MX && WBK * W_CS <= W_STAGE, "the ring lives inside the exchange buffer");
+
+struct WinoGeom {
+    int batch, C, H, W, M;
+    int n_mt, n_slab, slabs_per_split;
+    Div dNMT, dNPB, dNB, dNBX;   // m-tiles; pixel blocks of the launch; per image; per block row
+};
+
+struct WinoEpi {
+    float *out, *ws;
+    const float *bias;
+    int act;
+    float slope;
+    int splits;
+    const float *mask_src;
+    float mask_slope;
+};
+
+typedef float wino_f4 __attribute__((ext_vector_type(4)));
+typedef float wino_f2 __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(512, 2) void conv_wino_kernel(const float *__restrict__ U, const float *__restrict__ X, const WinoGeom g,
+                                                          const WinoEpi e) {
+    __shared__ __attribute__((aligned(16))) float lds[W_MX];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int rest, mt, sp, pb, img, bi, by, bx;
+    g.dNMT.divmod((int)blockIdx.x, rest, mt);
+    g.dNPB.divmod(rest, sp, pb);
+    g.dNB.divmod(pb, img, bi);
+    g.dNBX.divmod(bi, by, bx);
+    const int y0 = by * 8, x0 = bx * 32;
+    const int s_begin = sp * g.slabs_per_split, s_end = min(g.n_slab, s_begin + g.slabs_per_split);
+    const int plane = g.H * g.W;
+
+    // ---- this wave's share of the patch LDS-DMA: slot -> (channel, patch row, column), fixed for the whole kernel ---------------
+    unsigned dma_off[W_DMA];
+#pragma unroll
+    for (int i = 0; i < W_DMA; ++i) {
+        const int slot = (wave * W_DMA + i) * 64 + lane;
+        const int ch = slot / W_CS, rem = slot - ch * W_CS;
+        const int row = rem / W_RS, sl = rem - row * W_RS;
+        const int col = sl < 17 ? 2 * sl : (sl >= 20 && sl < 37) ? 2 * (sl - 20) + 1 : -1;
+        const int gy = y0 - 1 + row, gx = x0 - 1 + col;
+        const bool ok = ch < WBK && col >= 0 && (unsigned)gy < (unsigned)g.H && (unsigned)gx < (unsigned)g.W;
+        dma_off[i] = ok ? (unsigned)((ch * plane + gy * g.W + gx) * 4) : 0x80000000u;
+    }
+    const char *xbase = reinterpret_cast<const char *>(X + (size_t)img * g.C * plane);
+    auto issue_dma = [&](const int s, const int buf) {
+        float *dst = lds + buf * W_STAGE + wave * (W_DMA * 64);
+        const int soff = s * (WBK * plane * 4);
+#pragma unroll
+        for (int i = 0; i < W_DMA; ++i) wino_dma_b32(xbase, dma_off[i], dst + i * 64, soff);
+    };
+
+    // ---- this wave's two positions ------------------------------------------------------------------------------------------------
+    const int a = wave >> 1, bsel = wave & 1;
+    const int xi0 = a * 4 + (bsel ? 1 : 0), xi1 = a * 4 + (bsel ? 2 : 3);
+    // BT row a = signed sum of patch rows i1, i2:  0: d0 - d2   1: d1 + d2   2: d2 - d1   3: d1 - d3
+    const int i1 = a == 0 ? 0 : a == 2 ? 2 : 1, i2 = a == 0 ? 2 : a == 1 ? 2 : a == 2 ? 1 : 3;
+    const float sgn = a == 1 ? 1.f : -1.f;
+    const int j = lane & 31, h = lane >> 5;
+    const int lane_base = h * W_CS + (2 * (j >> 4)) * W_RS + (j & 15);
+    const int ro1 = lane_base + i1 * W_RS, ro2 = lane_base + i2 * W_RS;
+    const int n_mbg = g.n_mt * 2;
+    // U fragments: wave-uniform base per (position, 32-row block) + lane * 4 floats; one slab = 256 floats further on
+    const float *ub[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+            ub[x][mb] = U + (size_t)((x ? xi1 : xi0) * n_mbg + mt * 2 + mb) * g.n_slab * 256;
+    auto load_a = [&](const int s, wino_f4 (&A)[2][2]) {
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) A[x][mb] = *reinterpret_cast<const wino_f4 *>(ub[x][mb] + (size_t)s * 256 + lane * 4);
+    };
+
+    f32x16 acc[2][2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[x][mb][tb][r] = 0.f;
+
+    // the K loop, compiled once per column set (BSEL: b in {1, 2} -- four reads per fragment pair -- or {0, 3} -- eight)
+    auto k_loop = [&](auto bsel_tag) {
+        constexpr bool BSEL = decltype(bsel_tag)::value;
+        constexpr int NR = BSEL ? 4 : 8;
+        // One slab: barrier, issue the patch DMA of slab s + 2 and the U loads of slab s + 1 (UNCONDITIONALLY, with the slab index
+        // clamped to the last one: behind a branch the compiler's waitcnt pass must assume they were not issued and waits for the
+        // pending fragments with vmcnt(0) -- on the path where they were, that drains the prefetch it just started; the clamped
+        // tail loads go to a ring stage / registers nobody reads), then the MFMAs of slab s on Acur.
+        int buf = 0;
+        auto slab = [&](const int s, wino_f4 (&Acur)[2][2], wino_f4 (&Anext)[2][2]) {
+            // everything this wave issued before the previous slab has landed -- its share of THIS slab's patch in particular (the
+            // compiler is free to order a slab's DMA and U loads among themselves: count them all)
+            WINO_WAIT_VMCNT(W_DMA + 4);
+            __builtin_amdgcn_s_barrier();
+            issue_dma(min(s + 2, s_end - 1), (buf + 2) & (W_NST - 1));
+            load_a(min(s + 1, s_end - 1), Anext);
+            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch HERE: the scheduler sinks the loads to the end of the slab otherwise
+            const float *st = lds + buf * W_STAGE;
+            const float *r1 = st + ro1, *r2 = st + ro2;
+            float raw[2][2][NR];     // [register buffer][tile block][value]
+            auto read_raw = [&](const int kp, float (&R)[2][NR]) {
+#pragma unroll
+                for (int tb = 0; tb < 2; ++tb) {
+                    const int o = 2 * kp * W_CS + tb * 4 * W_RS;
+                    if (BSEL) {     // columns 1, 2
+                        R[tb][0] = r1[o + 20]; R[tb][1] = r1[o + 1]; R[tb][2] = r2[o + 20]; R[tb][3] = r2[o + 1];
+                    } else {        // columns 0, 2 and 1, 3
+                        R[tb][0] = r1[o]; R[tb][1] = r1[o + 1]; R[tb][2] = r1[o + 20]; R[tb][3] = r1[o + 21];
+                        R[tb][NR - 4] = r2[o]; R[tb][NR - 3] = r2[o + 1]; R[tb][NR - 2] = r2[o + 20]; R[tb][NR - 1] = r2[o + 21];
+                    }
+                }
+            };
+            read_raw(0, raw[0]);
+#pragma unroll
+            for (int kp = 0; kp < WBK / 2; ++kp) {
+                const int cur = kp & 1;
+                if (kp + 1 < WBK / 2) read_raw(kp + 1, raw[cur ^ 1]);
+                float v[2][2];
+#pragma unroll
+                for (int tb = 0; tb < 2; ++tb) {
+                    const float (&R)[NR] = raw[cur][tb];
+                    if (BSEL) {
+                        const float p1 = R[0] + sgn * R[2], p2 = R[1] + sgn * R[3];
+                        v[0][tb] = p1 + p2;      // b = 1: d1 + d2
+                        v[1][tb] = p2 - p1;      // b = 2: d2 - d1
+                    } else {
+                        const float p0 = R[0] + sgn * R[NR - 4], p2 = R[1] + sgn * R[NR - 3], p1 = R[2] + sgn * R[NR - 2], p3 = R[3] + sgn * R[NR - 1];
+                        v[0][tb] = p0 - p2;      // b = 0: d0 - d2
+                        v[1][tb] = p1 - p3;      // b = 3: d1 - d3
+                    }
+                }
+#pragma unroll
+                for (int x = 0; x < 2; ++x)
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                        for (int tb = 0; tb < 2; ++tb)
+                            acc[x][mb][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(Acur[x][mb][kp], v[x][tb], acc[x][mb][tb], 0, 0, 0);
+            }
+            buf = (buf + 1) & (W_NST - 1);
+        };
+        wino_f4 A0[2][2], A1[2][2];
+        issue_dma(s_begin, 0);
+        __builtin_amdgcn_sched_barrier(0);   // the first slab's patch is the OLDEST request: slab()'s counted wait relies on it
+        issue_dma(min(s_begin + 1, s_end - 1), 1);
+        load_a(s_begin, A0);
+        int s = s_begin;
+        for (; s + 1 < s_end; s += 2) {
+            slab(s, A0, A1);
+            slab(s + 1, A1, A0);
+        }
+        if (s < s_end) slab(s, A0, A1);
+        WINO_WAIT_VMCNT(0);              // the clamped tail DMA must not land in the exchange buffer below
+    };
+    if (bsel) k_loop(std::true_type{}); else k_loop(std::false_type{});
+
+    // ---- epilogue: exchange the 16 positions through LDS, output transform, store ---------------------------------------------------
+    const int N = g.batch * plane;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        __syncthreads();    // the ring (first pass) / the previous pass's reads are done
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            float *mx = lds + (x ? xi1 : xi0) * (32 * 64) + j;
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx[((r & 3) + 8 * (r >> 2) + 4 * h) * 64 + tb * 32] = acc[x][mb][tb][r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ml = q * 8 + wave, t = lane;
+            const int m = mt * 64 + mb * 32 + ml;
+            const float *mp = lds + ml * 64 + t;
+            float y00, y01, y10, y11;
+            {
+                float t0[4], t1[4];
+#pragma unroll
+                for (int aa = 0; aa < 4; ++aa) {
+                    const float m0 = mp[(aa * 4 + 0) * 2048], m1 = mp[(aa * 4 + 1) * 2048], m2 = mp[(aa * 4 + 2) * 2048], m3 = mp[(aa * 4 + 3) * 2048];
+                    t0[aa] = m0 + m1 + m2;
+                    t1[aa] = m1 - m2 - m3;
+                }
+                y00 = t0[0] + t0[1] + t0[2]; y01 = t1[0] + t1[1] + t1[2];
+                y10 = t0[1] - t0[2] - t0[3]; y11 = t1[1] - t1[2] - t1[3];
+            }
+            if (m >= g.M) continue;
+            const int oy = y0 + 2 * (t >> 4), ox = x0 + 2 * (t & 15);
+            const size_t pix = (size_t)oy * g.W + ox;
+            if (e.splits > 1) {
+                float *o = e.ws + ((size_t)sp * g.M + m) * N + (size_t)img * plane + pix;
+                *reinterpret_cast<wino_f2 *>(o) = wino_f2{y00, y01};
+                *reinterpret_cast<wino_f2 *>(o + g.W) = wino_f2{y10, y11};
+                continue;
+            }
+            const size_t o = ((size_t)img * g.M + m) * plane + pix;
+            if (e.bias) { const float bv = e.bias[m]; y00 += bv; y01 += bv; y10 += bv; y11 += bv; }
+            y00 = apply_act(y00, e.act, e.slope); y01 = apply_act(y01, e.act, e.slope);
+            y10 = apply_act(y10, e.act, e.slope); y11 = apply_act(y11, e.act, e.slope);
+            if (e.mask_src) {
+                const wino_f2 k0 = *reinterpret_cast<const wino_f2 *>(e.mask_src + o), k1 = *reinterpret_cast<const wino_f2 *>(e.mask_src + o + g.W);
+                y00 = k0[0] > 0.f ? y00 : y00 * e.mask_slope; y01 = k0[1] > 0.f ? y01 : y01 * e.mask_slope;
+                y10 = k1[0] > 0.f ? y10 : y10 * e.mask_slope; y11 = k1[1] > 0.f ? y11 : y11 * e.mask_slope;
+            }
+            *reinterpret_cast<wino_f2 *>(e.out + o) = wino_f2{y00, y01};
+            *reinterpret_cast<wino_f2 *>(e.out + o + g.W) = wino_f2{y10, y11};
+        }
+    }
+}
+
+// ---- transformed weights: wino_pack.h (layout, one tile per workgroup) --------------------------------------------------------------
+__global__ __launch_bounds__(256) void wino_pack_kernel(const float *__restrict__ w, float *__restrict__ out, const int Cout, const int Cin,
+                                                        const int for_dgrad) {
+    __shared__ float tile[16 * 256];
+    pack_tile_wino(w, out, Cout, Cin, for_dgrad, (int)blockIdx.x, tile);
+}
+
+}  // namespace scda
+
+using namespace scda;
+
+SCDA_API int scda_conv2d_wino_supported(int batch, int C, int H, int W, int M) {
+    return batch > 0 && M > 0 && C >= WBK && (C % WBK) == 0 && (H % 8) == 0 && (W % 32) == 0 && (long long)C * H * W * 4 < (1LL << 31) &&
+           (long long)M * H * W * 4 < (1LL << 31);
+}
+
+SCDA_API size_t scda_conv2d_wino_packed_elems(int Cout, int Cin, int for_dgrad) {
+    return (size_t)wino_packed_elems(for_dgrad ? Cin : Cout, for_dgrad ? Cout : Cin);
+}
+
+SCDA_API int scda_conv2d_wino_pack_hip(const float *w, float *out, int Cout, int Cin, int for_dgrad, void *stream) {
+    if (!w || !out || Cout <= 0 || Cin <= 0 || ((for_dgrad ? Cout : Cin) % WBK) != 0) { set_error("scda_conv2d_wino_pack_hip: bad arguments"); return SCDA_EINVAL; }
+    const long long tiles = wino_pack_tiles(for_dgrad ? Cin : Cout, for_dgrad ? Cout : Cin);
+    hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)tiles), dim3(256), 0, as_stream(stream), w, out, Cout, Cin, for_dgrad ? 1 : 0);
+    return launch_status("wino_pack_kernel");
+}
+
+// y [batch, M, H, W] = act(conv3x3(x [batch, C, H, W], stride 1, pad 1) + bias) (* act'(mask_src)); u = scda_conv2d_wino_pack_hip
+SCDA_API int scda_conv2d_wino_hip(const float *x, const float *u, const float *bias, float *y, int batch, int C, int H, int W, int M,
+                                  int act, float slope, const float *mask_src, float mask_slope, int for_dgrad, void *ws, size_t ws_bytes,
+                                  void *stream) {
+    if (!x || !u || !y) { set_error("scda_conv2d_wino_hip: bad arguments"); return SCDA_EINVAL; }
+    if (!scda_conv2d_wino_supported(batch, C, H, W, M)) {
+        set_error("scda_conv2d_wino_hip: needs C %% 8 == 0, H %% 8 == 0, W %% 32 == 0 and tensors below 2 GB per image (C=%d H=%d W=%d)", C, H, W);
+        return SCDA_EINVAL;
+    }
+    hipStream_t st = as_stream(stream);
+    WinoGeom g;
+    g.batch = batch; g.C = C; g.H = H; g.W = W; g.M = M;
+    g.n_mt = (M + 63) / 64; g.n_slab = C / WBK;
+    const int nbx = W / 32, nby = H / 8, npb = batch * nby * nbx;
+    g.dNMT = Div(g.n_mt); g.dNPB = Div(npb); g.dNB = Div(nby * nbx); g.dNBX = Div(nbx);
+    // split-K: a launch below one workgroup per CU splits the channel loop (>= 4 slabs per split), slabs in the natural pixel order
+    const long long tiles = (long long)g.n_mt * npb;
+    int splits = 1;
+    if (const char *f = getenv("SCDA_WINO_SPLITS")) splits = atoi(f);
+    else if (tiles < 200) splits = (int)std::min<long long>((256 + tiles - 1) / tiles, g.n_slab / 4 > 0 ? g.n_slab / 4 : 1);
+    if (splits < 1) splits = 1;
+    while (splits > 1 && (size_t)splits * M * batch * H * W * sizeof(float) > ws_bytes) --splits;
+    g.slabs_per_split = (g.n_slab + splits - 1) / splits;
+    splits = (g.n_slab + g.slabs_per_split - 1) / g.slabs_per_split;
+    WinoEpi e{y, (float *)ws, bias, act, slope, splits, mask_src, mask_slope};
+    prof_begin(for_dgrad ? PK_WINO_DGRAD : PK_WINO_FWD, 2.0 * M * (double)batch * H * W * C * 9, st,
+               4.0 * ((double)batch * C * H * W + 9.0 * M * C + (double)batch * M * H * W));
+    hipLaunchKernelGGL(conv_wino_kernel, dim3((unsigned)(tiles * splits)), dim3(512), 0, st, u, x, g, e);
+    prof_end(st);
+    int rc = launch_status("conv_wino_kernel");
+    if (rc || splits == 1) return rc;
+    return launch_conv_reduce((const float *)ws, splits, M, batch * H * W, H * W, bias, act, slope, y, mask_src, mask_slope, st);
+}

@@ -337,6 +337,56 @@ def conv2d_pack_weight(w, for_dgrad=False, cache=True):
     return out
 
 
+def wino_enabled():
+    """SCDA_WINOGRAD=1: the stride-1 3x3 layers the Winograd kernel supports run on it (forward and data gradient)"""
+    return os.environ.get("SCDA_WINOGRAD", "0") == "1"
+
+
+def wino_min_channels():
+    return int(os.environ.get("SCDA_WINOGRAD_MIN_C", "128"))
+
+
+def wino_ok(B, Cin, IH, IW, Cout, KH, KW, stride, pad, row_period=0):
+    """this convolution (forward: reduced channels Cin, output rows Cout; both at least wino_min_channels()) takes the Winograd path"""
+    if not (wino_enabled() and KH == 3 and KW == 3 and stride == 1 and pad == 1 and not row_period):
+        return False
+    if min(Cin, Cout) < wino_min_channels():
+        return False
+    return bool(lib().scda_conv2d_wino_supported(i32(B), i32(Cin), i32(IH), i32(IW), i32(Cout)))
+
+
+def conv2d_wino_pack(w, for_dgrad=False, cache=True):
+    """[Cout,Cin,3,3] -> the Winograd kernel's transformed filters (scda_ops.h), cached like conv2d_pack_weight's layouts"""
+    _req(w, "w")
+    Cout, Cin, KH, KW = w.shape
+    cache = cache and isinstance(w, torch.nn.Parameter)
+    key = (w.data_ptr(), 2 + int(for_dgrad))
+    flat = getattr(w, "_scda_flat", None)
+    tag = (w._version, flat.epoch if flat is not None else WEIGHT_EPOCH[0], tuple(w.shape))
+    if cache:
+        hit = _PACK_CACHE.get(key)
+        if hit is not None and hit[0] == tag and hit[2]() is w:
+            return hit[1]
+    L = lib()
+    L.scda_conv2d_wino_packed_elems.restype = ctypes.c_size_t
+    n = L.scda_conv2d_wino_packed_elems(i32(Cout), i32(Cin), i32(int(for_dgrad)))
+    out = torch.empty(n, dtype=torch.float32, device=w.device)
+    _check(L.scda_conv2d_wino_pack_hip(_p(w.contiguous()), _p(out), i32(Cout), i32(Cin), i32(int(for_dgrad)), _stream()), "scda_conv2d_wino_pack_hip")
+    if cache:
+        _PACK_CACHE[key] = (tag, out, weakref.ref(w))
+    return out
+
+
+def conv2d_wino(x, u, bias, M, act=ACT_NONE, slope=0.01, mask_src=None, mask_slope=0.0, for_dgrad=False):
+    """one Winograd launch: y [B, M, H, W] from x [B, C, H, W] and packed filters u (forward, or the data gradient with x = dy)"""
+    B, C, H, W = x.shape
+    y = torch.empty(B, M, H, W, dtype=torch.float32, device=x.device)
+    ws, n = _conv_ws(B, C, H, W, M, 3, 3, 1, 1, x.device)
+    _check(lib().scda_conv2d_wino_hip(_p(x), _p(u), _p(bias), _p(y), i32(B), i32(C), i32(H), i32(W), i32(M), i32(act), f32(slope),
+                                      _p(mask_src), f32(mask_slope), i32(int(for_dgrad)), _p(ws), _sz(n), _stream()), "scda_conv2d_wino_hip")
+    return y
+
+
 def conv2d_pack_all(flat):
     """Re-pack every conv weight of a FlatParams bucket (forward and data-gradient layouts) with ONE launch and seed the
     pack cache with the results.  Called by FlatAdam.step(): the lazy per-layer path above then never misses in the
@@ -344,26 +394,32 @@ def conv2d_pack_all(flat):
     ws = getattr(flat, "conv_weights", None)
     if not ws:
         return
+    # which weights ran on the Winograd kernel in their last forward call (native.conv2d_fwd notes it): those get its transformed
+    # filters (modes 2, 3) instead of the implicit-GEMM layouts (0, 1); a call that needs the other kind packs lazily
+    wino = tuple(bool(getattr(w, "_scda_wino_used", False)) for w in ws) if wino_enabled() else None
     plan = getattr(flat, "_scda_pack_plan", None)
+    if plan is not None and plan[4] != wino:
+        plan = None
     L = lib()
     if plan is None:
         L.scda_conv2d_packed_elems.restype = ctypes.c_size_t
         L.scda_conv2d_pack_tiles.restype = ctypes.c_longlong
         rows, entries, off, tiles = [], [], 0, 0
         base = flat.data.data_ptr()
-        for w in ws:
+        for i, w in enumerate(ws):
             Cout, Cin, KH, KW = w.shape
             src = (w.data_ptr() - base) // 4
-            for d in (0, 1):
+            use_wino = wino is not None and wino[i] and (KH, KW) == (3, 3) and Cin % 8 == 0 and Cout % 8 == 0
+            for d in ((2, 3) if use_wino else (0, 1)):
                 n = int(L.scda_conv2d_packed_elems(i32(Cout), i32(Cin), i32(KH), i32(KW), i32(d)))
                 rows.append([src, off, Cout, Cin, KH * KW, d, tiles])
-                entries.append((w, bool(d), off, n))
+                entries.append((w, d if d >= 2 else bool(d), off, n))
                 off += n
                 tiles += int(L.scda_conv2d_pack_tiles(i32(Cout), i32(Cin), i32(KH), i32(KW), i32(d)))
         desc = upload(torch.tensor(rows, dtype=torch.int64), flat.data.device)
         out = torch.empty(off, dtype=torch.float32, device=flat.data.device)
-        plan = flat._scda_pack_plan = (desc, out, entries, tiles)
-    desc, out, entries, tiles = plan
+        plan = flat._scda_pack_plan = (desc, out, entries, tiles, wino)
+    desc, out, entries, tiles, _ = plan
     _check(L.scda_conv2d_pack_weights_batched_hip(_p(flat.data), _p(out), _p(desc), i32(len(entries)),
                                                   ctypes.c_longlong(tiles), _stream()), "scda_conv2d_pack_weights_batched_hip")
     for w, d, off, n in entries:
@@ -382,6 +438,11 @@ def conv2d_fwd(x, w, bias, stride, pad, act=ACT_NONE, slope=0.01, row_period=0):
         raise ValueError(f"conv2d: input has {Cin} channels, weight expects {Cin2}")
     OH = (IH + 2 * pad - KH) // stride + 1
     OW = (IW + 2 * pad - KW) // stride + 1
+    use_wino = wino_ok(B, Cin, IH, IW, Cout, KH, KW, stride, pad, row_period)
+    if isinstance(w, torch.nn.Parameter):
+        w._scda_wino_used = use_wino       # conv2d_pack_all re-packs the layouts the layer's calls actually use
+    if use_wino:
+        return conv2d_wino(x, conv2d_wino_pack(w, False), bias, Cout, act, slope)
     wp = conv2d_pack_weight(w, False)
     y = torch.empty(B, Cout, OH, OW, dtype=torch.float32, device=x.device)
     ws, n = _conv_ws(B, Cin, IH, IW, Cout, KH, KW, stride, pad, x.device)
@@ -397,11 +458,13 @@ def conv2d_dgrad(dy, w, x_shape, stride, pad, act_src=None, act_slope=0.0, row_p
     _req(dy, "dy"); _req(w, "w")
     B, Cin, IH, IW = x_shape
     Cout, _, KH, KW = w.shape
-    dx = torch.empty(B, Cin, IH, IW, dtype=torch.float32, device=dy.device)
     if act_src is not None:
         _req(act_src, "act_src")
         if tuple(act_src.shape) != tuple(x_shape):
             raise ValueError("act_src must have the shape of the conv input")
+    if wino_ok(B, Cout, IH, IW, Cin, KH, KW, stride, pad, row_period):
+        return conv2d_wino(dy, conv2d_wino_pack(w, True), None, Cin, ACT_NONE, 0.0, act_src, act_slope, for_dgrad=True)
+    dx = torch.empty(B, Cin, IH, IW, dtype=torch.float32, device=dy.device)
     if act_src is None and Cin <= 4 and Cout * KH * KW * 16 <= 65536 and (KH, KW) in ((3, 3), (1, 1)):
         # image-side layer: 3 rows of a 64-row MFMA tile would be 95 % padding -- direct kernel, unpacked weights
         _check(lib().scda_conv2d_dgrad_small_cin_hip(_p(dy), _p(w.contiguous()), _p(dx), i32(B), i32(Cin), i32(IH), i32(IW), i32(Cout),

@@ -1,0 +1,93 @@
+"""Winograd F(2x2, 3x3) convolution (csrc/conv_wino.hip, scda_conv2d_wino_hip) vs a plain PyTorch fp32 CPU reference of the same
+op -- forward (bias + activation) and data gradient (with and without the fused act' mask) -- and vs the direct implicit-GEMM kernel.
+Tolerance: max|err| / max|ref| < 2e-4, the bound of tests/test_conv_gemm_gpu.py (the transforms use the exact constants 0, +-1,
++-1/2; what differs from the direct form is the association of the sums)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def close(a, b, tol=2e-4):
+    a = a.detach().cpu().double(); b = b.detach().cpu().double()
+    assert a.shape == b.shape
+    scale = b.abs().max().item() + 1e-12
+    err = (a - b).abs().max().item() / scale
+    assert err < tol, f"relative-to-max error {err:.3e}"
+    return err
+
+
+WINO_CASES = [
+    # B, Cin, H, W, Cout
+    (1, 8, 8, 32, 64),        # one workgroup, one slab
+    (1, 16, 16, 64, 64),      # 2 x 2 pixel blocks: every border of a block is an image border or an inner seam
+    (1, 64, 24, 96, 128),     # two m-tiles, odd number of block rows
+    (2, 128, 16, 32, 128),    # batch 2 (blocks never straddle images), split-K (few tiles)
+    (1, 72, 8, 64, 40),       # ragged M (40 of 64 rows), 9 slabs (odd count: the unrolled K loop's tail)
+    (1, 512, 32, 64, 512),    # conv5_x / RPN: split-K 4
+    (4, 128, 64, 64, 128),    # the decoders' residual convolutions
+    (1, 256, 128, 256, 256),  # conv3_2 at full size
+]
+
+
+@pytest.mark.parametrize("case", WINO_CASES)
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_wino_fwd(cuda, case, act):
+    from scda_amd import native
+    B, Cin, H, W, Cout = case
+    assert native.lib().scda_conv2d_wino_supported(B, Cin, H, W, Cout)
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x, w, b, stride=1, padding=1)
+    ref = [lambda t: t, F.relu, lambda t: F.leaky_relu(t, 0.01)][act](ref)
+    wd = w.to(cuda)
+    u = native.conv2d_wino_pack(wd, False)
+    y = native.conv2d_wino(x.to(cuda), u, b.to(cuda), Cout, act, 0.01)
+    close(y, ref)
+    if act == 0:   # and against the direct kernel (same arithmetic, other association): tighter
+        close(y, native.conv2d_fwd(x.to(cuda), wd, b.to(cuda), 1, 1, 0, 0.01), 5e-5)
+
+
+@pytest.mark.parametrize("case", WINO_CASES)
+@pytest.mark.parametrize("masked", [False, True])
+def test_wino_dgrad(cuda, case, masked):
+    from scda_amd import native
+    B, Cin, H, W, Cout = case
+    if Cout % 8:
+        pytest.skip("the data gradient reduces over Cout: needs Cout % 8 == 0")
+    g = torch.Generator().manual_seed(sum(case) + 1)
+    x = torch.randn(B, Cin, H, W, generator=g, requires_grad=True)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).requires_grad_()
+    xin = F.leaky_relu(x, 0.2) if masked else x         # x is the output of a LeakyReLU whose gradient the conv's dgrad applies
+    y = F.conv2d(xin, w, None, stride=1, padding=1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    u = native.conv2d_wino_pack(w.detach().to(cuda), True)
+    src = xin.detach().to(cuda).contiguous() if masked else None
+    dx = native.conv2d_wino(dy.to(cuda), u, None, Cin, 0, 0.0, src, 0.2, for_dgrad=True)
+    close(dx, x.grad)
+
+
+def test_wino_routes_through_conv2d_entry_points(cuda, monkeypatch):
+    """SCDA_WINOGRAD=1: native.conv2d_fwd / conv2d_dgrad take the Winograd kernel for eligible layers (scda_prof sees its class)"""
+    from scda_amd import native
+    monkeypatch.setenv("SCDA_WINOGRAD", "1")
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 128, 32, 64, generator=g); w = torch.randn(128, 128, 3, 3, generator=g) / 34.0; b = torch.randn(128, generator=g)
+    names = native.prof_kernel_names()
+    native.prof_enable(["conv_wino_kernel<fwd>", "conv_wino_kernel<dgrad>"])
+    y = native.conv2d_fwd(x.to(cuda), w.to(cuda), b.to(cuda), 1, 1, 1)
+    dx = native.conv2d_dgrad(y, w.to(cuda), x.shape, 1, 1)
+    torch.cuda.synchronize()
+    native.prof_enable(False)
+    prof = native.prof_collect()
+    assert prof["conv_wino_kernel<fwd>"][0] == 1 and prof["conv_wino_kernel<dgrad>"][0] == 1, (prof, names)
+    close(y, F.relu(F.conv2d(x, w, b, padding=1)))
+    # a layer below the channel threshold, a strided one and a stacked-map one stay on the direct kernel
+    assert not native.wino_ok(1, 64, 32, 64, 64, 3, 3, 1, 1)
+    assert not native.wino_ok(1, 128, 32, 64, 128, 3, 3, 2, 1)
+    assert not native.wino_ok(1, 128, 32, 64, 128, 3, 3, 1, 1, row_period=8)
+    assert not native.wino_ok(1, 128, 30, 64, 128, 3, 3, 1, 1)
