@@ -58,9 +58,13 @@ for _k in CFG:
 H, W, G = 512, 1024, 12
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 F_ITER_TFLOP = 2.255          # necessary conv / FC / convT work of one iteration
-PMC_TRAFFIC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
+PMC_TRAFFIC_FILES = ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
 DOMINANT_SMALL_TILES = "conv_igemm_glds_kernel<64,*,3,3,1,fwd>"
 DOMINANT = "conv_igemm_glds_kernel<128|256,*,3,3,1,fwd>"   # the instantiations with 128 or 256 tile rows (256 = 8 waves), any tile width, 3x3 stride 1, forward
+# with the Winograd kernel (the default): every stride-1 3x3 forward with >= 64 channels is a launch of this ONE kernel (VGG 12 + RPN 1
+# per image, the decoders' residual / up-sampling convolutions); the library's profiler counts the MFMA work it EXECUTES
+DOMINANT_WINO = "conv_wino_kernel<fwd>"
+WINO_RATIO = 2.25            # direct-convolution MACs per executed Winograd F(2x2,3x3) MAC
 
 
 def synth_batch(rank, H=H, W=W):
@@ -76,7 +80,7 @@ def synth_batch(rank, H=H, W=W):
     return src, tgt, gts, torch.tensor([[H, W, 1.0]])
 
 
-def pmc_traffic():
+def pmc_traffic(kernel):
     """L2 memory-side bytes per launch of the dominant kernel.  PMC counters cannot be sampled from inside the timed
     run; they come from the committed rocprofv3 passes of this same command (scripts/collect_profiles.sh ->
     profiles/r01_pmc_traffic.json: `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` in separate passes, FETCH_SIZE doubled as
@@ -85,6 +89,8 @@ def pmc_traffic():
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 d = json.load(f)
+            if d["dominant"].get("kernel", DOMINANT).split("<")[0] != kernel.split("<")[0]:
+                continue              # a counter pass of another kernel says nothing about this one
             return int(d["dominant"]["traffic_bytes_per_launch"]), "profiles/" + name
         except Exception:
             continue
@@ -204,7 +210,8 @@ def main():
 
     torch.manual_seed(0)          # identical initial weights on every rank (then broadcast, as the reference does)
     np.random.seed(100 + rank)    # per-rank sampling / soft-label stream
-    bh, bw, f_iter, dominant = H, W, F_ITER_TFLOP, DOMINANT
+    wino = native.wino_enabled()
+    bh, bw, f_iter, dominant = H, W, F_ITER_TFLOP, (DOMINANT_WINO if wino else DOMINANT)
     step_kw = {}
     if a.config in ("resnet50", "maskrcnn"):
         from scda_amd import resnet_config as RC
@@ -270,6 +277,8 @@ def main():
     if os.environ.get("SCDA_BENCH_NO_TEMPLATE_PASS"):     # profile collection: keep the trace to the warm-up + timed iterations
         in_region = False
         template = None
+    if wino:
+        in_region = False     # one kernel, one tile shape: there is no "template over every tile shape" to add
     if in_region and rank == 0:
         # the same kernel TEMPLATE over every tile shape it is launched with (the 64-row instantiations of the 64-channel layers and
         # of the GAN nets included): ~3x the launches, so its event pairs go into a pass of their own after the timed region
@@ -302,13 +311,19 @@ def main():
         if dominant in prof:
             n, tms, fl, by = prof[dominant]
             ach = fl / (tms * 1e-3) / 1e12
-            traffic, src = pmc_traffic() if a.config == "vgg16" else (None, None)   # counter passes exist for the VGG configuration
+            traffic, src = pmc_traffic(dominant) if a.config == "vgg16" else (None, None)   # counter passes exist for the VGG configuration
             it_ach = f_iter * world * a.steps / dt
             roof = {"bound": "mfma", "kernel": dominant, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                     "traffic_unit": "bytes/launch (HBM+Infinity-Cache side of L2: 2*FETCH_SIZE + WRITE_SIZE)", "traffic_source": src,
                     "algorithmic_bytes_per_launch": round(by / n), "launches": n, "avg_launch_ms": round(tms / n, 4),
                     "gflop_per_launch": round(fl / n / 1e9, 2),
+                    **({"flop_definition": "MFMA work the Winograd F(2x2,3x3) kernel executes (16 products per 2x2 output tile and channel "
+                                           "pair) = the direct convolution's / 2.25",
+                        "direct_equivalent": {"achieved": round(ach * WINO_RATIO, 2), "frac": round(ach * WINO_RATIO / PEAK_F32_MFMA_TFLOPS, 4),
+                                              "gflop_per_launch": round(fl * WINO_RATIO / n / 1e9, 2),
+                                              "definition": "2 * Cout * pixels * Cin * 9 FLOP of the same launches / the same time (what "
+                                                            "roofline.iteration's F_iter counts): may exceed the MFMA peak"}} if wino else {}),
                     "template_all_tiles": template,
                     "iteration": {"achieved": round(it_ach / world, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s per GPU",
                                   "frac": round(it_ach / world / PEAK_F32_MFMA_TFLOPS, 4),

@@ -331,7 +331,8 @@ SCDA_API int scda_conv2d_wino_hip(const float *x, const float *u, const float *b
     g.slabs_per_split = (g.n_slab + splits - 1) / splits;
     splits = (g.n_slab + g.slabs_per_split - 1) / g.slabs_per_split;
     WinoEpi e{y, (float *)ws, bias, act, slope, splits, mask_src, mask_slope};
-    prof_begin(for_dgrad ? PK_WINO_DGRAD : PK_WINO_FWD, 2.0 * M * (double)batch * H * W * C * 9, st,
+    // flops = the MFMA work the kernel EXECUTES (16 products per 2x2 tile and channel pair: the direct form's 36 / 2.25)
+    prof_begin(for_dgrad ? PK_WINO_DGRAD : PK_WINO_FWD, 2.0 * M * (double)batch * H * W * C * 4, st,
                4.0 * ((double)batch * C * H * W + 9.0 * M * C + (double)batch * M * H * W));
     hipLaunchKernelGGL(conv_wino_kernel, dim3((unsigned)(tiles * splits)), dim3(512), 0, st, u, x, g, e);
     prof_end(st);

@@ -338,12 +338,13 @@ def conv2d_pack_weight(w, for_dgrad=False, cache=True):
 
 
 def wino_enabled():
-    """SCDA_WINOGRAD=1: the stride-1 3x3 layers the Winograd kernel supports run on it (forward and data gradient)"""
-    return os.environ.get("SCDA_WINOGRAD", "0") == "1"
+    """the stride-1 3x3 layers the Winograd kernel supports run on it, forward and data gradient (SCDA_WINOGRAD=0: every layer on
+    the direct implicit-GEMM kernels)"""
+    return os.environ.get("SCDA_WINOGRAD", "1") != "0"
 
 
 def wino_min_channels():
-    return int(os.environ.get("SCDA_WINOGRAD_MIN_C", "128"))
+    return int(os.environ.get("SCDA_WINOGRAD_MIN_C", "64"))
 
 
 def wino_ok(B, Cin, IH, IW, Cout, KH, KW, stride, pad, row_period=0):

@@ -8,6 +8,12 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _direct_kernels(monkeypatch):
+    """this module tests the direct implicit-GEMM family: keep eligible 3x3 layers off the Winograd kernel (tests/test_conv_wino_gpu.py)"""
+    monkeypatch.setenv("SCDA_WINOGRAD", "0")
+
+
 def close(a, b, tol=2e-4):
     a = a.detach().cpu().double(); b = b.detach().cpu().double()
     assert a.shape == b.shape
