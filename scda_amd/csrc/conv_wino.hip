@@ -58,12 +58,12 @@ constexpr int W_CS = W_PR * W_RS;               // channel stride
 constexpr int W_DMA = 7;                        // LDS-DMA instructions per wave and slab: 8 x 7 x 64 slots >= 8 channels x 400
 constexpr int W_STAGE = 8 * W_DMA * 64;         // floats per ring stage (3584)
 constexpr int W_NST = 4;
-constexpr int W_MX = 16 * 32 * 64;              // epilogue exchange: [position][32 rows][64 tiles]
+constexpr int W_MX = 16 * 16 * 64;              // epilogue exchange per 16 rows: [position][rows][64 tiles]
 static_assert(W_NST * W_STAGE <= W_MX && WBK * W_CS <= W_STAGE, "the ring lives inside the exchange buffer");
 
 struct WinoGeom {
     int batch, C, H, W, M;
-    int n_mt, n_slab, slabs_per_split;
+    int n_mt, n_mbg, n_slab, slabs_per_split;   // m-tiles of the launch (32 * MB rows each); 32-row blocks of the packed filters
     Div dNMT, dNPB, dNB, dNBX;   // m-tiles; pixel blocks of the launch; per image; per block row
 };
 
@@ -75,14 +75,20 @@ struct WinoEpi {
     int splits;
     const float *mask_src;
     float mask_slope;
+    int dbg;   // ablation knob (SCDA_WINO_DBG): 1 = no epilogue, 2 = no K loop
 };
 
 typedef float wino_f4 __attribute__((ext_vector_type(4)));
 typedef float wino_f2 __attribute__((ext_vector_type(2)));
 
-__global__ __launch_bounds__(512, 2) void conv_wino_kernel(const float *__restrict__ U, const float *__restrict__ X, const WinoGeom g,
-                                                          const WinoEpi e) {
-    __shared__ __attribute__((aligned(16))) float lds[W_MX];
+// MB = 32-row blocks of output channels per workgroup.  2: 64 x 64 tile, 128 accumulator registers per wave, 128 KB of exchange
+// buffer -- one workgroup per CU; every U and V fragment feeds two MFMAs.  1: 32 x 64 tile, 64 accumulators, 64 KB -- TWO
+// workgroups per CU (4 waves per SIMD at <= 128 registers): one's start-up (first patch + U round trip, ~5 us) and epilogue
+// (~5 us) run underneath the other's K loop, which is what a layer with a short channel loop or few tiles per CU loses on MB = 2.
+template <int MB>
+__global__ __launch_bounds__(512, (MB == 2 ? 2 : 4)) void conv_wino_kernel(const float *__restrict__ U, const float *__restrict__ X,
+                                                                        const WinoGeom g, const WinoEpi e) {
+    __shared__ __attribute__((aligned(16))) float lds[W_MX * MB];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int rest, mt, sp, pb, img, bi, by, bx;
@@ -123,26 +129,26 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const float *__restri
     const int j = lane & 31, h = lane >> 5;
     const int lane_base = h * W_CS + (2 * (j >> 4)) * W_RS + (j & 15);
     const int ro1 = lane_base + i1 * W_RS, ro2 = lane_base + i2 * W_RS;
-    const int n_mbg = g.n_mt * 2;
+    const int n_mbg = g.n_mbg;
     // U fragments: wave-uniform base per (position, 32-row block) + lane * 4 floats; one slab = 256 floats further on
-    const float *ub[2][2];
+    const float *ub[2][MB];
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
-            ub[x][mb] = U + (size_t)((x ? xi1 : xi0) * n_mbg + mt * 2 + mb) * g.n_slab * 256;
-    auto load_a = [&](const int s, wino_f4 (&A)[2][2]) {
+        for (int mb = 0; mb < MB; ++mb)
+            ub[x][mb] = U + (size_t)((x ? xi1 : xi0) * n_mbg + mt * MB + mb) * g.n_slab * 256;
+    auto load_a = [&](const int s, wino_f4 (&A)[2][MB]) {
 #pragma unroll
         for (int x = 0; x < 2; ++x)
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb) A[x][mb] = *reinterpret_cast<const wino_f4 *>(ub[x][mb] + (size_t)s * 256 + lane * 4);
+            for (int mb = 0; mb < MB; ++mb) A[x][mb] = *reinterpret_cast<const wino_f4 *>(ub[x][mb] + (size_t)s * 256 + lane * 4);
     };
 
-    f32x16 acc[2][2][2];
+    f32x16 acc[2][MB][2];
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
+        for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
             for (int tb = 0; tb < 2; ++tb)
 #pragma unroll
@@ -157,10 +163,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const float *__restri
         // pending fragments with vmcnt(0) -- on the path where they were, that drains the prefetch it just started; the clamped
         // tail loads go to a ring stage / registers nobody reads), then the MFMAs of slab s on Acur.
         int buf = 0;
-        auto slab = [&](const int s, wino_f4 (&Acur)[2][2], wino_f4 (&Anext)[2][2]) {
+        auto slab = [&](const int s, wino_f4 (&Acur)[2][MB], wino_f4 (&Anext)[2][MB]) {
             // everything this wave issued before the previous slab has landed -- its share of THIS slab's patch in particular (the
             // compiler is free to order a slab's DMA and U loads among themselves: count them all)
-            WINO_WAIT_VMCNT(W_DMA + 4);
+            WINO_WAIT_VMCNT(W_DMA + 2 * MB);
             __builtin_amdgcn_s_barrier();
             issue_dma(min(s + 2, s_end - 1), (buf + 2) & (W_NST - 1));
             load_a(min(s + 1, s_end - 1), Anext);
@@ -202,14 +208,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const float *__restri
 #pragma unroll
                 for (int x = 0; x < 2; ++x)
 #pragma unroll
-                    for (int mb = 0; mb < 2; ++mb)
+                    for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
                         for (int tb = 0; tb < 2; ++tb)
                             acc[x][mb][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(Acur[x][mb][kp], v[x][tb], acc[x][mb][tb], 0, 0, 0);
             }
             buf = (buf + 1) & (W_NST - 1);
         };
-        wino_f4 A0[2][2], A1[2][2];
+        wino_f4 A0[2][MB], A1[2][MB];
         issue_dma(s_begin, 0);
         __builtin_amdgcn_sched_barrier(0);   // the first slab's patch is the OLDEST request: slab()'s counted wait relies on it
         issue_dma(min(s_begin + 1, s_end - 1), 1);
@@ -222,33 +228,42 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const float *__restri
         if (s < s_end) slab(s, A0, A1);
         WINO_WAIT_VMCNT(0);              // the clamped tail DMA must not land in the exchange buffer below
     };
-    if (bsel) k_loop(std::true_type{}); else k_loop(std::false_type{});
+    if (!(e.dbg & 2)) { if (bsel) k_loop(std::true_type{}); else k_loop(std::false_type{}); }
+    if (e.dbg & 1) { if (acc[0][0][0][0] == 123.456f) e.out[0] = 1.f; return; }
 
     // ---- epilogue: exchange the 16 positions through LDS, output transform, store ---------------------------------------------------
+    // two passes: MB = 2: one 32-row block each (all 16 accumulator registers of a tile); MB = 1: rows 16 p .. 16 p + 15 of the
+    // one block = accumulator registers 8 p .. 8 p + 7 (frag_row: (r & 3) + 8 * (r >> 2) + 4 * h)
+    constexpr int RP = 16 * MB, NRG = 8 * MB;        // rows per pass; accumulator registers per tile and pass
     const int N = g.batch * plane;
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
+    for (int pass = 0; pass < 2; ++pass) {
+        const int mb = MB == 2 ? pass : 0;
         __syncthreads();    // the ring (first pass) / the previous pass's reads are done
 #pragma unroll
         for (int x = 0; x < 2; ++x) {
-            float *mx = lds + (x ? xi1 : xi0) * (32 * 64) + j;
+            float *mx = lds + (x ? xi1 : xi0) * (RP * 64) + j;
 #pragma unroll
             for (int tb = 0; tb < 2; ++tb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) mx[((r & 3) + 8 * (r >> 2) + 4 * h) * 64 + tb * 32] = acc[x][mb][tb][r];
+                for (int rr = 0; rr < NRG; ++rr) {
+                    const int r = MB == 2 ? rr : 8 * pass + rr;
+                    const int row = MB == 2 ? (r & 3) + 8 * (r >> 2) + 4 * h : (r & 3) + 8 * ((r >> 2) & 1) + 4 * h;
+                    mx[row * 64 + tb * 32] = acc[x][mb][tb][r];
+                }
         }
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < RP / 8; ++q) {
             const int ml = q * 8 + wave, t = lane;
-            const int m = mt * 64 + mb * 32 + ml;
+            const int m = mt * (32 * MB) + pass * RP + ml;
             const float *mp = lds + ml * 64 + t;
             float y00, y01, y10, y11;
             {
                 float t0[4], t1[4];
 #pragma unroll
                 for (int aa = 0; aa < 4; ++aa) {
-                    const float m0 = mp[(aa * 4 + 0) * 2048], m1 = mp[(aa * 4 + 1) * 2048], m2 = mp[(aa * 4 + 2) * 2048], m3 = mp[(aa * 4 + 3) * 2048];
+                    const float m0 = mp[(aa * 4 + 0) * (RP * 64)], m1 = mp[(aa * 4 + 1) * (RP * 64)], m2 = mp[(aa * 4 + 2) * (RP * 64)], m3 = mp[(aa * 4 + 3) * (RP * 64)];
                     t0[aa] = m0 + m1 + m2;
                     t1[aa] = m1 - m2 - m3;
                 }
@@ -318,23 +333,35 @@ SCDA_API int scda_conv2d_wino_hip(const float *x, const float *u, const float *b
     hipStream_t st = as_stream(stream);
     WinoGeom g;
     g.batch = batch; g.C = C; g.H = H; g.W = W; g.M = M;
-    g.n_mt = (M + 63) / 64; g.n_slab = C / WBK;
+    // tile rows: 64 (every fragment feeds two MFMAs), or 32 for layers with <= 32 output rows (the decoders' 64 -> 32 stage: half of
+    // a 64-row tile would multiply padding).  Measured on every VGG / decoder layer (scripts/bench_wino.py, SCDA_WINO_MB=1|2): the
+    // two are within 3 % of each other everywhere else -- two co-resident 32-row workgroups start and finish together, so one's
+    // start-up and epilogue do NOT hide under the other's K loop.
+    static const int force_mb = getenv("SCDA_WINO_MB") ? atoi(getenv("SCDA_WINO_MB")) : 0;
+    // ... and for launches that would not fill the chip with 64-row tiles (the decoders' batch-4 residual convolutions: 128 tiles;
+    // conv5_x / the RPN: 64): twice the workgroups first, split-K (slabs + a reduce launch) only for what is still missing
+    const long long tiles64 = (long long)((M + 63) / 64) * batch * (H / 8) * (W / 32);
+    const int MBv = force_mb == 1 || force_mb == 2 ? force_mb : ((M <= 32 || tiles64 < 200) ? 1 : 2);
+    g.n_mbg = (M + 63) / 64 * 2;
+    g.n_mt = (M + 32 * MBv - 1) / (32 * MBv); g.n_slab = C / WBK;
     const int nbx = W / 32, nby = H / 8, npb = batch * nby * nbx;
     g.dNMT = Div(g.n_mt); g.dNPB = Div(npb); g.dNB = Div(nby * nbx); g.dNBX = Div(nbx);
     // split-K: a launch below one workgroup per CU splits the channel loop (>= 4 slabs per split), slabs in the natural pixel order
     const long long tiles = (long long)g.n_mt * npb;
     int splits = 1;
     if (const char *f = getenv("SCDA_WINO_SPLITS")) splits = atoi(f);
-    else if (tiles < 200) splits = (int)std::min<long long>((256 + tiles - 1) / tiles, g.n_slab / 4 > 0 ? g.n_slab / 4 : 1);
+    else if (tiles < 200 * (3 - MBv)) splits = (int)std::min<long long>((256 * (3 - MBv) + tiles / 2) / tiles, g.n_slab / 4 > 0 ? g.n_slab / 4 : 1);
     if (splits < 1) splits = 1;
     while (splits > 1 && (size_t)splits * M * batch * H * W * sizeof(float) > ws_bytes) --splits;
     g.slabs_per_split = (g.n_slab + splits - 1) / splits;
     splits = (g.n_slab + g.slabs_per_split - 1) / g.slabs_per_split;
-    WinoEpi e{y, (float *)ws, bias, act, slope, splits, mask_src, mask_slope};
+    static const int dbg = getenv("SCDA_WINO_DBG") ? atoi(getenv("SCDA_WINO_DBG")) : 0;
+    WinoEpi e{y, (float *)ws, bias, act, slope, splits, mask_src, mask_slope, dbg};
     // flops = the MFMA work the kernel EXECUTES (16 products per 2x2 tile and channel pair: the direct form's 36 / 2.25)
     prof_begin(for_dgrad ? PK_WINO_DGRAD : PK_WINO_FWD, 2.0 * M * (double)batch * H * W * C * 4, st,
                4.0 * ((double)batch * C * H * W + 9.0 * M * C + (double)batch * M * H * W));
-    hipLaunchKernelGGL(conv_wino_kernel, dim3((unsigned)(tiles * splits)), dim3(512), 0, st, u, x, g, e);
+    if (MBv == 2) hipLaunchKernelGGL(conv_wino_kernel<2>, dim3((unsigned)(tiles * splits)), dim3(512), 0, st, u, x, g, e);
+    else hipLaunchKernelGGL(conv_wino_kernel<1>, dim3((unsigned)(tiles * splits)), dim3(512), 0, st, u, x, g, e);
     prof_end(st);
     int rc = launch_status("conv_wino_kernel");
     if (rc || splits == 1) return rc;

@@ -344,7 +344,7 @@ def wino_enabled():
 
 
 def wino_min_channels():
-    return int(os.environ.get("SCDA_WINOGRAD_MIN_C", "64"))
+    return int(os.environ.get("SCDA_WINOGRAD_MIN_C", "32"))
 
 
 def wino_ok(B, Cin, IH, IW, Cout, KH, KW, stride, pad, row_period=0):

@@ -87,7 +87,7 @@ def test_wino_routes_through_conv2d_entry_points(cuda, monkeypatch):
     assert prof["conv_wino_kernel<fwd>"][0] == 1 and prof["conv_wino_kernel<dgrad>"][0] == 1, (prof, names)
     close(y, F.relu(F.conv2d(x, w, b, padding=1)))
     # a layer below the channel threshold, a strided one and a stacked-map one stay on the direct kernel
-    assert not native.wino_ok(1, 32, 32, 64, 64, 3, 3, 1, 1) and not native.wino_ok(1, 64, 32, 64, 32, 3, 3, 1, 1)
+    assert not native.wino_ok(1, 16, 32, 64, 64, 3, 3, 1, 1) and not native.wino_ok(1, 64, 32, 64, 16, 3, 3, 1, 1)
     assert not native.wino_ok(1, 128, 32, 64, 128, 3, 3, 2, 1)
     assert not native.wino_ok(1, 128, 32, 64, 128, 3, 3, 1, 1, row_period=8)
     assert not native.wino_ok(1, 128, 30, 64, 128, 3, 3, 1, 1)
