@@ -254,6 +254,13 @@ int scda_conv2d_wino_pack_hip(const float *w, float *out, int Cout, int Cin, int
 int scda_conv2d_wino_hip(const float *x, const float *u, const float *bias, float *y, int batch, int C, int H, int W, int M, int act,
                          float slope, const float *mask_src, float mask_slope, int for_dgrad, void *ws, size_t ws_bytes, void *stream);
 
+/* ... and the weight gradient in the same (transposed) algorithm: dw [Cout,Cin,3,3] (+)= G^T [ sum over 2x2 tiles (A dy A^T) .*
+ * (B^T x B) ] G, db [Cout] (+)= sum of dy (fused, may be NULL); deterministic split-K like scda_conv2d_wgrad_hip.
+ * scda_conv2d_wino_wgrad_supported: >= 64 channels on both sides, H % 2 == 0, W % 16 == 0. */
+int scda_conv2d_wino_wgrad_supported(int batch, int Cin, int H, int W, int Cout);
+int scda_conv2d_wino_wgrad_hip(const float *dy, const float *x, float *dw, float *db, int batch, int Cin, int H, int W, int Cout,
+                               int accumulate, int db_accumulate, void *ws, size_t ws_bytes, void *stream);
+
 /* C[M,N] (row stride ldc) (+)= op(A) op(B) (+ bias) -> act
  * trans_a = 0: A is [M,K] row-major (lda);  1: A is stored [K,M]
  * trans_b = 0: B is [N,K] row-major (ldb);  1: B is stored [K,N]

@@ -49,8 +49,8 @@ const float *zero_page();
 //   conv_igemm_glds_kernel<BM,BN,KH,KW,S,DGRAD> (classes follow the INSTANTIATION that ran: tile rows 64, or 128|256): id = ((DGRAD*2 + (BM==64)) * 3 + shape), shape 0: 3x3 s1, 1: 3x3 s2, 2: 1x1
 //   conv_wgrad_kernel<*,*,KH,KW,S>:          id = 12 + shape ;   gemm_kernel<*>: id = 15
 //   conv_igemm_kernel<*> (the gather kernel of the layers whose channel count is not a multiple of 16): id = 16
-//   conv_wino_kernel (Winograd F(2x2,3x3), conv_wino.hip): forward id = 17, data gradient id = 18
-enum { PK_CONV = 0, PK_CONV_WGRAD = 12, PK_GEMM = 15, PK_CONV_GATHER = 16, PK_WINO_FWD = 17, PK_WINO_DGRAD = 18, PK_COUNT = 19 };
+//   conv_wino_kernel (Winograd F(2x2,3x3), conv_wino.hip): forward id = 17, data gradient id = 18, weight gradient id = 19
+enum { PK_CONV = 0, PK_CONV_WGRAD = 12, PK_GEMM = 15, PK_CONV_GATHER = 16, PK_WINO_FWD = 17, PK_WINO_DGRAD = 18, PK_WINO_WGRAD = 19, PK_COUNT = 20 };
 static inline int prof_shape(int KH, int S) { return KH == 1 ? 2 : (S == 2 ? 1 : 0); }
 void prof_begin(int kernel, double flops, hipStream_t st, double bytes = 0.0);   // bytes: algorithmic HBM bytes of the launch
 void prof_end(hipStream_t st);

@@ -1846,6 +1846,12 @@ int launch_conv_reduce(const float *ws, int splits, int M, int N, int phw, const
     return launch_status("conv_splitk_reduce_kernel");
 }
 
+// the weight gradients' combine (slabs [splits][M][N] + fused bias-gradient partials) for conv_wino.hip
+int launch_wgrad_reduce(const float *ws, int splits, long long total, int N, int accumulate, float *out, const float *db_ws, float *db,
+                        int db_n, int db_accumulate, hipStream_t st) {
+    return launch_dense_reduce(ws, splits, total, N, nullptr, 0, (int)ACT_NONE, 0.f, accumulate, out, db_ws, db, db_n, db_accumulate, st);
+}
+
 template <int KH, int KW, int S>
 static int launch_wgrad(const float *dY, const float *X, WgradGeom g, float *dW, int accumulate, float *ws,
                         size_t ws_bytes, hipStream_t st, float *db = nullptr, int db_accumulate = 0) {

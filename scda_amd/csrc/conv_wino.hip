@@ -39,6 +39,8 @@ namespace scda {
 
 int launch_conv_reduce(const float *ws, int splits, int M, int N, int phw, const float *bias, int act, float slope, float *out,
                        const float *mask_src, float mask_slope, hipStream_t st);   // conv_gemm.hip
+int launch_wgrad_reduce(const float *ws, int splits, long long total, int N, int accumulate, float *out, const float *db_ws, float *db,
+                        int db_n, int db_accumulate, hipStream_t st);               // conv_gemm.hip
 
 typedef __attribute__((address_space(3))) void wino_lds_void_t;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -294,6 +296,245 @@ __global__ __launch_bounds__(512, (MB == 2 ? 2 : 4)) void conv_wino_kernel(const
     }
 }
 
+// ---- weight gradient --------------------------------------------------------------------------------------------------------------
+// The transposed bilinear algorithm:  dg[m][c] = G^T [ sum_t (A dY_t A^T) .* (B^T d_t B) ] G  -- per position xi a GEMM
+// dU_xi[m][c] = sum_t Z_xi[m][t] V_xi[c][t] over ALL 2x2 output tiles t of all images (K = pixels / 4), then 16 -> 9 values per
+// (m, c).  Same 2.25x fewer MFMA operations as the forward.  Workgroup = 64 output channels x 64 input channels, 8 waves, wave w owns
+// the positions (a = w >> 1, b in {1, 2} or {0, 3}) as in conv_wino_kernel; a K-slab = 8 tiles of one tile row (2 x 16 output
+// pixels): LDS holds the raw 2 x 16 dY patch of the 64 output channels and the raw 4 x 18 X patch of the 64 input channels
+// (channel strides 34 / 74 floats: a half-wave's 32 channels read their 8-byte pairs from 64 different banks), ring of 4 stages, LDS-DMA issued by all
+// waves (14 dword instructions per wave and slab).  Both MFMA operands are formed from raw values on the fly:
+//   Z_ab = sum_pq A[a][p] A[b][q] dY[p][q],  A = [[1,0],[1,1],[1,-1],[0,-1]]  (4 reads, row coefficients are wave constants)
+//   V_ab as in the forward (4 or 8 reads).
+// The patch moves every slab, so which halo lanes fall off the image is a per-slab scalar (top / bottom / left / right) ANDed with
+// per-lane constant bits.  Split-K over the slabs (always: M x C tiles are few), partial dg slabs in [m][c][3][3] order, combined
+// by conv_gemm.hip's fixed-order reduce into the gradient bucket.  Bias gradient fused: Z_11 is the sum of a tile's four dY values,
+// so the wave that owns position (1, 1) accumulates its A fragments.
+constexpr int G_YS = 34, G_XS = 74;                      // channel strides of the dY / X patches (floats): EVEN, = 2 x odd -- the 8-byte
+                                                         // reads of a half-wave's 32 channels cover the 64 banks exactly once
+constexpr int G_YR = 64 * G_YS / 64, G_XR = 64 * G_XS / 64;   // 64-slot runs of the two regions: 34, 74
+constexpr int G_DMA = 14;                                // LDS-DMA instructions per wave and slab (8 x 14 = 112 runs >= 106)
+constexpr int G_STAGE = 8 * G_DMA * 64;                  // 7168 floats
+constexpr int G_NST = 4;
+static_assert(G_NST * G_STAGE >= 16 * 16 * 64, "the exchange buffer lives inside the ring");
+
+struct WinoWgradGeom {
+    int batch, C, H, W, M;
+    int n_ct, TY, TX;            // input-channel tiles; tile rows per image (H / 2); slabs per tile row (W / 16)
+    int n_slab, slabs_per_split; // slabs of the launch (batch * TY * TX)
+    Div dNMT, dNCT, dTX, dTY;
+};
+
+__global__ __launch_bounds__(512, 2) void conv_wino_wgrad_kernel(const float *__restrict__ dY, const float *__restrict__ X,
+                                                                 const WinoWgradGeom g, float *__restrict__ ws, float *__restrict__ db_ws) {
+    __shared__ __attribute__((aligned(16))) float lds[G_NST * G_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int rest, mt, ct, sp;
+    g.dNMT.divmod((int)blockIdx.x, rest, mt);
+    g.dNCT.divmod(rest, sp, ct);
+    const int m0 = mt * 64, c0 = ct * 64;
+    const int s_begin = sp * g.slabs_per_split, s_end = min(g.n_slab, s_begin + g.slabs_per_split);
+    const int plane = g.H * g.W;
+
+    // ---- this wave's LDS-DMA runs: run r = wave * 14 + i covers stage slots [64 r, 64 r + 64) ---------------------------------------
+    //   r < 34: dY region, slot = ch * 34 + e, e = p * 16 + col (e >= 32: padding)      34 <= r < 108: X region, slot = ch * 74 + e,
+    //   e = row * 18 + col (e >= 72: padding)                                            r >= 108: unused tail of the stage
+    unsigned dma_off[G_DMA];
+    unsigned long long xbits = 0;     // 4 bits per instruction: the lane's element is in patch row 0 / row 3 / column 0 / column 17
+#pragma unroll
+    for (int i = 0; i < G_DMA; ++i) {
+        const int r = wave * G_DMA + i;
+        unsigned off = 0x80000000u;
+        if (r < G_YR) {
+            const int slot = r * 64 + lane, ch = slot / G_YS, e = slot - ch * G_YS;
+            if (e < 32 && m0 + ch < g.M) off = (unsigned)((ch * plane + (e >> 4) * g.W + (e & 15)) * 4);
+        } else if (r < G_YR + G_XR) {
+            const int slot = (r - G_YR) * 64 + lane, ch = slot / G_XS, e = slot - ch * G_XS;
+            const int row = e / 18, col = e - row * 18;
+            if (e < 72 && c0 + ch < g.C) {
+                off = (unsigned)((ch * plane + row * g.W + col) * 4);     // relative to (y0 - 1, x0 - 1): the base is moved back
+                xbits |= (unsigned long long)((row == 0) | ((row == 3) << 1) | ((col == 0) << 2) | ((col == 17) << 3)) << (4 * i);
+            }
+        }
+        dma_off[i] = off;
+    }
+    // slab cursor of the issue side: (image, tile row, slab in the row), advanced by one slab per issue; frozen at the last slab
+    int q_img, q_ty, q_tx;
+    {
+        int t;
+        g.dTX.divmod(s_begin, t, q_tx);
+        g.dTY.divmod(t, q_img, q_ty);
+    }
+    int q_s = s_begin;
+    auto issue_dma = [&](const int buf) {
+        const char *yb = reinterpret_cast<const char *>(dY + ((size_t)q_img * g.M + m0) * plane);
+        const char *xb = reinterpret_cast<const char *>(X + ((size_t)q_img * g.C + c0) * plane) - (g.W + 1) * 4;
+        const int soff = (2 * q_ty * g.W + 16 * q_tx) * 4;
+        const unsigned edge = (unsigned)(q_ty == 0) | ((unsigned)(q_ty == g.TY - 1) << 1) | ((unsigned)(q_tx == 0) << 2) | ((unsigned)(q_tx == g.TX - 1) << 3);
+        float *dst = lds + buf * G_STAGE + wave * (G_DMA * 64);
+        if (edge == 0) {     // interior slab (most): the lane offsets as they are
+#pragma unroll
+            for (int i = 0; i < G_DMA; ++i) wino_dma_b32(wave * G_DMA + i < G_YR ? yb : xb, dma_off[i], dst + i * 64, soff);
+        } else {
+#pragma unroll
+            for (int i = 0; i < G_DMA; ++i) {
+                const unsigned off = ((unsigned)(xbits >> (4 * i)) & edge) ? 0x80000000u : dma_off[i];
+                wino_dma_b32(wave * G_DMA + i < G_YR ? yb : xb, off, dst + i * 64, soff);
+            }
+        }
+        if (q_s + 1 < s_end) {
+            ++q_s;
+            if (++q_tx == g.TX) { q_tx = 0; if (++q_ty == g.TY) { q_ty = 0; ++q_img; } }
+        }
+    };
+
+    // ---- this wave's two positions ------------------------------------------------------------------------------------------------
+    const int a = wave >> 1, bsel = wave & 1;
+    const int xi0 = a * 4 + (bsel ? 1 : 0), xi1 = a * 4 + (bsel ? 2 : 3);
+    const int i1 = a == 0 ? 0 : a == 2 ? 2 : 1, i2 = a == 0 ? 2 : a == 1 ? 2 : a == 2 ? 1 : 3;     // BT row a (as in the forward)
+    const float sgn = a == 1 ? 1.f : -1.f;
+    const float ya = a == 3 ? 0.f : 1.f, yb2 = a == 0 ? 0.f : a == 1 ? 1.f : -1.f;                 // A row a = (ya, yb2)
+    const int j = lane & 31, h = lane >> 5;
+    const int yo = j * G_YS + 2 * h;                          // + mb * 32 * 33 + 4 kp (+ p * 16 + q)
+    const int xo = G_YR * 64 + j * G_XS + 2 * h;              // + cb * 32 * 73 + 4 kp + row * 18 (+ column)
+    const int xo1 = xo + i1 * 18, xo2 = xo + i2 * 18;
+    const bool bias_wave = db_ws != nullptr && ct == 0 && a == 1 && bsel == 1;
+
+    f32x16 acc[2][2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[x][mb][cb][r] = 0.f;
+    float rs[2] = {0.f, 0.f};
+
+    auto k_loop = [&](auto bsel_tag) {
+        constexpr bool BSEL = decltype(bsel_tag)::value;
+        int buf = 0;
+        auto slab = [&]() {
+            WINO_WAIT_VMCNT(G_DMA);      // this wave's share of THIS slab's patches has landed (only the previous slab's issue is younger)
+            __builtin_amdgcn_s_barrier();
+            issue_dma((buf + 2) & (G_NST - 1));
+            __builtin_amdgcn_sched_barrier(0);
+            const float *st = lds + buf * G_STAGE;
+            // raw values stay in the 8-byte pairs they are read as; the transforms are written on the pairs (packed fp32 math on
+            // natural register pairs -- element-wise code made the compiler assemble pairs with ~50 v_mov per slab)
+            wino_f2 ry[2][2][2], rx[2][2][4];     // [register buffer][block][pair]
+            auto read_raw = [&](const int kp, wino_f2 (&Y)[2][2], wino_f2 (&R)[2][4]) {
+                // 8-byte reads at immediate offsets from three lane addresses (every offset below is a multiple of 2 floats)
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) {
+                    const float *p = st + yo + mb * (32 * G_YS) + 4 * kp;
+                    Y[mb][0] = *reinterpret_cast<const wino_f2 *>(p);          // tile row 0: (q = 0, q = 1)
+                    Y[mb][1] = *reinterpret_cast<const wino_f2 *>(p + 16);     // tile row 1
+                }
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) {
+                    const float *p1 = st + xo1 + cb * (32 * G_XS) + 4 * kp, *p2 = st + xo2 + cb * (32 * G_XS) + 4 * kp;
+                    R[cb][0] = *reinterpret_cast<const wino_f2 *>(p1);         // patch row i1: columns (0, 1)
+                    R[cb][1] = *reinterpret_cast<const wino_f2 *>(p1 + 2);     //               columns (2, 3)
+                    R[cb][2] = *reinterpret_cast<const wino_f2 *>(p2);         // patch row i2
+                    R[cb][3] = *reinterpret_cast<const wino_f2 *>(p2 + 2);
+                }
+            };
+            read_raw(0, ry[0], rx[0]);
+#pragma unroll
+            for (int kp = 0; kp < 4; ++kp) {
+                const int cur = kp & 1;
+                if (kp + 1 < 4) read_raw(kp + 1, ry[cur ^ 1], rx[cur ^ 1]);
+                float z[2][2], v[2][2];
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) {
+                    const wino_f2 sq = ya * ry[cur][mb][0] + yb2 * ry[cur][mb][1];            // A row a over the tile's two rows: (s0, s1)
+                    if (BSEL) { z[0][mb] = sq[0] + sq[1]; z[1][mb] = sq[0] - sq[1]; }         // b = 1, 2
+                    else { z[0][mb] = sq[0]; z[1][mb] = -sq[1]; }                             // b = 0, 3
+                }
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) {
+                    const wino_f2 p01 = rx[cur][cb][0] + sgn * rx[cur][cb][2], p23 = rx[cur][cb][1] + sgn * rx[cur][cb][3];   // BT row a: (p0, p1), (p2, p3)
+                    if (BSEL) {
+                        v[0][cb] = p01[1] + p23[0];       // b = 1: d1 + d2
+                        v[1][cb] = p23[0] - p01[1];       // b = 2: d2 - d1
+                    } else {
+                        const wino_f2 d = p01 - p23;      // b = 0: d0 - d2;  b = 3: d1 - d3
+                        v[0][cb] = d[0];
+                        v[1][cb] = d[1];
+                    }
+                }
+#pragma unroll
+                for (int x = 0; x < 2; ++x)
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                        for (int cb = 0; cb < 2; ++cb)
+                            acc[x][mb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(z[x][mb], v[x][cb], acc[x][mb][cb], 0, 0, 0);
+                if (BSEL && bias_wave) { rs[0] += z[0][0]; rs[1] += z[0][1]; }     // position (1, 1): the tile's four dY values summed
+            }
+            buf = (buf + 1) & (G_NST - 1);
+        };
+        issue_dma(0);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_dma(1);
+        for (int s = s_begin; s < s_end; ++s) slab();
+        WINO_WAIT_VMCNT(0);
+    };
+    if (bsel) k_loop(std::true_type{}); else k_loop(std::false_type{});
+
+    // ---- epilogue: 4 passes of 16 output-channel rows through LDS, G^T . G, partial dg slab ---------------------------------------------
+    const size_t wrow = (size_t)g.C * 9;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int mb = pass >> 1, half = pass & 1;
+        __syncthreads();
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            float *mx = lds + (x ? xi1 : xi0) * (16 * 64) + j;
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) {
+                    const int r = 8 * half + rr;
+                    mx[((r & 3) + 8 * ((r >> 2) & 1) + 4 * h) * 64 + cb * 32] = acc[x][mb][cb][r];
+                }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int ml = q * 8 + wave, cl = lane;
+            const int m = m0 + mb * 32 + half * 16 + ml, c = c0 + cl;
+            const float *mp = lds + ml * 64 + cl;
+            float t[3][4];     // G^T dU: rows u, columns b
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const float d0 = mp[(0 * 4 + b) * 1024], d1 = mp[(1 * 4 + b) * 1024], d2 = mp[(2 * 4 + b) * 1024], d3 = mp[(3 * 4 + b) * 1024];
+                t[0][b] = d0 + 0.5f * (d1 + d2);
+                t[1][b] = 0.5f * (d1 - d2);
+                t[2][b] = 0.5f * (d1 + d2) + d3;
+            }
+            if (m >= g.M || c >= g.C) continue;
+            float *o = ws + ((size_t)sp * g.M + m) * wrow + (size_t)c * 9;
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                o[u * 3 + 0] = t[u][0] + 0.5f * (t[u][1] + t[u][2]);
+                o[u * 3 + 1] = 0.5f * (t[u][1] - t[u][2]);
+                o[u * 3 + 2] = 0.5f * (t[u][1] + t[u][2]) + t[u][3];
+            }
+        }
+    }
+    if (bias_wave) {
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            const float tsum = rs[mb] + __shfl_xor(rs[mb], 32);
+            const int m = m0 + mb * 32 + j;
+            if (h == 0 && m < g.M) db_ws[(size_t)sp * g.M + m] = tsum;
+        }
+    }
+}
+
 // ---- transformed weights: wino_pack.h (layout, one tile per workgroup) --------------------------------------------------------------
 __global__ __launch_bounds__(256) void wino_pack_kernel(const float *__restrict__ w, float *__restrict__ out, const int Cout, const int Cin,
                                                         const int for_dgrad) {
@@ -366,4 +607,43 @@ SCDA_API int scda_conv2d_wino_hip(const float *x, const float *u, const float *b
     int rc = launch_status("conv_wino_kernel");
     if (rc || splits == 1) return rc;
     return launch_conv_reduce((const float *)ws, splits, M, batch * H * W, H * W, bias, act, slope, y, mask_src, mask_slope, st);
+}
+
+SCDA_API int scda_conv2d_wino_wgrad_supported(int batch, int Cin, int H, int W, int Cout) {
+    return batch > 0 && Cin >= 64 && Cout >= 64 && (H % 2) == 0 && (W % 16) == 0 && 64LL * H * W * 4 < (1LL << 31);
+}
+
+// dw [Cout,Cin,3,3] (+)= weight gradient of the stride-1, pad-1 3x3 convolution; db [Cout] (+)= bias gradient (may be NULL)
+SCDA_API int scda_conv2d_wino_wgrad_hip(const float *dy, const float *x, float *dw, float *db, int batch, int Cin, int H, int W, int Cout,
+                                        int accumulate, int db_accumulate, void *ws, size_t ws_bytes, void *stream) {
+    if (!dy || !x || !dw || !ws) { set_error("scda_conv2d_wino_wgrad_hip: bad arguments"); return SCDA_EINVAL; }
+    if (!scda_conv2d_wino_wgrad_supported(batch, Cin, H, W, Cout)) {
+        set_error("scda_conv2d_wino_wgrad_hip: needs >= 64 channels on both sides, H %% 2 == 0, W %% 16 == 0 (Cin=%d Cout=%d H=%d W=%d)", Cin, Cout, H, W);
+        return SCDA_EINVAL;
+    }
+    hipStream_t st = as_stream(stream);
+    WinoWgradGeom g;
+    g.batch = batch; g.C = Cin; g.H = H; g.W = W; g.M = Cout;
+    const int n_mt = (Cout + 63) / 64;
+    g.n_ct = (Cin + 63) / 64; g.TY = H / 2; g.TX = W / 16;
+    g.n_slab = batch * g.TY * g.TX;
+    g.dNMT = Div(n_mt); g.dNCT = Div(g.n_ct); g.dTX = Div(g.TX); g.dTY = Div(g.TY);
+    const long long tiles = (long long)n_mt * g.n_ct;
+    const size_t slab_bytes = (size_t)Cout * Cin * 9 * sizeof(float), db_bytes = db ? (size_t)1024 * Cout * sizeof(float) : 0;
+    if (ws_bytes < slab_bytes + db_bytes) { set_error("scda_conv2d_wino_wgrad_hip: workspace too small"); return SCDA_EINVAL; }
+    // one workgroup per CU and round: splits so that the launch has ~256 workgroups (>= 8 slabs each, <= 1024 splits)
+    int splits = (int)((256 + tiles - 1) / tiles);
+    if (const char *f = getenv("SCDA_WINO_WGRAD_SPLITS")) splits = atoi(f);
+    splits = std::max(1, std::min(std::min(splits, 1024), std::max(1, g.n_slab / 8)));
+    while (splits > 1 && (size_t)splits * slab_bytes + db_bytes > ws_bytes) --splits;
+    g.slabs_per_split = (g.n_slab + splits - 1) / splits;
+    splits = (g.n_slab + g.slabs_per_split - 1) / g.slabs_per_split;
+    float *wsf = (float *)ws;
+    float *db_ws = db ? wsf + (size_t)splits * Cout * Cin * 9 : nullptr;
+    prof_begin(PK_WINO_WGRAD, 2.0 * Cout * (double)batch * H * W * Cin * 4, st);
+    hipLaunchKernelGGL(conv_wino_wgrad_kernel, dim3((unsigned)(tiles * splits)), dim3(512), 0, st, dy, x, g, wsf, db_ws);
+    prof_end(st);
+    int rc = launch_status("conv_wino_wgrad_kernel");
+    if (rc) return rc;
+    return launch_wgrad_reduce(wsf, splits, (long long)Cout * Cin * 9, Cin * 9, accumulate, dw, db_ws, db, Cout, db_accumulate, st);
 }

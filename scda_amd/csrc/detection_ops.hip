@@ -765,7 +765,7 @@ SCDA_API const char *scda_prof_kernel_name(int k) {
         "conv_igemm_glds_kernel<128|256,*,3,3,1,dgrad>", "conv_igemm_glds_kernel<128|256,*,3,3,2,dgrad>", "conv_igemm_glds_kernel<128|256,*,1,1,1,dgrad>",
         "conv_igemm_glds_kernel<64,*,3,3,1,dgrad>", "conv_igemm_glds_kernel<64,*,3,3,2,dgrad>", "conv_igemm_glds_kernel<64,*,1,1,1,dgrad>",
         "conv_wgrad_glds_kernel<*,*,3,3,1>", "conv_wgrad_glds_kernel<*,*,3,3,2>", "conv_wgrad_glds_kernel<*,*,1,1,1>", "gemm_glds_kernel<*>", "conv_igemm_kernel<*>",
-        "conv_wino_kernel<fwd>", "conv_wino_kernel<dgrad>"};
+        "conv_wino_kernel<fwd>", "conv_wino_kernel<dgrad>", "conv_wino_wgrad_kernel"};
     return (k >= 0 && k < PK_COUNT) ? names[k] : "";
 }
 SCDA_API int scda_prof_collect(long long *launches, double *ms, double *flops, double *bytes) {

@@ -356,6 +356,36 @@ def wino_ok(B, Cin, IH, IW, Cout, KH, KW, stride, pad, row_period=0):
     return bool(lib().scda_conv2d_wino_supported(i32(B), i32(Cin), i32(IH), i32(IW), i32(Cout)))
 
 
+def wino_wgrad_ok(B, Cin, IH, IW, Cout, KH, KW, stride, pad, row_period=0):
+    """this weight gradient takes the Winograd kernel (SCDA_WINOGRAD_WGRAD=0 keeps it on the direct one)"""
+    if not (wino_enabled() and os.environ.get("SCDA_WINOGRAD_WGRAD", "1") != "0" and KH == 3 and KW == 3 and stride == 1 and pad == 1
+            and not row_period):
+        return False
+    return bool(lib().scda_conv2d_wino_wgrad_supported(i32(B), i32(Cin), i32(IH), i32(IW), i32(Cout)))
+
+
+def conv2d_wino_wgrad(dy, x, w_shape, out=None, db_out=None, want_bias=False):
+    """(dw, db) of a stride-1 pad-1 3x3 convolution on the Winograd weight-gradient kernel; accumulates into out / db_out when given"""
+    _req(dy, "dy"); _req(x, "x")
+    B, Cin, IH, IW = x.shape
+    Cout = w_shape[0]
+    acc = dbacc = 0
+    if out is None:
+        out = torch.empty(tuple(w_shape), dtype=torch.float32, device=x.device)
+    else:
+        _req(out, "out"); acc = 1
+    db = None
+    if want_bias or db_out is not None:
+        if db_out is None:
+            db = torch.empty(Cout, dtype=torch.float32, device=x.device)
+        else:
+            _req(db_out, "db_out"); db = db_out; dbacc = 1
+    ws, n = _conv_ws(B, Cin, IH, IW, Cout, 3, 3, 1, 1, x.device)
+    _check(lib().scda_conv2d_wino_wgrad_hip(_p(dy), _p(x), _p(out), _p(db), i32(B), i32(Cin), i32(IH), i32(IW), i32(Cout), i32(acc),
+                                            i32(dbacc), _p(ws), _sz(n), _stream()), "scda_conv2d_wino_wgrad_hip")
+    return out, db
+
+
 def conv2d_wino_pack(w, for_dgrad=False, cache=True):
     """[Cout,Cin,3,3] -> the Winograd kernel's transformed filters (scda_ops.h), cached like conv2d_pack_weight's layouts"""
     _req(w, "w")
@@ -485,6 +515,8 @@ def conv2d_wgrad(dy, x, w_shape, stride, pad, out=None, row_period=0):
     _req(dy, "dy"); _req(x, "x")
     B, Cin, IH, IW = x.shape
     Cout, _, KH, KW = w_shape
+    if wino_wgrad_ok(B, Cin, IH, IW, Cout, KH, KW, stride, pad, row_period):
+        return conv2d_wino_wgrad(dy, x, w_shape, out=out)[0]
     acc = 0
     if out is None:
         out = torch.empty(tuple(w_shape), dtype=torch.float32, device=x.device)
@@ -504,6 +536,8 @@ def conv2d_wgrad_bias(dy, x, w_shape, stride, pad, out=None, db_out=None, row_pe
     _req(dy, "dy"); _req(x, "x")
     B, Cin, IH, IW = x.shape
     Cout, _, KH, KW = w_shape
+    if wino_wgrad_ok(B, Cin, IH, IW, Cout, KH, KW, stride, pad, row_period):
+        return conv2d_wino_wgrad(dy, x, w_shape, out=out, db_out=db_out, want_bias=True)
     L = lib()
     if not L.scda_conv2d_wgrad_bias_fusable(i32(B), i32(Cout), i32(dy.shape[2]), i32(dy.shape[3]), _p(dy)):
         return conv2d_wgrad(dy, x, w_shape, stride, pad, out=out, row_period=row_period), bias_grad_nchw(dy, out=db_out)

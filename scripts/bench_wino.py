@@ -36,7 +36,15 @@ for name, B, Cin, H, W, Cout in LAYERS:
     uf = native.conv2d_wino_pack(w, False); ud = native.conv2d_wino_pack(w, True)
     tw_f = timeit(lambda: native.conv2d_wino(x, uf, b, Cout, 1, 0.01)); tw_d = timeit(lambda: native.conv2d_wino(dy, ud, None, Cin, for_dgrad=True))
     tp = timeit(lambda: native.conv2d_wino_pack(w, False, cache=False))
+    wg = ""
+    if native.lib().scda_conv2d_wino_wgrad_supported(B, Cin, H, W, Cout):
+        os.environ["SCDA_WINOGRAD"] = "0"
+        td_w = timeit(lambda: native.conv2d_wgrad_bias(dy, x, w.shape, 1, 1))
+        tw_w = timeit(lambda: native.conv2d_wino_wgrad(dy, x, w.shape, want_bias=True))
+        dd = native.conv2d_wgrad_bias(dy, x, w.shape, 1, 1)[0]; dwv = native.conv2d_wino_wgrad(dy, x, w.shape, want_bias=True)[0]
+        wg = " | wgrad direct %7.1f us %6.1f TF  wino %7.1f us %6.1f TF  x%.2f relerr %.1e" % (
+            td_w * 1e3, flop / td_w / 1e9, tw_w * 1e3, flop / tw_w / 1e9, td_w / tw_w, ((dd - dwv).abs().max() / dd.abs().max()).item())
     err = (native.conv2d_wino(x, uf, b, Cout, 1, 0.01) - native.conv2d_fwd(x, w, b, 1, 1, 1)).abs().max().item()
     print("%-8s %6.2f GFLOP | fwd direct %7.1f us %6.1f TF  wino %7.1f us %6.1f TF  x%.2f | dgrad direct %7.1f us %6.1f TF  wino %7.1f us %6.1f TF  x%.2f | pack %6.1f us | max|diff| %.2e"
           % (name, flop / 1e9, td_f * 1e3, flop / td_f / 1e9, tw_f * 1e3, flop / tw_f / 1e9, td_f / tw_f, td_d * 1e3, flop / td_d / 1e9,
-             tw_d * 1e3, flop / tw_d / 1e9, td_d / tw_d, tp * 1e3, err), flush=True)
+             tw_d * 1e3, flop / tw_d / 1e9, td_d / tw_d, tp * 1e3, err) + wg, flush=True)

@@ -91,3 +91,52 @@ def test_wino_routes_through_conv2d_entry_points(cuda, monkeypatch):
     assert not native.wino_ok(1, 128, 32, 64, 128, 3, 3, 2, 1)
     assert not native.wino_ok(1, 128, 32, 64, 128, 3, 3, 1, 1, row_period=8)
     assert not native.wino_ok(1, 128, 30, 64, 128, 3, 3, 1, 1)
+
+
+WGRAD_CASES = [
+    # B, Cin, H, W, Cout
+    (1, 64, 2, 16, 64),        # one slab: every halo row / column is off the image
+    (1, 64, 8, 32, 64),        # 4 x 2 slabs: all four edges and the interior
+    (2, 64, 6, 48, 128),       # two images (the slab cursor wraps rows and images), two output-channel tiles
+    (1, 128, 16, 32, 72),      # ragged Cout (72 = 64 + 8), two input-channel tiles
+    (1, 72, 4, 16, 64),        # ragged Cin
+    (4, 128, 64, 64, 128),     # the decoders' residual convolutions
+    (1, 256, 64, 128, 512),    # conv4_1
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_wino_wgrad(cuda, case):
+    from scda_amd import native
+    B, Cin, H, W, Cout = case
+    assert native.lib().scda_conv2d_wino_wgrad_supported(B, Cin, H, W, Cout)
+    g = torch.Generator().manual_seed(sum(case) + 2)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).requires_grad_()
+    b = torch.randn(Cout, generator=g).requires_grad_()
+    y = F.conv2d(x, w, b, stride=1, padding=1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    dw, db = native.conv2d_wino_wgrad(dy.to(cuda), x.to(cuda), w.shape, want_bias=True)
+    close(dw, w.grad)
+    close(db, b.grad)
+    # accumulation into existing buffers (the gradient bucket), and the bias-less form
+    dw2, db2 = native.conv2d_wino_wgrad(dy.to(cuda), x.to(cuda), w.shape, out=dw.clone(), db_out=db.clone())
+    close(dw2, 2 * w.grad); close(db2, 2 * b.grad)
+    dw3, none = native.conv2d_wino_wgrad(dy.to(cuda), x.to(cuda), w.shape)
+    assert none is None and torch.equal(dw3, dw)      # deterministic: same splits, same order
+
+
+def test_wino_wgrad_routes_through_conv2d_entry_points(cuda):
+    from scda_amd import native
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(1, 128, 32, 64, generator=g); dy = torch.randn(1, 128, 32, 64, generator=g)
+    native.prof_enable(["conv_wino_wgrad_kernel"])
+    dw, db = native.conv2d_wgrad_bias(dy.to(cuda), x.to(cuda), (128, 128, 3, 3), 1, 1)
+    dw1 = native.conv2d_wgrad(dy.to(cuda), x.to(cuda), (128, 128, 3, 3), 1, 1)
+    torch.cuda.synchronize()
+    native.prof_enable(False)
+    assert native.prof_collect()["conv_wino_wgrad_kernel"][0] == 2
+    assert torch.equal(dw, dw1)
+    assert not native.wino_wgrad_ok(1, 32, 32, 64, 64, 3, 3, 1, 1) and not native.wino_wgrad_ok(1, 64, 32, 64, 64, 3, 3, 2, 1)
+    assert not native.wino_wgrad_ok(1, 64, 32, 72, 64, 3, 3, 1, 1)
