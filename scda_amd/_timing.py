@@ -12,6 +12,8 @@ def mark(label):
         MARKS.append((label, time.perf_counter()))
         if DEVICE:
             import torch
+            if torch.cuda.is_current_stream_capturing():     # a timing event cannot be recorded inside a hipGraph capture
+                return
             e = torch.cuda.Event(enable_timing=True)
             e.record()
             EVENTS.append((label, e))

@@ -851,13 +851,17 @@ SCDA_API int scda_roi_pool_bwd_hip(const float *top_grad, const int32_t *argmax,
     static const bool force_gather = getenv("SCDA_ROIPOOL_BWD_GATHER") != nullptr;   // A/B knob
     const size_t per = ((size_t)H * W + kScatterBands - 1) / kScatterBands;
     const size_t scatter_lds = per * 8 * kScatterBands + (size_t)2 * kScatterChunk * 64 * 8;
-    if (PH * PW <= 64 && scatter_lds <= 96 * 1024 && !force_gather) {
+    // more than 64 KB of dynamic LDS must be asked for once per kernel; if the runtime refuses, the gather kernel below takes the shape
+    static const bool big_lds_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(roi_pool_bwd_scatter_kernel),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
+    if (!big_lds_ok) (void)hipGetLastError();
+    if (PH * PW <= 64 && scatter_lds <= (big_lds_ok ? 96 : 64) * (size_t)1024 && !force_gather) {
         hipLaunchKernelGGL(roi_pool_bwd_scatter_kernel, dim3(B * C), dim3(64 * kScatterBands), scatter_lds, as_stream(stream),
                            top_grad, argmax, rois, R, C, H * W, PH * PW, bottom_grad);
         return launch_status("roi_pool_bwd_scatter_kernel");
     }
     const size_t lds = (size_t)R * 5 * sizeof(int);
-    if (lds > 96 * 1024) { set_error("scda_roi_pool_bwd_hip: R=%d too large", R); return SCDA_EINVAL; }
+    if (lds > 64 * 1024) { set_error("scda_roi_pool_bwd_hip: R=%d too large", R); return SCDA_EINVAL; }
     const int bands = (H + kBandRows - 1) / kBandRows;
     hipLaunchKernelGGL(roi_pool_bwd_kernel, dim3((unsigned)((long long)B * C * bands)), dim3(256), lds, as_stream(stream), top_grad,
                        argmax, R, spatial_scale, C, H, W, PH, PW, bottom_grad, rois);

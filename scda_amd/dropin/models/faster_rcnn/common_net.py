@@ -29,11 +29,15 @@ class INSResBlock(nn.Module):
         self.model = nn.Sequential(*seq)
         self.model.apply(gaussian_weights_init)
 
+    def tail_fusable(self):
+        """IN -> Dropout -> (+ x) of this block can run as one launch each way (training mode, a real dropout rate)"""
+        tail = self.model[-2:]
+        return (len(self.model) == 6 and isinstance(tail[0], L.InstanceNorm2d) and tail[0].fused_act == ACT_NONE
+                and isinstance(tail[1], L.Dropout) and 0.0 < tail[1].p < 1.0 and not os.environ.get("SCDA_NO_RESBLOCK_TAIL_FUSION"))
+
     def forward(self, x):
         tail = self.model[-2:]
-        if (len(self.model) == 6 and self.training and isinstance(tail[0], L.InstanceNorm2d) and tail[0].fused_act == ACT_NONE
-                and isinstance(tail[1], L.Dropout) and 0.0 < tail[1].p < 1.0 and L.Dropout.mask_source is None and x.is_cuda
-                and not os.environ.get("SCDA_NO_RESBLOCK_TAIL_FUSION")):
+        if self.tail_fusable() and self.training and L.Dropout.mask_source is None and x.is_cuda:
             # IN -> Dropout -> (+ x) in one launch each way (autograd_ops.InstNormDropAddFn); the seed is drawn where the un-fused
             # Dropout module draws it, so the torch generator is consumed identically
             h = self.model[:-2](x)

@@ -149,6 +149,12 @@ class Dropout(nn.Module):
             if fused:   # replayed masks (parity tests of the FUSED path): explicit mask, ReLU gradient through a no-op ReLU
                 x = A.ActFn.apply(x, N.ACT_MODE["relu"], 0.0)
             return A.DropoutFn.apply(x, mask, 1.0 / (1.0 - self.p))
+        from . import seeds
+        if seeds.active is not None:
+            # a hipGraph is being recorded: this launch takes its seed as a kernel ARGUMENT, which a recording would freeze -- every
+            # replay would drop the same elements.  (The residual blocks' fused tail reads its seed from device memory; the trainer
+            # only records when every dropout of the region is one of those: ScdaTrainer._gan_graph_ok.)
+            raise RuntimeError("scda_amd.layers.Dropout cannot be recorded into a hipGraph (host-side seed)")
         seed = int(torch.randint(0, 1 << 62, (1,), dtype=torch.int64))
         return A.DropoutSeededFn.apply(x, self.p, seed, fused)
 

@@ -168,6 +168,10 @@ class _GanGraphs:
         from . import layers as L
         return [m for m in self.tr.dis_patch.modules() if isinstance(m, L.BatchNorm2d)]
 
+    def fits(self, t):
+        """this iteration's tensors have the shapes the regions were recorded with (otherwise the iteration runs eagerly)"""
+        return all(k not in self.static or self.static[k].shape == t[k].shape for k in ('src_patch', 'tgt_patch', 'x_small', 't_small'))
+
     def _load(self, name, t):
         """this iteration's inputs of region `name` into the recorded tensors -- each ONCE per iteration: B and C read what A loaded
         (and while B is being recorded, autograd still holds A's inputs as saved tensors: an in-place copy would invalidate them)"""
@@ -290,6 +294,7 @@ class ScdaTrainer:
             self.opt = {k: FlatAdam(f, lr, betas=(0.9, 0.999), weight_decay=weight_decay) for k, f in self.flat.items()}
         self._warmup = None          # per-iteration schedulers while warming up (begin_warmup / end_warmup)
         self._epoch_sched = None     # per-epoch MultiStepLR (set_epoch_schedule / begin_epoch)
+        self._in_graph = False   # a GAN region is being recorded / replayed: its all-reduces are issued by step(), behind it
         self.capture = False   # debugging / parity tests: keep a copy of each phase's gradients in self.trace
         self.trace = {}        # ... as computed by this rank, and in self.trace_reduced after the all-reduce (world_size > 1)
         self.trace_reduced = {}
@@ -351,17 +356,26 @@ class ScdaTrainer:
         if self.capture:
             self.trace_reduced[name] = {k: p.grad.detach().clone() for k, p in module.named_parameters()}
 
-    def _reduce(self, module, async_op):
+    def _finish_grads(self, module):
+        """device side of the end of a phase's backward (recordable into a hipGraph): the B halves joined, lazily-zeroed slices
+        nobody wrote this phase filled (FlatParams.lazy)"""
         self._join_branch()
         flat = getattr(module, "_scda_flat", None)
         if flat is not None:
-            flat.finalize_grads()      # lazily-zeroed slices nobody wrote this phase (see FlatParams.lazy)
+            flat.finalize_grads()
+
+    def _all_reduce(self, module, async_op):
+        """host side: gradient capture (tests) and the phase's all-reduce -- never inside a recorded region"""
         if self.capture:
             name = {id(self.model): 'det', id(self.dec): 'dec', id(self.dis): 'dis', id(self.dis_patch): 'dis_patch'}[id(module)]
             self.trace[name] = {k: p.grad.detach().clone() for k, p in module.named_parameters()}
         if self.collectives:
             return average_gradients(module, async_op=async_op)
         return None
+
+    def _reduce(self, module, async_op):
+        self._finish_grads(module)
+        return self._all_reduce(module, async_op)
 
     # ---- phases 1 + 2 (image discriminators, patch discriminator): forward, losses, both backward passes ----------------------
     def _dis_out_len(self, crops):
@@ -394,12 +408,16 @@ class ScdaTrainer:
                       (d_tgt_fake, score0, w_tgt), (d_tgt_real, score1, None)],         # ad_tgt  (:596-600)
                      scale=1.0 / ws)
         adloss.backward()
-        w1 = self._reduce(self.dis, async_op=True)
+        self._finish_grads(self.dis)
+        # eager: the discriminators' all-reduce starts here, underneath phase 2; as a hipGraph region the collectives are issued by
+        # the caller behind the replay (step): 0.75 + 15 MB, still underneath phase 3
+        w1 = None if self._in_graph else self._all_reduce(self.dis, async_op=True)
         mark('phase1')
         self.opt['dis_patch'].zero_grad()
         dis_patch_loss = (bce(src_pro, score1p) + bce(tgt_pro, score0p)) / ws
         dis_patch_loss.backward()
-        w2 = self._reduce(self.dis_patch, async_op=True)
+        self._finish_grads(self.dis_patch)
+        w2 = None if self._in_graph else self._all_reduce(self.dis_patch, async_op=True)
         return adloss.detach(), dis_patch_loss.detach(), w1, w2
 
     # ---- the GAN part of the iteration as three regions without a host decision inside --------------------------------------
@@ -427,7 +445,8 @@ class ScdaTrainer:
             fake1_src = adv([(d_src_fake, t['one_s'], None), (d_src_real, t['zero_s'], None)])           # :683-687
             recon_loss = (fake1_src + fake1_tgt) / ws
             recon_loss.backward()
-        w3 = self._reduce(self.dec, async_op=True)
+        self._finish_grads(self.dec)
+        w3 = None if self._in_graph else self._all_reduce(self.dec, async_op=True)
         return recon_loss.detach(), fake1_src.detach(), w_tgt2, w3
 
     def _region_c(self, t, w_tgt2):
@@ -440,11 +459,25 @@ class ScdaTrainer:
         return fake_loss_source, fake_loss_target
 
     def _gan_graph_ok(self):
-        """SCDA_GAN_GRAPH=1: the three regions above as hipGraphs (~330 of the iteration's ~700 launches, fixed shapes).  Not with
-        collectives inside the regions, gradient capture, the reference-style schedule or the parity tests' hooks."""
+        """The three regions above as hipGraphs (~330 of the iteration's ~700 launches, fixed shapes; SCDA_GAN_GRAPH=0 turns them off).
+        Not with gradient capture, the reference-style schedule or the parity tests' hooks; not when a dropout of the decoders would
+        take its seed as a kernel argument (a recording would freeze it: only the residual blocks' fused tail reads a device seed).
+        The all-reduces of a data-parallel run are host calls: issued behind each replay (step), never recorded."""
         from . import layers as L
-        return (os.environ.get("SCDA_GAN_GRAPH") == "1" and self.device.type == "cuda" and not self.collectives and not self.capture
-                and self.early_backward and A.replay is None and L.Dropout.mask_source is None)
+        from .dropin.models.faster_rcnn.common_net import INSResBlock
+        if not (os.environ.get("SCDA_GAN_GRAPH", "1") != "0" and self.device.type == "cuda" and not self.capture and self.early_backward
+                and A.replay is None and L.Dropout.mask_source is None and self.flat):
+            return False
+        ok = getattr(self, "_graphable_nets", None)
+        if ok is None:
+            fused = set()
+            for blk in self.dec.modules():
+                if isinstance(blk, INSResBlock) and blk.tail_fusable():
+                    fused.add(id(blk.model[-1]))
+            ok = all(id(m) in fused or m.p == 0.0 for net in (self.dec, self.dis, self.dis_patch) for m in net.modules()
+                     if isinstance(m, L.Dropout))
+            self._graphable_nets = ok
+        return ok
 
     def _ones_row(self, row):
         c = getattr(self, "_ones_row_cache", None)
@@ -495,6 +528,9 @@ class ScdaTrainer:
              't_small': _crops(target, get_corner_from_center(ctr_t, self.recon, self.new_w, self.new_h), self.recon),
              'src_patch': src_patch, 'tgt_patch': tgt_patch}
         graphs = self._gan_graphs() if self._gan_graph_ok() else None
+        if graphs is not None and not graphs.fits(t):
+            graphs = None              # other cluster / crop shapes than the recorded ones: this iteration runs eagerly
+        in_graph = graphs is not None and graphs.recording()
 
         # The adversarial terms below are the reference's sums over clusters of F.binary_cross_entropy(torch.sigmoid(d)[c], label)
         # (one mean per cluster row), each group evaluated by ONE fused kernel (A.adversarial_loss) on the logits.
@@ -505,12 +541,17 @@ class ScdaTrainer:
         pro_shape = (src_patch.shape[0], self._dis_patch_out_len())
         t['score1'], t['score0'], t['score0p'], t['score1p'] = _labels(
             [('s', 1, row), ('s', 0, row), ('s', 0, pro_shape), ('s', 1, pro_shape)], dev)
+        self._in_graph = in_graph
         if graphs is not None and graphs.ready('a'):
             src_recon, tgt_recon, adloss, dis_patch_loss = graphs.run('a', t)
             w1 = w2 = None
         else:
             with _recording(graphs, 'a', t) as rec:
                 src_recon, tgt_recon, adloss, dis_patch_loss, w1, w2 = rec(lambda tt: self._region_a(tt))
+        self._in_graph = False
+        if in_graph:                   # the region's collectives, behind the replay
+            w1 = self._all_reduce(self.dis, async_op=True)
+            w2 = self._all_reduce(self.dis_patch, async_op=True)
         mark('phase2')
         if w1 is not None:
             w1.wait()
@@ -523,12 +564,16 @@ class ScdaTrainer:
 
         # ---------------- (3) decoders ----------------
         t['one_t'], t['zero_t'], t['one_s'], t['zero_s'] = _labels([('h', 1, row), ('h', 0, row), ('h', 1, row), ('h', 0, row)], dev)
+        self._in_graph = in_graph
         if graphs is not None and graphs.ready('b'):
             recon_loss, fake1_src, w_tgt2 = graphs.run('b', t)
             w3 = None
         else:
             with _recording(graphs, 'b', t) as rec:
                 recon_loss, fake1_src, w_tgt2, w3 = rec(lambda tt: self._region_b(src_recon, tgt_recon, tt))
+        self._in_graph = False
+        if in_graph:
+            w3 = self._all_reduce(self.dec, async_op=True)
         mark('phase3')
 
         # ---------------- (4) detector ----------------

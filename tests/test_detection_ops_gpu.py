@@ -86,7 +86,10 @@ def test_nms_rejects_cpu_tensor(cuda):
         native.nms(torch.zeros(3, 5), 0.5)
 
 
-@pytest.mark.parametrize("shape,R", [((1, 8, 32, 64), 64), ((2, 5, 16, 24), 33), ((1, 512, 32, 64), 512)])
+# (1, 6, 80, 80): 6400 pixels per plane = 83 KB of dynamic LDS in the ordered-scatter backward (the 64 - 96 KB window that needs
+# hipFuncAttributeMaxDynamicSharedMemorySize); (1, 3, 100, 120): 12000 pixels, beyond it -> the gather kernel
+@pytest.mark.parametrize("shape,R", [((1, 8, 32, 64), 64), ((2, 5, 16, 24), 33), ((1, 512, 32, 64), 512), ((1, 6, 80, 80), 96),
+                                     ((1, 3, 100, 120), 40)])
 def test_roi_pool_fwd_bwd_bit_exact(cuda, shape, R):
     from scda_amd import native
     rs = np.random.RandomState(R)
