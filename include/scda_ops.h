@@ -75,6 +75,12 @@ int scda_nms_valid_hip(const float *boxes, const unsigned char *valid, int n, fl
 /* the pairwise suppression bit-mask alone (upper triangle of col-blocks only):
  * mask uint64 [n, ceil(n/64)]                                                */
 int scda_nms_mask_hip(const float *boxes, int n, float thresh, uint64_t *mask, void *stream);
+/* S independent score-sorted lists in one mask launch + one sweep launch (one workgroup per list) -- the per-(class, image) calls of
+ * functions/predict_bbox.py:29-55 batched.  seg: DEVICE int64 [S][3] = {first row of the list in boxes / keep, its length n, first
+ * word of its mask in mask_ws (a list owns n * ceil(n / 64) words)}; max_n = the longest list.  keep [all rows]: each list's kept
+ * indices, LOCAL to the list, from its first row on; num_out [S]: the counts. */
+int scda_nms_segments_hip(const float *boxes, const long long *seg, int S, int max_n, float thresh, void *mask_ws, int64_t *keep,
+                          int64_t *num_out, void *stream);
 
 /* ------------------------------------------------------------ RoIPool ---- */
 /* replaces  int roi_pooling_forward_cuda(int ph,int pw,float scale, THCudaTensor* features,

@@ -89,8 +89,18 @@ __device__ __forceinline__ float iou_plus1(const float *a, const float *b) {
 // owns one row box and emits one 64-bit word.  Only col_block >= row_block is
 // computed: the sweep never reads the lower triangle (nms_cuda.c:53 starts at
 // j = nblock); those workgroups exit at once.
-__global__ __launch_bounds__(64) void nms_mask_kernel(const int n, const float thresh, const float *__restrict__ boxes,
-                                                       uint64_t *__restrict__ mask, const int col_blocks) {
+// seg (may be null): SEGMENTED form -- blockIdx.z = segment s with seg[3 s .. 3 s + 2] = {first box row, box count, first mask word}:
+// independent lists in one launch (the per-class lists of functions/predict_bbox.py:29-55), block-diagonal by construction.
+__global__ __launch_bounds__(64) void nms_mask_kernel(const int n_, const float thresh, const float *__restrict__ boxes,
+                                                       uint64_t *__restrict__ mask, const int col_blocks_,
+                                                       const long long *__restrict__ seg) {
+    int n = n_, col_blocks = col_blocks_;
+    if (seg) {
+        const long long *d = seg + 3 * blockIdx.z;
+        boxes += d[0] * 5; n = (int)d[1]; mask += d[2];
+        col_blocks = (n + 63) / 64;
+        if ((int)blockIdx.x >= col_blocks || (int)blockIdx.y >= col_blocks) return;
+    }
     const int row_start = blockIdx.y;
     const int col_start = blockIdx.x;
     if (col_start < row_start) return;  // lower triangle is never read by the sweep
@@ -127,11 +137,21 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const int n, const float t
 // valid (may be null): boxes with valid[i] == 0 start out removed -- they are never kept and, never being kept, never suppress
 // anything: the result equals the sweep over the list with those boxes deleted, with indices into the ORIGINAL list (the
 // min-size filter of functions/rpn_proposal.py:57-59 without a compaction pass or a host round trip for the new length)
-__global__ __launch_bounds__(1024) void nms_sweep_kernel(const uint64_t *__restrict__ mask, const int n,
-                                                        const int col_blocks, int64_t *__restrict__ keep,
+// seg (may be null): segmented form, one workgroup per segment (see nms_mask_kernel): keep indices are local to the segment and go to
+// keep + its first row, its count to num_out[segment].
+__global__ __launch_bounds__(1024) void nms_sweep_kernel(const uint64_t *__restrict__ mask, const int n_,
+                                                        const int col_blocks_, int64_t *__restrict__ keep,
                                                         int64_t *__restrict__ num_out, const int max_keep,
-                                                        const unsigned char *__restrict__ valid) {
+                                                        const unsigned char *__restrict__ valid,
+                                                        const long long *__restrict__ seg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    int n = n_, col_blocks = col_blocks_;
+    if (seg) {
+        const long long *d = seg + 3 * blockIdx.x;
+        keep += d[0]; n = (int)d[1]; mask += d[2]; num_out += blockIdx.x;
+        col_blocks = (n + 63) / 64;
+        if (n == 0) { if (threadIdx.x == 0) num_out[0] = 0; return; }
+    }
     uint64_t *remv = reinterpret_cast<uint64_t *>(smem_raw);  // [col_blocks]
     uint64_t *bcast = remv + col_blocks;                       // [2]: kept mask, stop flag
     const int tid = threadIdx.x;
@@ -795,7 +815,7 @@ SCDA_API int scda_nms_mask_hip(const float *boxes, int n, float thresh, uint64_t
     if (n < 0 || (n > 0 && (!boxes || !mask))) { set_error("scda_nms_mask_hip: bad arguments"); return SCDA_EINVAL; }
     if (n == 0) return SCDA_OK;
     const int cb = (n + 63) / 64;
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(cb, cb), dim3(64), 0, as_stream(stream), n, thresh, boxes, mask, cb);
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(cb, cb), dim3(64), 0, as_stream(stream), n, thresh, boxes, mask, cb, (const long long *)nullptr);
     return launch_status("nms_mask_kernel");
 }
 
@@ -820,7 +840,33 @@ SCDA_API int scda_nms_valid_hip(const float *boxes, const unsigned char *valid, 
     const size_t lds = (size_t)(cb + 2) * sizeof(uint64_t);
     if (lds > 64 * 1024) { set_error("scda_nms_hip: n=%d too large for the LDS-resident sweep", n); return SCDA_EINVAL; }
     hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(1024), lds, as_stream(stream), (const uint64_t *)mask_ws, n, cb,
-                       keep, num_out, max_keep, valid);
+                       keep, num_out, max_keep, valid, (const long long *)nullptr);
+    return launch_status("nms_sweep_kernel");
+}
+
+// S independent score-sorted lists in ONE mask launch + ONE sweep launch (one workgroup per list): functions/predict_bbox.py:29-55
+// calls nms once per (class, image).  seg: DEVICE int64 [S][3] = {first row of the list in boxes / keep, its length, first word of
+// its mask in mask_ws (lengths n occupy n * ceil(n / 64) words)}; max_n = the longest list; keep [rows of all lists] receives each
+// list's kept indices (local to the list) at its first row, num_out [S] the counts.
+SCDA_API int scda_nms_segments_hip(const float *boxes, const long long *seg, int S, int max_n, float thresh, void *mask_ws, int64_t *keep,
+                                   int64_t *num_out, void *stream) {
+    if (S < 0 || max_n < 0 || (S > 0 && (!seg || !num_out)) || (S > 0 && max_n > 0 && (!boxes || !mask_ws || !keep))) {
+        set_error("scda_nms_segments_hip: bad arguments");
+        return SCDA_EINVAL;
+    }
+    if (S == 0) return SCDA_OK;
+    if (max_n == 0) {
+        hipError_t e = hipMemsetAsync(num_out, 0, sizeof(int64_t) * S, as_stream(stream));
+        return e == hipSuccess ? SCDA_OK : SCDA_ELAUNCH;
+    }
+    const int cb = (max_n + 63) / 64;
+    const size_t lds = (size_t)(cb + 2) * sizeof(uint64_t);
+    if (lds > 64 * 1024 || S > 65535) { set_error("scda_nms_segments_hip: list of %d boxes / %d lists too large", max_n, S); return SCDA_EINVAL; }
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(cb, cb, S), dim3(64), 0, as_stream(stream), 0, thresh, boxes, (uint64_t *)mask_ws, 0, seg);
+    int st = launch_status("nms_mask_kernel");
+    if (st) return st;
+    hipLaunchKernelGGL(nms_sweep_kernel, dim3(S), dim3(1024), lds, as_stream(stream), (const uint64_t *)mask_ws, 0, 0, keep, num_out, 0,
+                       (const unsigned char *)nullptr, seg);
     return launch_status("nms_sweep_kernel");
 }
 

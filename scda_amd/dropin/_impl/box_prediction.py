@@ -12,18 +12,15 @@ from scda_amd.dropin import backend
 from scda_amd.dropin.utils import bbox_helper
 
 
-def _detections_of(image, cls, scores, boxes, image_hw, cfg):
-    """one (image, class) pair -> [k,7] rows or None"""
+def _candidates_of(scores, boxes, image_hw, cfg):
+    """one (image, class) pair -> its boxes [k,5] clipped, thresholded and ordered by score (descending), or None"""
     boxes[:, :4] = bbox_helper.clip_bbox(boxes[:, :4], image_hw)
     if cfg['score_thresh'] > 0:
         above = np.where(scores > cfg['score_thresh'])[0]
         scores, boxes = scores[above], boxes[above]
     if scores.size == 0:
         return None
-    boxes = boxes[scores.argsort()[::-1], :]
-    kept = boxes[backend.nms(torch.from_numpy(boxes).float(), cfg['nms_iou_thresh']).numpy()]
-    n = kept.shape[0]
-    return np.hstack([np.full((n, 1), image), kept, np.full((n, 1), cls)])
+    return boxes[scores.argsort()[::-1], :]
 
 
 def compute_predicted_bboxes(rois, pred_cls, pred_loc, image_info, cfg):
@@ -35,7 +32,9 @@ def compute_predicted_bboxes(rois, pred_cls, pred_loc, image_info, cfg):
     members = [np.where(rois[:, 0] == b)[0] for b in range(n_img)]
     stds, means = np.array(cfg['bbox_normalize_stds'])[None, :], np.array(cfg['bbox_normalize_means'])[None, :]
 
-    rows = []
+    # every (class, image) list first, then ONE batched NMS over all of them (one upload, a mask and a sweep launch with one
+    # workgroup per list, one download) instead of (classes - 1) x images round trips
+    lists, tags = [], []
     for cls in range(1, n_cls):
         scores = pred_cls[:, cls].squeeze()
         deltas = pred_loc[:, 4 * cls:4 * cls + 4].squeeze()
@@ -43,9 +42,15 @@ def compute_predicted_bboxes(rois, pred_cls, pred_loc, image_info, cfg):
             deltas = deltas * stds + means
         scored = np.hstack([bbox_helper.compute_loc_bboxes(rois[:, 1:5], deltas), scores[:, None]])
         for b, idx in enumerate(members):
-            det = _detections_of(b, cls, scores[idx], scored[idx], image_info[b], cfg)
-            if det is not None:
-                rows.append(det)
+            cand = _candidates_of(scores[idx], scored[idx], image_info[b], cfg)
+            if cand is not None:
+                lists.append(cand)
+                tags.append((b, cls))
+    rows = []
+    for cand, keep, (b, cls) in zip(lists, backend.nms_segments(lists, cfg['nms_iou_thresh']), tags):
+        kept = cand[np.asarray(keep, dtype=np.int64)]
+        n = kept.shape[0]
+        rows.append(np.hstack([np.full((n, 1), b), kept, np.full((n, 1), cls)]))
     rows = np.vstack(rows)
     if cfg['top_n'] > 0:
         best = []

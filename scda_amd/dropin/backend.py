@@ -4,6 +4,8 @@ Default: the HIP kernels (through the C ABI).  Tests and the CPU oracle may
 plug the C oracle in with `use(...)` to exercise the host logic on a machine
 without a GPU; the product never does.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -61,6 +63,46 @@ def _hip_nms(dets, thresh, max_keep=0):
         host[n:].copy_(num, non_blocking=True)
         aux.synchronize()
     return host[: int(host[n])].clone()
+
+
+def _hip_nms_segments(lists, thresh):
+    """lists: score-sorted float arrays [n_i, >=4] -> list of kept-index arrays, ONE upload, two launches, ONE download"""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    lens = [int(a.shape[0]) for a in lists]
+    rows, max_n = sum(lens), max(lens, default=0)
+    if rows == 0:
+        return [np.zeros(0, dtype=np.int64) for _ in lists]
+    packed = np.zeros((rows, 5), dtype=np.float32)
+    seg = np.zeros((len(lists), 3), dtype=np.int64)
+    r = w = 0
+    for i, (a, n) in enumerate(zip(lists, lens)):
+        packed[r:r + n, :4] = a[:, :4]
+        seg[i] = (r, n, w)
+        r += n
+        w += n * ((n + 63) // 64)
+    aux = _aux_stream(dev)
+    with torch.cuda.stream(aux):
+        b = _pinned(packed).to(dev, non_blocking=True)
+        sg = _pinned(seg).to(dev, non_blocking=True)
+        keep, num = native.nms_segments(b, sg, max_n, float(thresh))
+        host = torch.empty(rows + len(lists), dtype=torch.int64, pin_memory=True)
+        host[:rows].copy_(keep[:rows], non_blocking=True)
+        host[rows:].copy_(num[:len(lists)], non_blocking=True)
+        aux.synchronize()
+    h = host.numpy()
+    return [h[o:o + int(h[rows + i])].copy() for i, (o, n) in enumerate(zip(seg[:, 0], lens))]
+
+
+def nms_segments(lists, thresh):
+    """NMS of several independent score-sorted lists at once (functions/predict_bbox.py:29-55 calls nms per class and image).  With a
+    substituted nms hook (tests on the CPU): one call of it per list."""
+    f = _impl.get("nms")
+    if f is None:
+        if os.environ.get("SCDA_NMS_UNBATCHED"):       # A/B knob (scripts/time_eval.py): one round trip per list, as before
+            return [_hip_nms(torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)), thresh).numpy() for a in lists]
+        return _hip_nms_segments(lists, thresh)
+    return [np.asarray(f(torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)), thresh)) if a.shape[0] else np.zeros(0, dtype=np.int64)
+            for a in lists]
 
 
 def host_array(x, copy=False):

@@ -84,6 +84,20 @@ def nms(boxes, thresh, max_keep=0):
     return keep, num
 
 
+def nms_segments(boxes, seg, max_n, thresh):
+    """S independent score-sorted lists in one mask + one sweep launch (scda_nms_segments_hip): boxes [rows,5] fp32 CUDA (the lists
+    back to back), seg int64 [S,3] CUDA = (first row, length, first mask word) -> (keep int64 [rows] CUDA, num int64 [S] CUDA)"""
+    _req(boxes, "boxes"); _req(seg, "seg", torch.int64)
+    S, rows = seg.shape[0], boxes.shape[0]
+    keep = torch.empty(max(rows, 1), dtype=torch.int64, device=boxes.device)
+    num = torch.zeros(max(S, 1), dtype=torch.int64, device=boxes.device)
+    words = S * max_n * ((max_n + 63) // 64)                  # upper bound of the lists' mask words
+    ws = torch.empty(max(words, 1), dtype=torch.int64, device=boxes.device)
+    _check(lib().scda_nms_segments_hip(_p(boxes), _p(seg), i32(S), i32(max_n), f32(thresh), _p(ws), _p(keep), _p(num), _stream()),
+           "scda_nms_segments_hip")
+    return keep, num
+
+
 def nms_mask(boxes, thresh):
     _req(boxes, "boxes")
     n = boxes.shape[0]

@@ -80,6 +80,29 @@ def test_nms_mask_upper_triangle_bit_exact(cuda):
     np.testing.assert_array_equal(m[upper], ref[upper])
 
 
+def test_nms_segments_equal_per_list_nms(cuda):
+    """scda_nms_segments_hip (the per-class lists of functions/predict_bbox.py:29-55 in one mask + one sweep launch): every list's
+    keep indices equal a separate scda_nms_hip call's and the oracle's, for empty / one-box / chunk-boundary / 300-box lists"""
+    from scda_amd import native
+    from scda_amd.dropin import backend
+    rs = np.random.RandomState(12)
+    lens = [0, 1, 63, 64, 65, 300, 128, 0, 300, 7]
+    lists = []
+    for n in lens:
+        b = rand_boxes(rs, n) if n else np.zeros((0, 5), np.float32)
+        if n:
+            b = b[np.argsort(-b[:, 4], kind="stable")]
+        lists.append(b.astype(np.float32))
+    got = backend.nms_segments(lists, 0.5)
+    assert len(got) == len(lists)
+    for b, k in zip(lists, got):
+        want = orc.nms(b, 0.5) if b.shape[0] else np.zeros(0, np.int64)
+        np.testing.assert_array_equal(np.asarray(k), want)
+        if b.shape[0]:
+            keep, num = native.nms(dev(b, cuda), 0.5)
+            np.testing.assert_array_equal(keep[: int(num)].cpu().numpy(), want)
+
+
 def test_nms_rejects_cpu_tensor(cuda):
     from scda_amd import native
     with pytest.raises(native.ScdaNativeError):
@@ -154,6 +177,71 @@ def test_roi_align_fwd_bwd(cuda):
     eg = orc.roi_align_bwd(top, rois, shape, 8, 8, 1 / 16.)
     g = native.roi_align_bwd(dev(top, cuda), dev(rois, cuda), shape, 8, 8, 1 / 16.)
     np.testing.assert_allclose(g.cpu().numpy(), eg, rtol=1e-5, atol=1e-5)  # atomics: order differs
+
+
+def _roi_align_third_statement(feat, rois, AH, AW, scale, top=None):
+    """A THIRD, independent statement of extensions/_roi_align/src/roi_align_kernel.cu:15-70 (forward) and :94-143 (backward), written
+    from the kernel text by flat-index arithmetic only -- it shares no helper with oracle/scda_oracle.c or tests/np_restate.py.  Sample
+    geometry in float32 exactly as the kernel's float variables hold it (the `1.` literals make the divisions double, the results are
+    stored to float), interpolation in float64.  -> out [R, C, AH, AW] (float64), and with `top` the gradient [B, C, H, W]."""
+    B, C, H, W = feat.shape
+    R = rois.shape[0]
+    f32 = np.float32
+    r = rois.astype(f32)
+    sc = f32(scale)
+    x1, y1, x2, y2 = (r[:, 1] * sc).astype(f32), (r[:, 2] * sc).astype(f32), (r[:, 3] * sc).astype(f32), (r[:, 4] * sc).astype(f32)
+    rw = np.maximum((x2 - x1).astype(np.float64) + 1.0, 0.0).astype(f32)          # fmaxf(roi_end_w - roi_start_w + 1., 0.)
+    rh = np.maximum((y2 - y1).astype(np.float64) + 1.0, 0.0).astype(f32)
+    bh = (rh.astype(np.float64) / (AH - 1.0)).astype(f32)                          # roi_height / (aligned_height - 1.)
+    bw = (rw.astype(np.float64) / (AW - 1.0)).astype(f32)
+    ph = np.arange(AH, dtype=f32)[None, :]
+    pw = np.arange(AW, dtype=f32)[None, :]
+    h = (ph * bh[:, None] + y1[:, None]).astype(f32)                               # [R, AH]   (float)(ph) * bin_size_h + roi_start_h
+    w = (pw * bw[:, None] + x1[:, None]).astype(f32)                               # [R, AW]
+    hs = np.minimum(np.floor(h), f32(H - 2)).astype(np.int64)                      # fminf(floor(h), height - 2)
+    ws = np.minimum(np.floor(w), f32(W - 2)).astype(np.int64)
+    inside = ~((h < 0) | (h >= H))[:, :, None] & ~((w < 0) | (w >= W))[:, None, :] # [R, AH, AW]
+    hr = (h - hs.astype(f32)).astype(f32).astype(np.float64)[:, :, None]           # h_ratio (float), used in double arithmetic
+    wr = (w - ws.astype(f32)).astype(f32).astype(np.float64)[:, None, :]
+    img = r[:, 0].astype(np.int64)
+    base = img[:, None, None] * (C * H * W) + np.where(inside, hs[:, :, None] * W + ws[:, None, :], 0)   # channel 0's up-left corner
+    flat = feat.astype(np.float64).reshape(-1)
+    coef = [(1.0 - hr) * (1.0 - wr), (1.0 - hr) * wr, hr * (1.0 - wr), hr * wr]
+    offs = [0, 1, W, W + 1]
+    chan = (np.arange(C, dtype=np.int64) * (H * W))[None, :, None, None]
+    idx0 = base[:, None, :, :] + chan                                               # [R, C, AH, AW]
+    out = np.zeros((R, C, AH, AW))
+    for cf, o in zip(coef, offs):
+        out += flat[idx0 + o] * cf[:, None, :, :]
+    out *= inside[:, None, :, :]
+    if top is None:
+        return out
+    grad = np.zeros(B * C * H * W)
+    t = top.astype(np.float64) * inside[:, None, :, :]
+    for cf, o in zip(coef, offs):
+        np.add.at(grad, (idx0 + o).reshape(-1), (t * cf[:, None, :, :]).reshape(-1))
+    return out, grad.reshape(B, C, H, W)
+
+
+def test_roi_align_unpinned_third_independent_statement(cuda):
+    """RoIAlign's oracle cannot be pinned against a build or run of the reference (its only source is a .cu file); besides the C
+    restatement (bit-exact above) and tests/np_restate.py this is a third statement, at the shape BASELINE configs[3] runs: features
+    [1, 1024, 50, 84], 512 RoIs, 8 x 8 samples (channels in four chunks of 256 to bound the float64 temporaries)."""
+    from scda_amd import native
+    rs = np.random.RandomState(77)
+    C, H, W, R = 1024, 50, 84, 512
+    feat = rs.randn(1, C, H, W).astype(np.float32)
+    rois = rand_rois(rs, R, B=1, W=W * 16, H=H * 16)
+    rois[0] = [0, -30, -30, 100, 100]                       # samples left of / above the map: zeros, no gradient
+    rois[1] = [0, W * 16 - 40, H * 16 - 40, W * 16 + 60, H * 16 + 60]      # ... right of / below it; the hstart = height - 2 clamp
+    top = rs.randn(R, C, 8, 8).astype(np.float32)
+    out = native.roi_align_fwd(dev(feat, cuda), dev(rois, cuda), 8, 8, 1 / 16.).cpu().numpy()
+    g = native.roi_align_bwd(dev(top, cuda), dev(rois, cuda), feat.shape, 8, 8, 1 / 16.).cpu().numpy()
+    for c0 in range(0, C, 256):
+        want, wg = _roi_align_third_statement(feat[:, c0:c0 + 256], rois, 8, 8, 1 / 16., top[:, c0:c0 + 256])
+        np.testing.assert_allclose(out[:, c0:c0 + 256], want, rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(g[:, c0:c0 + 256], wg, rtol=1e-4, atol=1e-4 * float(np.abs(wg).max()))
+    assert float(np.abs(out[0]).max()) > 0 and (out[0, :, 0, 0] == 0).all()      # RoI 0's first sample lies outside
 
 
 @pytest.mark.parametrize("shape,R,a", [((1, 24, 50, 84), 512, 8), ((2, 5, 13, 9), 33, 7), ((1, 3, 200, 336), 40, 8)])

@@ -259,6 +259,70 @@ def test_gradients_with_replayed_selections(cuda, H, W):
     assert all(e <= 1e-4 for _, e in worst.values()), worst
 
 
+def test_fullsize_free_running_iteration_tracks_oracle(cuda, monkeypatch):
+    """512 x 1024 (the BASELINE size) with NOTHING replayed but the dropout masks: each side ranks its own RPN scores, breaks its own
+    ties and samples its own RoIs.  Among 30720 fp32 objectness scores some pairs sit closer than the 1e-6 by which two correct
+    implementations differ, so a few proposals swap places and the sampled RoI sets part ways (why the arithmetic is compared with the
+    selections replayed, test_gradients_with_replayed_selections) -- but the iteration as a whole must stay on the oracle's:
+    identical anchor labelling (positive / negative counts), >= 90 % of the 2000 source proposals identical, every loss within 2 %."""
+    from scda_amd import layers as L
+    from scda_amd.train_step import ScdaTrainer
+    from scda_amd.dropin.functions import anchor_target as AT
+    from scda_amd.dropin.models.faster_rcnn import faster_rcnn_adver_expansion_reweight_cluster as FRC
+    H, W, lr = 512, 1024, 1e-3
+    counts = []
+    orig = AT.compute_anchor_targets
+
+    def counting(*a, **kw):
+        out = orig(*a, **kw)
+        lab = out[0].detach().cpu()
+        counts.append((int((lab == 1).sum()), int((lab == 0).sum()), int((lab == -1).sum()), float(out[3])))
+        return out
+
+    monkeypatch.setattr(AT, "compute_anchor_targets", counting)      # the oracle imports it at call time ...
+    monkeypatch.setattr(FRC, "compute_anchor_targets", counting)     # ... the product's detector module holds its own reference
+    ref, _, masks = mc.oracle_iteration(H, W, lr=lr, record_masks=True)
+    n_ref = len(counts)
+    assert n_ref == 1
+    torch.manual_seed(1)
+    tr = ScdaTrainer(mc.CFG, cuda, lr=lr, new_w=W, new_h=H, models=mc.seeded_models(build_product))
+    src, tgt, gts, info = mc.seeded_inputs(H, W)
+    grabbed = {}
+    fwd = tr.model.forward
+
+    def grabbing(x, target):
+        out = fwd(x, target)
+        grabbed.update(out)
+        return out
+
+    tr.model.forward = grabbing
+    tape = list(masks)
+    L.Dropout.mask_source = lambda shape, p, device: tape.pop(0).to(device)
+    try:
+        np.random.seed(mc.SEEDS['numpy'])
+        out = tr.step(src.to(cuda), gts, info, tgt.to(cuda))
+        torch.cuda.synchronize()
+    finally:
+        L.Dropout.mask_source = None
+    assert not tape
+    # anchor labelling: a function of the ground truth and numpy's generator alone
+    assert len(counts) == 2 and counts[0] == counts[1], counts
+    assert counts[0][0] > 0 and counts[0][0] + counts[0][1] == 256           # the RPN batch
+    # proposals
+    p_ref, p_got = ref['_outputs']['predict'][0].numpy(), grabbed['predict'][0].cpu().numpy()
+    assert p_ref.shape == p_got.shape == (2000, 6), (p_ref.shape, p_got.shape)
+    same_place = int((np.abs(p_ref[:, :5] - p_got[:, :5]).max(1) <= 1e-3).sum())
+    ref_rows = {tuple(np.round(r, 2)) for r in p_ref[:, 1:5]}
+    anywhere = sum(tuple(np.round(r, 2)) in ref_rows for r in p_got[:, 1:5])
+    assert anywhere >= 1800, (same_place, anywhere)          # >= 90 % of the oracle's proposals are in the device's list
+    # losses
+    for k in LOSS_KEYS:
+        a, b = float(out[k]), float(ref[k])
+        assert abs(a - b) <= 0.02 * max(abs(b), 1e-3), (k, a, b)
+    assert abs(float(out['rpn_acc'][0]) - float(ref['rpn_acc'][0])) < 1.0
+    assert abs(float(out['rcnn_acc'][0]) - float(ref['rcnn_acc'][0])) < 2.0
+
+
 def test_vgg16_bn_detector_trains(cuda):
     """the batch-norm backbone variant (vgg16_bn, `--arch vgg16bn_FasterRCNN` in the reference driver): one full iteration
     through the same step; finite losses, BN statistics updated, torchvision's vgg16_bn key layout"""
