@@ -59,4 +59,17 @@ def prefer_blocking_sync(device_index=0):
     rc = int(hip.hipSetDevice(ctypes.c_int(int(device_index))))   # the flags apply to the calling thread's current device
     if rc:
         return rc
-    return int(hip.hipSetDeviceFlags(ctypes.c_uint(4)))
+    rc = int(hip.hipSetDeviceFlags(ctypes.c_uint(4)))
+    if rc == 0:
+        _blocking_sync[0] = True
+    return rc
+
+
+_blocking_sync = [False]
+
+
+def blocking_sync_selected():
+    """prefer_blocking_sync() took effect in this process.  The trainer then keeps the GAN phases eager: under any non-default
+    scheduling flag each hipGraph launch costs the device ~1.3 ms inside the runtime (profiles/r03_hipgraph.txt; round 4, same
+    measurement: 22.4 ms per iteration with the graphs against 19.2 ms without, scripts/host_budget_8ranks.py)."""
+    return _blocking_sync[0]

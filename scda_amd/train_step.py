@@ -465,6 +465,9 @@ class ScdaTrainer:
         The all-reduces of a data-parallel run are host calls: issued behind each replay (step), never recorded."""
         from . import layers as L
         from .dropin.models.faster_rcnn.common_net import INSResBlock
+        from .hostenv import blocking_sync_selected
+        if blocking_sync_selected() and os.environ.get("SCDA_GAN_GRAPH") != "1":
+            return False      # several ranks per node (bench.py): blocking waits, and in that mode a graph launch costs device time
         if not (os.environ.get("SCDA_GAN_GRAPH", "1") != "0" and self.device.type == "cuda" and not self.capture and self.early_backward
                 and A.replay is None and L.Dropout.mask_source is None and self.flat):
             return False
