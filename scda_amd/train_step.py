@@ -466,8 +466,11 @@ class ScdaTrainer:
         from . import layers as L
         from .dropin.models.faster_rcnn.common_net import INSResBlock
         from .hostenv import blocking_sync_selected
-        if blocking_sync_selected() and os.environ.get("SCDA_GAN_GRAPH") != "1":
-            return False      # several ranks per node (bench.py): blocking waits, and in that mode a graph launch costs device time
+        if (blocking_sync_selected() or self.collectives) and os.environ.get("SCDA_GAN_GRAPH") != "1":
+            # several ranks per node (bench.py): blocking waits, and in that mode a graph launch costs device time; and with the
+            # collectives' stream in the process the replays interact badly with it (one-rank RCCL group, scripts/onerank_rccl_cost.py:
+            # 27.6 ms per iteration with the graphs, 19.7 without, 19.4 without collectives) -- data-parallel runs stay eager
+            return False
         if not (os.environ.get("SCDA_GAN_GRAPH", "1") != "0" and self.device.type == "cuda" and not self.capture and self.early_backward
                 and A.replay is None and L.Dropout.mask_source is None and self.flat):
             return False
