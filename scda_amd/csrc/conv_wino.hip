@@ -123,7 +123,9 @@ __global__ __launch_bounds__(512, (MB == 2 ? 2 : 4)) void conv_wino_kernel(const
     };
 
     // ---- this wave's two positions ------------------------------------------------------------------------------------------------
-    const int a = wave >> 1, bsel = wave & 1;
+    // waves w and w + 4 share a SIMD (a workgroup's waves go to the SIMDs cyclically): one of each column set per SIMD -- the {0, 3} waves
+    // read and add twice as much per fragment as the {1, 2} waves, and every slab ends in a barrier
+    const int a = wave & 3, bsel = wave >> 2;
     const int xi0 = a * 4 + (bsel ? 1 : 0), xi1 = a * 4 + (bsel ? 2 : 3);
     // BT row a = signed sum of patch rows i1, i2:  0: d0 - d2   1: d1 + d2   2: d2 - d1   3: d1 - d3
     const int i1 = a == 0 ? 0 : a == 2 ? 2 : 1, i2 = a == 0 ? 2 : a == 1 ? 2 : a == 2 ? 1 : 3;
@@ -390,7 +392,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino_wgrad_kernel(const float *__
     };
 
     // ---- this wave's two positions ------------------------------------------------------------------------------------------------
-    const int a = wave >> 1, bsel = wave & 1;
+    // waves w and w + 4 share a SIMD (a workgroup's waves go to the SIMDs cyclically): one of each column set per SIMD -- the {0, 3} waves
+    // read and add twice as much per fragment as the {1, 2} waves, and every slab ends in a barrier
+    const int a = wave & 3, bsel = wave >> 2;
     const int xi0 = a * 4 + (bsel ? 1 : 0), xi1 = a * 4 + (bsel ? 2 : 3);
     const int i1 = a == 0 ? 0 : a == 2 ? 2 : 1, i2 = a == 0 ? 2 : a == 1 ? 2 : a == 2 ? 1 : 3;     // BT row a (as in the forward)
     const float sgn = a == 1 ? 1.f : -1.f;
