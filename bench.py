@@ -63,7 +63,8 @@ DOMINANT_SMALL_TILES = "conv_igemm_glds_kernel<64,*,3,3,1,fwd>"
 DOMINANT = "conv_igemm_glds_kernel<128|256,*,3,3,1,fwd>"   # the instantiations with 128 or 256 tile rows (256 = 8 waves), any tile width, 3x3 stride 1, forward
 # with the Winograd kernel (the default): every stride-1 3x3 forward with >= 64 channels is a launch of this ONE kernel (VGG 12 + RPN 1
 # per image, the decoders' residual / up-sampling convolutions); the library's profiler counts the MFMA work it EXECUTES
-DOMINANT_WINO = "conv_wino_kernel<fwd>"
+DOMINANT_WINO = ("conv_wino_kernel<fwd>", "conv_wino_kernel<dgrad>")   # ONE kernel function (conv_wino_kernel<1|2> in rocprofv3's listing): the
+#                                       data gradient is the same launch with the rotated filters; the profiler tags them apart
 WINO_RATIO = 2.25            # direct-convolution MACs per executed Winograd F(2x2,3x3) MAC
 
 
@@ -80,13 +81,14 @@ def synth_batch(rank, H=H, W=W):
     return src, tgt, gts, torch.tensor([[H, W, 1.0]])
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, prefix=""):
     """L2 memory-side bytes per launch of the dominant kernel.  PMC counters cannot be sampled from inside the timed
     run; they come from the committed rocprofv3 passes of this same command (scripts/collect_profiles.sh ->
     profiles/r01_pmc_traffic.json: `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` in separate passes, FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for gfx950).  None when that file is absent."""
     for name in PMC_TRAFFIC_FILES:     # newest committed counter pass first
         try:
+            name = name.replace("_pmc_traffic", "_" + prefix + "pmc_traffic") if prefix else name
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 d = json.load(f)
             if d["dominant"].get("kernel", DOMINANT).split("<")[0] != kernel.split("<")[0]:
@@ -253,7 +255,8 @@ def main():
     # iteration, timed INSIDE the timed region.  ResNet: its dominant class is 86 launches per iteration, so it is timed in a
     # separate pass after the timed region (3 more iterations) and the throughput number stays unperturbed.
     in_region = a.config == "vgg16"
-    native.prof_enable([dominant] if in_region else False)
+    dom_list = list(dominant) if isinstance(dominant, tuple) else [dominant]
+    native.prof_enable(dom_list if in_region else False)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -267,7 +270,7 @@ def main():
     if mask_rois is not None:
         f_iter += RC.mask_branch_tflop(mask_rois)
     if not in_region:
-        native.prof_enable([dominant])
+        native.prof_enable(dom_list)
         for _ in range(3):
             tr.step(src, gts, info, tgt, **step_kw)
         torch.cuda.synchronize()
@@ -308,10 +311,13 @@ def main():
         roof = None
         if dominant is None and prof:
             dominant = max(prof, key=lambda k: prof[k][1])
+        if isinstance(dominant, tuple) and any(k in prof for k in dominant):     # classes of one kernel function: summed
+            prof["conv_wino_kernel<1|2> (forward + data gradient)"] = tuple(sum(prof[k][i] for k in dominant if k in prof) for i in range(4))
+            dominant = "conv_wino_kernel<1|2> (forward + data gradient)"
         if dominant in prof:
             n, tms, fl, by = prof[dominant]
             ach = fl / (tms * 1e-3) / 1e12
-            traffic, src = pmc_traffic(dominant) if a.config == "vgg16" else (None, None)   # counter passes exist for the VGG configuration
+            traffic, src = pmc_traffic(dominant, "" if a.config == "vgg16" else "resnet50_")   # the committed counter passes of this configuration
             it_ach = f_iter * world * a.steps / dt
             roof = {"bound": "mfma", "kernel": dominant, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,

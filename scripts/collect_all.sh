@@ -22,7 +22,9 @@ if [ "${1:-}" = "--install" ]; then
   [ -s $S/maskrcnn_bench.json ] && cp $S/maskrcnn_bench.json $D/${TAG}_maskrcnn_bench_1gpu.json
   [ -s $S/maskrcnn/kernel_categories.md ] && cp $S/maskrcnn/kernel_categories.md $D/${TAG}_maskrcnn_kernel_categories.md
   cp $S/resnet50/exposed_time.md $D/${TAG}_resnet50_exposed_time.md
-  for f in device_phase_times.txt host_cpu.txt resnet50_plan_search.txt plan_search.txt s2_conv_layers.txt; do
+  cp $S/resnet50/pmc_traffic.md $D/${TAG}_resnet50_pmc_traffic.md; cp $S/resnet50/pmc_traffic.json $D/${TAG}_resnet50_pmc_traffic.json
+  cp $S/resnet50/pmc_mfma.md $D/${TAG}_resnet50_pmc_mfma.md
+  for f in device_phase_times.txt host_cpu.txt resnet50_plan_search.txt plan_search.txt s2_conv_layers.txt host_budget.txt onerank_rccl.txt allreduce_contention.txt wino_layers.txt eval.txt; do
     [ -s $S/$f ] && cp $S/$f $D/${TAG}_$f
   done
   for f in $D/${TAG}_*; do [ -s $f ] || echo "WARNING: $f is empty"; done
@@ -55,6 +57,21 @@ bash scripts/kt.sh $TAG/resnet50 "--config resnet50" > $OUT/resnet50/kernel_cate
   rocprofv3 --kernel-trace --output-format csv -d $OUT/kt_csv -o kt -- python $R/bench.py --config resnet50 --steps 6 --warmup 3 --no-cpu-baseline > $OUT/kt_csv.log 2>&1 )
 python scripts/exposed_time.py "$OUT/kt_csv/*kernel_trace.csv" 6 > $OUT/resnet50/exposed_time.md
 rm -rf $OUT/kt_csv
+# counter passes for the ResNet-50 C4 configuration (FETCH_SIZE / WRITE_SIZE separately, then the MFMA pipe): PMC only + kernel trace
+( cd /tmp; export TMPDIR=/tmp
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/resnet50/pmc_$c -o pmc -- python $R/bench.py --config resnet50 --steps 2 --warmup 1 --no-cpu-baseline > $OUT/resnet50/pmc_$c.log 2>&1
+  done
+  timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/resnet50/pmc_mfma -o pmc -- python $R/bench.py --config resnet50 --steps 2 --warmup 1 --no-cpu-baseline > $OUT/resnet50/pmc_mfma.log 2>&1 )
+python scripts/pmc_summary.py $OUT/resnet50 $OUT/resnet50/pmc_traffic.md $OUT/resnet50/pmc_traffic.json resnet > /dev/null
+python scripts/pmc_mfma_summary.py $OUT/resnet50/pmc_mfma/pmc_counter_collection.csv $OUT/resnet50/pmc_mfma.md > /dev/null
+python scripts/host_budget_8ranks.py spin > $OUT/host_budget.txt 2>/dev/null
+python scripts/host_budget_8ranks.py block >> $OUT/host_budget.txt 2>/dev/null
+SCDA_GAN_GRAPH=1 python scripts/host_budget_8ranks.py block >> $OUT/host_budget.txt 2>/dev/null
+( python scripts/onerank_rccl_cost.py 0; python scripts/onerank_rccl_cost.py 1; SCDA_GAN_GRAPH=1 python scripts/onerank_rccl_cost.py 1 ) 2>/dev/null | grep collectives > $OUT/onerank_rccl.txt
+python scripts/allreduce_contention.py 32 4 2>/dev/null > $OUT/allreduce_contention.txt
+python scripts/bench_wino.py > $OUT/wino_layers.txt 2>/dev/null
+python scripts/time_eval.py 2>/dev/null > $OUT/eval.txt
 if [ "${2:-}" = "full" ]; then
   python scripts/tune_plans.py resnet > $OUT/resnet50_plan_search.txt 2>/dev/null
   python scripts/tune_plans.py > $OUT/plan_search.txt 2>/dev/null

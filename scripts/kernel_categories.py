@@ -7,6 +7,8 @@ for l in open(path):
     if m:
         rows.append((m.group(1), int(m.group(2)), float(m.group(3))))
 def cat(k):
+    if 'conv_wino_wgrad' in k: return 'conv wgrad (Winograd MFMA)'
+    if 'conv_wino_kernel' in k: return 'conv fwd/dgrad (Winograd MFMA)'
     if 'conv_igemm_glds' in k: return 'conv fwd/dgrad (direct-to-LDS MFMA)'
     if 'conv_igemm_kernel' in k: return 'conv gather (MFMA)'
     if 'conv_wgrad' in k: return 'conv wgrad (MFMA)'

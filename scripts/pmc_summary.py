@@ -28,21 +28,28 @@ def short(name):
     return name
 
 
-def main(d, out_md, out_json, algo_json=None):
+def main(d, out_md, out_json, which=None):
     F, W = load(d, "FETCH_SIZE"), load(d, "WRITE_SIZE")
     rows = []
     for k, f in F.items():
         w = W.get(k, [0.0])
         rows.append((short(k), len(f), 2.0 * 1024 * sum(f) / len(f), 1024 * sum(w) / len(w)))
     rows.sort(key=lambda r: -(r[2] + r[3]) * r[1])
-    dom = [r for r in rows if r[0].startswith(("conv_igemm_glds_kernel<128, ", "conv_igemm_glds_kernel<256, ")) and r[0].endswith("3, 3, 1, false>")]
+    dom_name = "conv_wino_kernel<1|2> (forward + data gradient)"
+    dom = [r for r in rows if r[0].startswith("conv_wino_kernel<")]
+    if which == "resnet":     # the ResNet-50 C4 configuration's dominant class: the 64-row tiles of its 1x1 convolutions (resnet_config.DOMINANT)
+        dom_name = "conv_igemm_glds_kernel<64,*,1,1,1,fwd>"
+        dom = [r for r in rows if r[0].startswith("conv_igemm_glds_kernel<64, ") and r[0].endswith("1, 1, 1, false>")]
+    elif not dom:     # SCDA_WINOGRAD=0: the direct kernel's 128- / 256-row forward instantiations
+        dom_name = "conv_igemm_glds_kernel<128|256,*,3,3,1,fwd>"
+        dom = [r for r in rows if r[0].startswith(("conv_igemm_glds_kernel<128, ", "conv_igemm_glds_kernel<256, ")) and r[0].endswith("3, 3, 1, false>")]
     n = sum(r[1] for r in dom)
     dom_fetch = sum(r[2] * r[1] for r in dom) / max(n, 1)
     dom_write = sum(r[3] * r[1] for r in dom) / max(n, 1)
     cal = {r[0]: r for r in rows}
     with open(out_md, "w") as f:
         f.write("# rocprofv3 PMC: L2 memory-side traffic per launch\n\n")
-        f.write("Two passes of `python bench.py --steps 2 --warmup 1 --no-cpu-baseline`: `rocprofv3 --pmc FETCH_SIZE --kernel-trace` and\n"
+        f.write("Two passes of `python bench.py --steps 2 --warmup 1 --no-cpu-baseline" + (" --config resnet50" if which == "resnet" else "") + "`: `rocprofv3 --pmc FETCH_SIZE --kernel-trace` and\n"
                 "`rocprofv3 --pmc WRITE_SIZE --kernel-trace` (counters never combined, no other trace domains).  read = 2 x FETCH_SIZE KB\n"
                 "(gfx950 counts 64 B per 128-byte request), write = WRITE_SIZE KB.  Infinity-Cache hits are counted, so these are\n"
                 "bytes leaving the L2, an upper bound on HBM bytes.\n\n")
@@ -53,13 +60,13 @@ def main(d, out_md, out_json, algo_json=None):
                           ("dropout_apply_kernel", "reads 4 B + 1 B mask, writes 4 B -> read/write = 1.25")):
             if k in cal and cal[k][3] > 0:
                 f.write("* `%s`: %s; measured (2 x FETCH)/WRITE = %.3f\n" % (k, expect, cal[k][2] / cal[k][3]))
-        f.write("\nDominant kernel class `conv_igemm_glds_kernel<128|256,*,3,3,1,fwd>` (%d launches): read %.1f MB + write %.1f MB = %.1f MB per launch\n\n"
-                % (n, dom_fetch / 1e6, dom_write / 1e6, (dom_fetch + dom_write) / 1e6))
+        f.write("\nDominant kernel class `%s` (%d launches): read %.1f MB + write %.1f MB = %.1f MB per launch\n\n"
+                % (dom_name, n, dom_fetch / 1e6, dom_write / 1e6, (dom_fetch + dom_write) / 1e6))
         f.write("| kernel | launches | read MB/launch | write MB/launch |\n|---|---:|---:|---:|\n")
         for r in rows[:45]:
             f.write("| `%s` | %d | %.2f | %.2f |\n" % (r[0][:110], r[1], r[2] / 1e6, r[3] / 1e6))
     with open(out_json, "w") as f:
-        json.dump({"dominant": {"kernel": "conv_igemm_glds_kernel<128|256,*,3,3,1,fwd>", "launches": n,
+        json.dump({"dominant": {"kernel": dom_name, "launches": n,
                                 "read_bytes_per_launch": round(dom_fetch), "write_bytes_per_launch": round(dom_write),
                                 "traffic_bytes_per_launch": round(dom_fetch + dom_write)},
                    "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; read = 2*FETCH_SIZE KB*1024, write = WRITE_SIZE KB*1024"},
@@ -68,4 +75,4 @@ def main(d, out_md, out_json, algo_json=None):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:5])
