@@ -52,6 +52,9 @@ __device__ __forceinline__ void wino_dma_b32(const void *base, const unsigned vo
 #else
 __device__ __forceinline__ void wino_dma_b32(const void *, const unsigned, float *, const int) {}
 #endif
+#ifndef SCDA_WINO_ABLATE
+#define SCDA_WINO_ABLATE 0     // timing ablations of conv_wino_kernel's K loop (scripts/ablate/wino_ablate.sh): 4 no barrier, 8 no patch DMA, 16 no LDS reads
+#endif
 #define WINO_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
 constexpr int WBK = WINO_BK;                    // channels per K-slab (8)
@@ -67,6 +70,8 @@ struct WinoGeom {
     int batch, C, H, W, M;
     int n_mt, n_mbg, n_slab, slabs_per_split;   // m-tiles of the launch (32 * MB rows each); 32-row blocks of the packed filters
     Div dNMT, dNPB, dNB, dNBX;   // m-tiles; pixel blocks of the launch; per image; per block row
+    int pixel_major, npb, per_xcd;   // XCD-aware order with the pixel block outermost (see the kernel); pixel blocks of the launch;
+                                     // (split, pixel block) items per XCD
 };
 
 struct WinoEpi {
@@ -94,8 +99,23 @@ __global__ __launch_bounds__(512, (MB == 2 ? 2 : 4)) void conv_wino_kernel(const
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int rest, mt, sp, pb, img, bi, by, bx;
-    g.dNMT.divmod((int)blockIdx.x, rest, mt);
-    g.dNPB.divmod(rest, sp, pb);
+    if (g.pixel_major) {
+        // workgroup b runs on XCD b % 8.  Inside an XCD's sequence the m-tile is fastest and a pixel block's m-tiles are consecutive:
+        // one XCD's L2 fetches a patch once for all of them (m-tile-major puts the m-tiles of a block on DIFFERENT XCDs: the input
+        // crosses the fabric n_mt times); the XCD then needs every m-tile's filters, which is why the launcher only picks this order
+        // when all 16 x M x C of them fit an L2.  An XCD owns a CONTIGUOUS run of (split, pixel block) items -- row neighbours run side
+        // by side on it and share the 128-byte lines their 136-byte patch rows straddle (the halo columns make every row touch three
+        // lines: dealt round-robin, neighbouring blocks landed on different XCDs and each fetched the shared lines itself).
+        const int x = (int)(blockIdx.x & 7), j = (int)(blockIdx.x >> 3);
+        int pl;
+        g.dNMT.divmod(j, pl, mt);
+        rest = x * g.per_xcd + pl;
+        if (pl >= g.per_xcd || rest >= g.npb * e.splits) return;
+        g.dNPB.divmod(rest, sp, pb);
+    } else {
+        g.dNMT.divmod((int)blockIdx.x, rest, mt);
+        g.dNPB.divmod(rest, sp, pb);
+    }
     g.dNB.divmod(pb, img, bi);
     g.dNBX.divmod(bi, by, bx);
     const int y0 = by * 8, x0 = bx * 32;
@@ -171,8 +191,12 @@ __global__ __launch_bounds__(512, (MB == 2 ? 2 : 4)) void conv_wino_kernel(const
             // everything this wave issued before the previous slab has landed -- its share of THIS slab's patch in particular (the
             // compiler is free to order a slab's DMA and U loads among themselves: count them all)
             WINO_WAIT_VMCNT(W_DMA + 2 * MB);
+#if !(SCDA_WINO_ABLATE & 4)
             __builtin_amdgcn_s_barrier();
+#endif
+#if !(SCDA_WINO_ABLATE & 8)
             issue_dma(min(s + 2, s_end - 1), (buf + 2) & (W_NST - 1));
+#endif
             load_a(min(s + 1, s_end - 1), Anext);
             __builtin_amdgcn_sched_barrier(0);   // keep the prefetch HERE: the scheduler sinks the loads to the end of the slab otherwise
             const float *st = lds + buf * W_STAGE;
@@ -181,6 +205,10 @@ __global__ __launch_bounds__(512, (MB == 2 ? 2 : 4)) void conv_wino_kernel(const
             auto read_raw = [&](const int kp, float (&R)[2][NR]) {
 #pragma unroll
                 for (int tb = 0; tb < 2; ++tb) {
+#if (SCDA_WINO_ABLATE & 16)
+                    for (int q = 0; q < NR; ++q) R[tb][q] = sgn;       // ablation: no LDS reads
+                    continue;
+#endif
                     const int o = 2 * kp * W_CS + tb * 4 * W_RS;
                     if (BSEL) {     // columns 1, 2
                         R[tb][0] = r1[o + 20]; R[tb][1] = r1[o + 1]; R[tb][2] = r2[o + 20]; R[tb][3] = r2[o + 1];
@@ -591,6 +619,13 @@ SCDA_API int scda_conv2d_wino_hip(const float *x, const float *u, const float *b
     g.n_mt = (M + 32 * MBv - 1) / (32 * MBv); g.n_slab = C / WBK;
     const int nbx = W / 32, nby = H / 8, npb = batch * nby * nbx;
     g.dNMT = Div(g.n_mt); g.dNPB = Div(npb); g.dNB = Div(nby * nbx); g.dNBX = Div(nbx);
+    // XCD order: pixel-block-major when every m-tile's filters fit one XCD's 4 MB L2 beside the patches (<= 3 MB: every layer below
+    // 512 x 512 channels), m-tile-major otherwise (SCDA_WINO_ORDER=m|p forces one: A/B, counter passes)
+    static const char *order_env = getenv("SCDA_WINO_ORDER");
+    g.npb = npb; g.per_xcd = 0;
+    // (... and only for launches of >= 32 pixel blocks per XCD: the runs leave up to 7 idle workgroups per m-tile, and a small
+    // launch -- the decoders' 64 blocks -- lost 13 % to the imbalance)
+    g.pixel_major = order_env ? (order_env[0] == 'p') : (g.n_mt > 1 && npb >= 256 && 16.0 * g.n_mbg * 32 * C * 4 <= 3.0e6);
     // split-K: a launch below one workgroup per CU splits the channel loop (>= 4 slabs per split), slabs in the natural pixel order
     const long long tiles = (long long)g.n_mt * npb;
     int splits = 1;
@@ -605,8 +640,13 @@ SCDA_API int scda_conv2d_wino_hip(const float *x, const float *u, const float *b
     // flops = the MFMA work the kernel EXECUTES (16 products per 2x2 tile and channel pair: the direct form's 36 / 2.25)
     prof_begin(for_dgrad ? PK_WINO_DGRAD : PK_WINO_FWD, 2.0 * M * (double)batch * H * W * C * 4, st,
                4.0 * ((double)batch * C * H * W + 9.0 * M * C + (double)batch * M * H * W));
-    if (MBv == 2) hipLaunchKernelGGL(conv_wino_kernel<2>, dim3((unsigned)(tiles * splits)), dim3(512), 0, st, u, x, g, e);
-    else hipLaunchKernelGGL(conv_wino_kernel<1>, dim3((unsigned)(tiles * splits)), dim3(512), 0, st, u, x, g, e);
+    long long wgs = tiles * splits;
+    if (g.pixel_major) {      // 8 runs of per_xcd (split, pixel block) items x n_mt m-tiles; the last run may hold idle workgroups
+        g.per_xcd = (int)(((long long)npb * splits + 7) / 8);
+        wgs = 8LL * g.per_xcd * g.n_mt;
+    }
+    if (MBv == 2) hipLaunchKernelGGL(conv_wino_kernel<2>, dim3((unsigned)wgs), dim3(512), 0, st, u, x, g, e);
+    else hipLaunchKernelGGL(conv_wino_kernel<1>, dim3((unsigned)wgs), dim3(512), 0, st, u, x, g, e);
     prof_end(st);
     int rc = launch_status("conv_wino_kernel");
     if (rc || splits == 1) return rc;
