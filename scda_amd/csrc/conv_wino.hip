@@ -352,6 +352,7 @@ struct WinoWgradGeom {
     int batch, C, H, W, M;
     int n_ct, TY, TX;            // input-channel tiles; tile rows per image (H / 2); slabs per tile row (W / 16)
     int n_slab, slabs_per_split; // slabs of the launch (batch * TY * TX)
+    int splits, splits_per_xcd;
     Div dNMT, dNCT, dTX, dTY;
 };
 
@@ -360,9 +361,20 @@ __global__ __launch_bounds__(512, 2) void conv_wino_wgrad_kernel(const float *__
     __shared__ __attribute__((aligned(16))) float lds[G_NST * G_STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // workgroup b runs on XCD b % 8: an XCD owns a contiguous run of K-splits and walks ALL (m-tile, c-tile) pairs of a split
+    // back to back -- they read the same pixels of dY and X (different channel blocks), so a split's slice of both tensors crosses
+    // the fabric once instead of once per tile pair
     int rest, mt, ct, sp;
-    g.dNMT.divmod((int)blockIdx.x, rest, mt);
-    g.dNCT.divmod(rest, sp, ct);
+    if (g.splits_per_xcd > 0) {
+        const int x = (int)(blockIdx.x & 7), j = (int)(blockIdx.x >> 3);
+        int sl;
+        g.dNMT.divmod(j, rest, mt);
+        g.dNCT.divmod(rest, sl, ct);
+        sp = x * g.splits_per_xcd + sl;
+    } else {      // fewer than 8 splits (512 x 512 channels: 64 tile pairs x 4): tile pairs across the XCDs, as they come
+        g.dNMT.divmod((int)blockIdx.x, rest, mt);
+        g.dNCT.divmod(rest, sp, ct);
+    }
     const int m0 = mt * 64, c0 = ct * 64;
     const int s_begin = sp * g.slabs_per_split, s_end = min(g.n_slab, s_begin + g.slabs_per_split);
     const int plane = g.H * g.W;
@@ -679,12 +691,15 @@ SCDA_API int scda_conv2d_wino_wgrad_hip(const float *dy, const float *x, float *
     int splits = (int)((256 + tiles - 1) / tiles);
     if (const char *f = getenv("SCDA_WINO_WGRAD_SPLITS")) splits = atoi(f);
     splits = std::max(1, std::min(std::min(splits, 1024), std::max(1, g.n_slab / 8)));
+    if (splits >= 8) splits = (splits + 7) / 8 * 8;      // whole runs per XCD (the last XCD's run would otherwise hold idle workgroups)
+    splits = std::min(splits, std::max(1, g.n_slab / 4));
     while (splits > 1 && (size_t)splits * slab_bytes + db_bytes > ws_bytes) --splits;
     g.slabs_per_split = (g.n_slab + splits - 1) / splits;
     splits = (g.n_slab + g.slabs_per_split - 1) / g.slabs_per_split;
     float *wsf = (float *)ws;
     float *db_ws = db ? wsf + (size_t)splits * Cout * Cin * 9 : nullptr;
     prof_begin(PK_WINO_WGRAD, 2.0 * Cout * (double)batch * H * W * Cin * 4, st);
+    g.splits = splits; g.splits_per_xcd = (splits % 8) == 0 ? splits / 8 : 0;
     hipLaunchKernelGGL(conv_wino_wgrad_kernel, dim3((unsigned)(tiles * splits)), dim3(512), 0, st, dy, x, g, wsf, db_ws);
     prof_end(st);
     int rc = launch_status("conv_wino_wgrad_kernel");
