@@ -16,6 +16,7 @@ import torch.nn as nn
 
 from scda_amd import autograd_ops as A
 from scda_amd import layers as L
+from scda_amd import native as N
 from scda_amd.autograd_ops import ACT_NONE, ACT_RELU
 from scda_amd.dropin.extensions._roi_align.modules.roi_align import RoIAlignAvg
 from scda_amd.dropin.extensions import RoIPool
@@ -224,16 +225,24 @@ class ResNet(FasterRCNN_AdEx):
         if not (self.with_mask and self.training) or input.get('ground_truth_masks') is None:
             return []
         from scda_amd.dropin.functions.mask import compute_mask_targets
+        masks = input['ground_truth_masks']
+        if torch.is_tensor(masks) and masks.is_cuda:
+            # the target generation (functions/mask.py:51-179) is host code, as in the reference: masks on the device would come back
+            # with a synchronous copy behind the whole compute-stream backlog, every iteration, in front of the early detector backward
+            raise ValueError("ground_truth_masks must stay on the host (pass the uint8 [1, G, H, W] tensor as the loader yields it)")
         rois, labels = compute_mask_targets(proposals, self.mask_target_cfg, input['ground_truth_bboxes'],
-                                            input['ground_truth_masks'], input['image_info'], input.get('ignore_regions'))
+                                            masks, input['image_info'], input.get('ignore_regions'))
         dev = feat.device
         if rois.shape[1] < 6:                        # the all-ignore placeholder row: no positive RoI in this image
             return [feat.new_zeros(())]
         cls = rois[:, 5].long()
         r = torch.arange(rois.shape[0])
-        own = labels[r, cls].reshape(rois.shape[0], -1).to(dev)            # [R, 28*28] in {0, 1}
-        logits = self.mask_predictor(feat, rois[:, :5].contiguous().to(dev))
-        sel = logits[r.to(dev), cls.to(dev)].reshape(rois.shape[0], -1)
+        # host -> device through pinned staging, non-blocking (a pageable .to(dev) is a synchronous copy on the compute stream)
+        own = N.upload(labels[r, cls].reshape(rois.shape[0], -1).contiguous(), dev)      # [R, 28*28] in {0, 1}
+        rois_dev = N.upload(rois[:, :5].contiguous(), dev)
+        cls_dev = N.upload(cls, dev)
+        logits = self.mask_predictor(feat, rois_dev)
+        sel = logits[torch.arange(rois.shape[0], device=dev), cls_dev].reshape(rois.shape[0], -1)
         self.last_mask_rois = int(rois.shape[0])
         return [A.adversarial_loss([(sel, own, None)], scale=1.0 / rois.shape[0])]
 
