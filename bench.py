@@ -68,6 +68,48 @@ DOMINANT_WINO = ("conv_wino_kernel<fwd>", "conv_wino_kernel<dgrad>")   # ONE ker
 WINO_RATIO = 2.25            # direct-convolution MACs per executed Winograd F(2x2,3x3) MAC
 
 
+def cpu_baseline_resnet(with_mask):
+    """BASELINE configs[3] / [4] on the host cores: the DETECTOR part of the iteration through the CPU oracle of that configuration
+    (oracle/resnet_ref.py: source forward with the four / five losses, target forward, backward) at 800 x 1344.  No CPU statement of
+    the SCDA nets exists on this configuration's rectangular maps inside one trainer, so the figure omits them: an UPPER bound of the
+    CPU rate (the SCDA nets are ~20 % of the VGG iteration's CPU time)."""
+    from oracle import resnet_ref as RR, torch_ref as R
+    from scda_amd import resnet_config as RC
+    from scda_amd.hostenv import cpu_quota
+    cores = os.cpu_count() or 1
+    quota = cpu_quota()
+    if quota:
+        cores = min(cores, quota)
+    torch.set_num_threads(cores)
+    R.use_cpu_backend()
+    try:
+        torch.manual_seed(0)
+        np.random.seed(0)
+        shared = dict(CFG["shared"], with_mask=with_mask)
+        det = RR.RefResNetDetector(shared).train()
+        src, tgt, gts, info = synth_batch(0, RC.H, RC.W)
+        x = {"cfg": CFG, "image": src, "image_info": info, "ground_truth_bboxes": gts, "ignore_regions": None, "cluster_num": 4,
+             "threshold": 128}
+        if with_mask:
+            x["ground_truth_masks"] = RC.synth_masks(gts, RC.H, RC.W)
+        times = []
+        for i in range(3):
+            t0 = time.time()
+            out = det(x, tgt)
+            sum(out["losses"]).backward()
+            det.zero_grad()
+            if i:
+                times.append(time.time() - t0)
+        dt = sum(times) / len(times)
+    finally:
+        R.reset_backend()
+        torch.set_num_threads(1)
+    return {"value": round(2.0 / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "2 timed detector passes after 1 warm-up (source forward + losses, target forward, backward; 800x1344) of "
+                      "oracle/resnet_ref.py RefResNetDetector%s -- the SCDA nets are not in it (upper bound of the CPU rate): %s s"
+                      % (" with the mask branch" if with_mask else "", ", ".join("%.2f" % t for t in times)), "s_per_iter": round(dt, 3)}
+
+
 def synth_batch(rank, H=H, W=W):
     """N(0,1) images clamped to [-1,1]; G integer-cornered gt boxes, log-uniform sizes, classes 1..8"""
     g = torch.Generator().manual_seed(1000 + rank)
@@ -361,8 +403,8 @@ def main():
                        "preconditioning_iterations": a.warmup + precond},
             "roofline": roof,
         }
-        if world == 1 and not a.no_cpu_baseline and a.config == "vgg16":
-            res["cpu_baseline"] = cpu_baseline()
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline() if a.config == "vgg16" else cpu_baseline_resnet(a.config == "maskrcnn")
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

@@ -18,6 +18,6 @@ for coll in ([bool(int(sys.argv[1]))] if len(sys.argv) > 1 else (False, True)): 
     for _ in range(30): tr.step(src, gts, info, tgt)
     torch.cuda.synchronize()
     print("collectives=%-5s AB_STREAMS=%s SIDE=%s GRAPH=%s GPU_MAX_HW_QUEUES=%s: %.2f ms / iteration" % (coll, os.environ.get("SCDA_AB_STREAMS", "1"),
-          os.environ.get("SCDA_SIDE_STREAM", "1"), os.environ.get("SCDA_GAN_GRAPH", "1"), os.environ.get("GPU_MAX_HW_QUEUES", "default"), (time.perf_counter() - t0) / 30 * 1e3), flush=True)
+          os.environ.get("SCDA_SIDE_STREAM", "1"), "on" if tr._gan_graph_ok() else "off", os.environ.get("GPU_MAX_HW_QUEUES", "default"), (time.perf_counter() - t0) / 30 * 1e3), flush=True)
     del tr
 dist.destroy_process_group()
