@@ -642,7 +642,7 @@ SCDA_API int scda_conv2d_wino_hip(const float *x, const float *u, const float *b
     const long long tiles = (long long)g.n_mt * npb;
     int splits = 1;
     if (const char *f = getenv("SCDA_WINO_SPLITS")) splits = atoi(f);
-    else if (tiles < 200 * (3 - MBv)) splits = (int)std::min<long long>((256 * (3 - MBv) + tiles / 2) / tiles, g.n_slab / 4 > 0 ? g.n_slab / 4 : 1);
+    else if (tiles < 200) splits = (int)std::min<long long>((256 * (3 - MBv) + tiles / 2) / tiles, g.n_slab / 4 > 0 ? g.n_slab / 4 : 1);   // two 32-row workgroups per CU: conv5_x 65 -> 61 us   // (32-row tiles at one per CU: the decoders' 256-tile launches run 10 % faster unsplit, and without a reduce launch)
     if (splits < 1) splits = 1;
     while (splits > 1 && (size_t)splits * M * batch * H * W * sizeof(float) > ws_bytes) --splits;
     g.slabs_per_split = (g.n_slab + splits - 1) / splits;
