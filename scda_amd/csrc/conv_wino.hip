@@ -53,7 +53,7 @@ __device__ __forceinline__ void wino_dma_b32(const void *base, const unsigned vo
 __device__ __forceinline__ void wino_dma_b32(const void *, const unsigned, float *, const int) {}
 #endif
 #ifndef SCDA_WINO_ABLATE
-#define SCDA_WINO_ABLATE 0     // timing ablations of conv_wino_kernel's K loop (scripts/ablate/wino_ablate.sh): 4 no barrier, 8 no patch DMA, 16 no LDS reads
+#define SCDA_WINO_ABLATE 0     // timing ablations of conv_wino_kernel's K loop (scripts/ablate/wino_ablate.sh): 4 no barrier, 8 no patch DMA, 16 no LDS reads; weight gradient: 128 / 64 / 32
 #endif
 #define WINO_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
@@ -461,8 +461,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino_wgrad_kernel(const float *__
         int buf = 0;
         auto slab = [&]() {
             WINO_WAIT_VMCNT(G_DMA);      // this wave's share of THIS slab's patches has landed (only the previous slab's issue is younger)
+#if !(SCDA_WINO_ABLATE & 128)
             __builtin_amdgcn_s_barrier();
+#endif
+#if !(SCDA_WINO_ABLATE & 64)
             issue_dma((buf + 2) & (G_NST - 1));
+#endif
             __builtin_amdgcn_sched_barrier(0);
             const float *st = lds + buf * G_STAGE;
             // raw values stay in the 8-byte pairs they are read as; the transforms are written on the pairs (packed fp32 math on
@@ -470,6 +474,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino_wgrad_kernel(const float *__
             wino_f2 ry[2][2][2], rx[2][2][4];     // [register buffer][block][pair]
             auto read_raw = [&](const int kp, wino_f2 (&Y)[2][2], wino_f2 (&R)[2][4]) {
                 // 8-byte reads at immediate offsets from three lane addresses (every offset below is a multiple of 2 floats)
+#if (SCDA_WINO_ABLATE & 32)
+                for (int mb = 0; mb < 2; ++mb) { Y[mb][0] = wino_f2{sgn, ya}; Y[mb][1] = wino_f2{ya, sgn}; }
+                for (int cb = 0; cb < 2; ++cb) for (int q = 0; q < 4; ++q) R[cb][q] = wino_f2{sgn, yb2};
+                return;
+#endif
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb) {
                     const float *p = st + yo + mb * (32 * G_YS) + 4 * kp;
