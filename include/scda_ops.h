@@ -248,7 +248,8 @@ int scda_conv2d_wgrad_bias_hip(const float *dy, const float *x, float *dw, float
  * operations than the implicit GEMM above, fp32 throughout (results differ from the direct form by rounding only: the transforms
  * use the exact constants 0, +-1, +-1/2).  What cuDNN picks for the same nn.Conv2d layers of the reference
  * (vgg_adver_expansion_cluster.py:101-114, head.py:13, common_net.py:59-80).
- *   scda_conv2d_wino_supported: C % 8 == 0, H % 8 == 0, W % 32 == 0, per-image tensors below 2 GB
+ *   scda_conv2d_wino_supported: C % 8 == 0, H and W even (8 x 32-pixel blocks, partial on the right / bottom edge), per-image
+ *       tensors below 2 GB
  *   u = scda_conv2d_wino_pack_hip(w [Cout,Cin,3,3], for_dgrad): the transformed filters G g G^T in the kernel's MFMA fragment
  *       order, scda_conv2d_wino_packed_elems floats; for_dgrad = 1: the data gradient's filters (rows = Cin, rotated by 180 degrees)
  *   scda_conv2d_wino_hip: y [batch,M,H,W] = act(conv3x3(x [batch,C,H,W]) + bias), optionally * act'(mask_src) as
@@ -262,7 +263,7 @@ int scda_conv2d_wino_hip(const float *x, const float *u, const float *bias, floa
 
 /* ... and the weight gradient in the same (transposed) algorithm: dw [Cout,Cin,3,3] (+)= G^T [ sum over 2x2 tiles (A dy A^T) .*
  * (B^T x B) ] G, db [Cout] (+)= sum of dy (fused, may be NULL); deterministic split-K like scda_conv2d_wgrad_hip.
- * scda_conv2d_wino_wgrad_supported: >= 64 channels on both sides, H % 2 == 0, W % 16 == 0. */
+ * scda_conv2d_wino_wgrad_supported: >= 64 channels on both sides, H and W even (K-slabs of 2 x 16 pixels, partial at the right edge). */
 int scda_conv2d_wino_wgrad_supported(int batch, int Cin, int H, int W, int Cout);
 int scda_conv2d_wino_wgrad_hip(const float *dy, const float *x, float *dw, float *db, int batch, int Cin, int H, int W, int Cout,
                                int accumulate, int db_accumulate, void *ws, size_t ws_bytes, void *stream);

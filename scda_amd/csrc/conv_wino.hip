@@ -302,8 +302,8 @@ __global__ __launch_bounds__(512, (MB == 2 ? 2 : 4)) void conv_wino_kernel(const
                 y00 = t0[0] + t0[1] + t0[2]; y01 = t1[0] + t1[1] + t1[2];
                 y10 = t0[1] - t0[2] - t0[3]; y11 = t1[1] - t1[2] - t1[3];
             }
-            if (m >= g.M) continue;
             const int oy = y0 + 2 * (t >> 4), ox = x0 + 2 * (t & 15);
+            if (m >= g.M || oy >= g.H || ox >= g.W) continue;      // (H, W even: a tile is inside the image or outside, never across)
             const size_t pix = (size_t)oy * g.W + ox;
             if (e.splits > 1) {
                 float *o = e.ws + ((size_t)sp * g.M + m) * N + (size_t)img * plane + pix;
@@ -384,19 +384,25 @@ __global__ __launch_bounds__(512, 2) void conv_wino_wgrad_kernel(const float *__
     //   e = row * 18 + col (e >= 72: padding)                                            r >= 108: unused tail of the stage
     unsigned dma_off[G_DMA];
     unsigned long long xbits = 0;     // 4 bits per instruction: the lane's element is in patch row 0 / row 3 / column 0 / column 17
+    unsigned pbits = 0;               // 1 bit per instruction: the lane's element lies beyond the image in a row's PARTIAL last slab
+    const int rem = g.W & 15;         // (W % 16 != 0: that slab holds rem / 2 real tiles; the others see zeros on both operands)
 #pragma unroll
     for (int i = 0; i < G_DMA; ++i) {
         const int r = wave * G_DMA + i;
         unsigned off = 0x80000000u;
         if (r < G_YR) {
             const int slot = r * 64 + lane, ch = slot / G_YS, e = slot - ch * G_YS;
-            if (e < 32 && m0 + ch < g.M) off = (unsigned)((ch * plane + (e >> 4) * g.W + (e & 15)) * 4);
+            if (e < 32 && m0 + ch < g.M) {
+                off = (unsigned)((ch * plane + (e >> 4) * g.W + (e & 15)) * 4);
+                pbits |= (unsigned)((e & 15) >= rem) << i;
+            }
         } else if (r < G_YR + G_XR) {
             const int slot = (r - G_YR) * 64 + lane, ch = slot / G_XS, e = slot - ch * G_XS;
             const int row = e / 18, col = e - row * 18;
             if (e < 72 && c0 + ch < g.C) {
                 off = (unsigned)((ch * plane + row * g.W + col) * 4);     // relative to (y0 - 1, x0 - 1): the base is moved back
                 xbits |= (unsigned long long)((row == 0) | ((row == 3) << 1) | ((col == 0) << 2) | ((col == 17) << 3)) << (4 * i);
+                pbits |= (unsigned)(col - 1 >= rem) << i;
             }
         }
         dma_off[i] = off;
@@ -415,13 +421,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino_wgrad_kernel(const float *__
         const int soff = (2 * q_ty * g.W + 16 * q_tx) * 4;
         const unsigned edge = (unsigned)(q_ty == 0) | ((unsigned)(q_ty == g.TY - 1) << 1) | ((unsigned)(q_tx == 0) << 2) | ((unsigned)(q_tx == g.TX - 1) << 3);
         float *dst = lds + buf * G_STAGE + wave * (G_DMA * 64);
-        if (edge == 0) {     // interior slab (most): the lane offsets as they are
+        const bool part = rem != 0 && q_tx == g.TX - 1;
+        if (edge == 0 && !part) {     // interior slab (most): the lane offsets as they are
 #pragma unroll
             for (int i = 0; i < G_DMA; ++i) wino_dma_b32(wave * G_DMA + i < G_YR ? yb : xb, dma_off[i], dst + i * 64, soff);
         } else {
+            const unsigned pm = part ? pbits : 0u;
 #pragma unroll
             for (int i = 0; i < G_DMA; ++i) {
-                const unsigned off = ((unsigned)(xbits >> (4 * i)) & edge) ? 0x80000000u : dma_off[i];
+                const unsigned off = (((unsigned)(xbits >> (4 * i)) & edge) | ((pm >> i) & 1u)) ? 0x80000000u : dma_off[i];
                 wino_dma_b32(wave * G_DMA + i < G_YR ? yb : xb, off, dst + i * 64, soff);
             }
         }
@@ -600,7 +608,7 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float *__restrict_
 using namespace scda;
 
 SCDA_API int scda_conv2d_wino_supported(int batch, int C, int H, int W, int M) {
-    return batch > 0 && M > 0 && C >= WBK && (C % WBK) == 0 && (H % 8) == 0 && (W % 32) == 0 && (long long)C * H * W * 4 < (1LL << 31) &&
+    return batch > 0 && M > 0 && C >= WBK && (C % WBK) == 0 && (H % 2) == 0 && (W % 2) == 0 && (long long)C * H * W * 4 < (1LL << 31) &&
            (long long)M * H * W * 4 < (1LL << 31);
 }
 
@@ -621,7 +629,7 @@ SCDA_API int scda_conv2d_wino_hip(const float *x, const float *u, const float *b
                                   void *stream) {
     if (!x || !u || !y) { set_error("scda_conv2d_wino_hip: bad arguments"); return SCDA_EINVAL; }
     if (!scda_conv2d_wino_supported(batch, C, H, W, M)) {
-        set_error("scda_conv2d_wino_hip: needs C %% 8 == 0, H %% 8 == 0, W %% 32 == 0 and tensors below 2 GB per image (C=%d H=%d W=%d)", C, H, W);
+        set_error("scda_conv2d_wino_hip: needs C %% 8 == 0, even H and W and tensors below 2 GB per image (C=%d H=%d W=%d)", C, H, W);
         return SCDA_EINVAL;
     }
     hipStream_t st = as_stream(stream);
@@ -634,11 +642,11 @@ SCDA_API int scda_conv2d_wino_hip(const float *x, const float *u, const float *b
     static const int force_mb = getenv("SCDA_WINO_MB") ? atoi(getenv("SCDA_WINO_MB")) : 0;
     // ... and for launches that would not fill the chip with 64-row tiles (the decoders' batch-4 residual convolutions: 128 tiles;
     // conv5_x / the RPN: 64): twice the workgroups first, split-K (slabs + a reduce launch) only for what is still missing
-    const long long tiles64 = (long long)((M + 63) / 64) * batch * (H / 8) * (W / 32);
+    const long long tiles64 = (long long)((M + 63) / 64) * batch * ((H + 7) / 8) * ((W + 31) / 32);
     const int MBv = force_mb == 1 || force_mb == 2 ? force_mb : ((M <= 32 || tiles64 < 200) ? 1 : 2);
     g.n_mbg = (M + 63) / 64 * 2;
     g.n_mt = (M + 32 * MBv - 1) / (32 * MBv); g.n_slab = C / WBK;
-    const int nbx = W / 32, nby = H / 8, npb = batch * nby * nbx;
+    const int nbx = (W + 31) / 32, nby = (H + 7) / 8, npb = batch * nby * nbx;   // blocks on the right / bottom edge may be partial
     g.dNMT = Div(g.n_mt); g.dNPB = Div(npb); g.dNB = Div(nby * nbx); g.dNBX = Div(nbx);
     // XCD order: pixel-block-major when every m-tile's filters fit one XCD's 4 MB L2 beside the patches (<= 3 MB: every layer below
     // 512 x 512 channels), m-tile-major otherwise (SCDA_WINO_ORDER=m|p forces one: A/B, counter passes)
@@ -675,7 +683,7 @@ SCDA_API int scda_conv2d_wino_hip(const float *x, const float *u, const float *b
 }
 
 SCDA_API int scda_conv2d_wino_wgrad_supported(int batch, int Cin, int H, int W, int Cout) {
-    return batch > 0 && Cin >= 64 && Cout >= 64 && (H % 2) == 0 && (W % 16) == 0 && 64LL * H * W * 4 < (1LL << 31);
+    return batch > 0 && Cin >= 64 && Cout >= 64 && (H % 2) == 0 && (W % 2) == 0 && 64LL * H * W * 4 < (1LL << 31);
 }
 
 // dw [Cout,Cin,3,3] (+)= weight gradient of the stride-1, pad-1 3x3 convolution; db [Cout] (+)= bias gradient (may be NULL)
@@ -683,14 +691,14 @@ SCDA_API int scda_conv2d_wino_wgrad_hip(const float *dy, const float *x, float *
                                         int accumulate, int db_accumulate, void *ws, size_t ws_bytes, void *stream) {
     if (!dy || !x || !dw || !ws) { set_error("scda_conv2d_wino_wgrad_hip: bad arguments"); return SCDA_EINVAL; }
     if (!scda_conv2d_wino_wgrad_supported(batch, Cin, H, W, Cout)) {
-        set_error("scda_conv2d_wino_wgrad_hip: needs >= 64 channels on both sides, H %% 2 == 0, W %% 16 == 0 (Cin=%d Cout=%d H=%d W=%d)", Cin, Cout, H, W);
+        set_error("scda_conv2d_wino_wgrad_hip: needs >= 64 channels on both sides and even H, W (Cin=%d Cout=%d H=%d W=%d)", Cin, Cout, H, W);
         return SCDA_EINVAL;
     }
     hipStream_t st = as_stream(stream);
     WinoWgradGeom g;
     g.batch = batch; g.C = Cin; g.H = H; g.W = W; g.M = Cout;
     const int n_mt = (Cout + 63) / 64;
-    g.n_ct = (Cin + 63) / 64; g.TY = H / 2; g.TX = W / 16;
+    g.n_ct = (Cin + 63) / 64; g.TY = H / 2; g.TX = (W + 15) / 16;
     g.n_slab = batch * g.TY * g.TX;
     g.dNMT = Div(n_mt); g.dNCT = Div(g.n_ct); g.dTX = Div(g.TX); g.dTY = Div(g.TY);
     const long long tiles = (long long)n_mt * g.n_ct;

@@ -28,6 +28,9 @@ WINO_CASES = [
     (1, 512, 32, 64, 512),    # conv5_x / RPN: split-K 4
     (4, 128, 64, 64, 128),    # the decoders' residual convolutions
     (1, 256, 128, 256, 256),  # conv3_2 at full size
+    (1, 64, 6, 20, 64),       # one PARTIAL block: 6 of 8 rows, 20 of 32 columns
+    (2, 128, 50, 84, 128),    # ResNet layer3's 50 x 84 maps: partial blocks on the right and bottom edges, batch 2
+    (1, 32, 100, 168, 72),    # layer2's 100 x 168
 ]
 
 
@@ -90,7 +93,7 @@ def test_wino_routes_through_conv2d_entry_points(cuda, monkeypatch):
     assert not native.wino_ok(1, 16, 32, 64, 64, 3, 3, 1, 1) and not native.wino_ok(1, 64, 32, 64, 16, 3, 3, 1, 1)
     assert not native.wino_ok(1, 128, 32, 64, 128, 3, 3, 2, 1)
     assert not native.wino_ok(1, 128, 32, 64, 128, 3, 3, 1, 1, row_period=8)
-    assert not native.wino_ok(1, 128, 30, 64, 128, 3, 3, 1, 1)
+    assert native.wino_ok(1, 128, 30, 64, 128, 3, 3, 1, 1) and not native.wino_ok(1, 128, 31, 64, 128, 3, 3, 1, 1)      # any EVEN height / width
 
 
 WGRAD_CASES = [
@@ -102,6 +105,9 @@ WGRAD_CASES = [
     (1, 72, 4, 16, 64),        # ragged Cin
     (4, 128, 64, 64, 128),     # the decoders' residual convolutions
     (1, 256, 64, 128, 512),    # conv4_1
+    (1, 64, 4, 6, 64),         # a single PARTIAL slab: 3 real tiles of 8
+    (2, 128, 50, 84, 128),     # ResNet layer3's 50 x 84: 5 slabs + a partial one (4 pixels) per tile row
+    (1, 64, 100, 168, 128),    # layer2's 100 x 168: partial slab of 8 pixels
 ]
 
 
@@ -139,4 +145,4 @@ def test_wino_wgrad_routes_through_conv2d_entry_points(cuda):
     assert native.prof_collect()["conv_wino_wgrad_kernel"][0] == 2
     assert torch.equal(dw, dw1)
     assert not native.wino_wgrad_ok(1, 32, 32, 64, 64, 3, 3, 1, 1) and not native.wino_wgrad_ok(1, 64, 32, 64, 64, 3, 3, 2, 1)
-    assert not native.wino_wgrad_ok(1, 64, 32, 72, 64, 3, 3, 1, 1)
+    assert native.wino_wgrad_ok(1, 64, 32, 72, 64, 3, 3, 1, 1) and not native.wino_wgrad_ok(1, 64, 32, 71, 64, 3, 3, 1, 1)
