@@ -261,6 +261,11 @@ int scda_conv2d_wino_pack_hip(const float *w, float *out, int Cout, int Cin, int
 int scda_conv2d_wino_hip(const float *x, const float *u, const float *bias, float *y, int batch, int C, int H, int W, int M, int act,
                          float slope, const float *mask_src, float mask_slope, int for_dgrad, void *ws, size_t ws_bytes, void *stream);
 
+/* conv3x3 + bias + activation + nn.MaxPool2d(2, 2) in ONE launch (a Winograd tile is a pooling window): pool_y [batch,M,H/2,W/2] and
+ * pool_idx (uint8 winner 0..3, scda_maxpool2x2_fwd_hip's convention: the backward is scda_maxpool2x2_bwd[_relu]_hip as usual); the
+ * full-resolution map is never written.  The pools of vgg_adver_expansion_cluster.py:101-114 behind conv1_2 / 2_2 / 3_3 / 4_3. */
+int scda_conv2d_wino_pool_hip(const float *x, const float *u, const float *bias, float *pool_y, unsigned char *pool_idx, int batch, int C,
+                              int H, int W, int M, int act, float slope, void *stream);
 /* ... and the weight gradient in the same (transposed) algorithm: dw [Cout,Cin,3,3] (+)= G^T [ sum over 2x2 tiles (A dy A^T) .*
  * (B^T x B) ] G, db [Cout] (+)= sum of dy (fused, may be NULL); deterministic split-K like scda_conv2d_wgrad_hip.
  * scda_conv2d_wino_wgrad_supported: >= 64 channels on both sides, H and W even (K-slabs of 2 x 16 pixels, partial at the right edge). */

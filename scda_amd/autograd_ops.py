@@ -97,6 +97,54 @@ class Conv2dFn(Function):
         return dx, dw, db, None, None, None, None, None, None
 
 
+class ConvPoolFn(Function):
+    """conv3x3 (+bias) + ReLU + MaxPool2d(2, 2) as ONE launch (scda_conv2d_wino_pool_hip: a Winograd tile is a pooling window); the
+    full-resolution map between them is never written.  Backward: the pool's scatter with the ReLU gradient applied through the pooled
+    value (a window's winner is > 0 exactly when its maximum is), then the convolution's usual data / weight / bias gradients.  Same
+    values, winners and gradients as Conv2dFn -> MaxPool2x2Fn on the fusion plan's deferred-ReLU path, bit for bit."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, slope, in_act):
+        x = _c(x)
+        if isinstance(w, torch.nn.Parameter):
+            w._scda_wino_used = True
+        y, idx = N.conv2d_wino_pool(x, N.conv2d_wino_pack(w, False), b, w.shape[0], ACT_RELU, slope)
+        ctx.in_act = in_act
+        ctx.has_bias = b is not None
+        ctx.bias_ref, ctx.w_ref = b, w
+        ctx.save_for_backward(x, w, idx, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, idx, y = ctx.saved_tensors
+        in_act = ctx.in_act
+        dyc = N.maxpool2x2_bwd(_c(dy), idx, (x.shape[0], w.shape[0], x.shape[2], x.shape[3]), relu_y=y)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            if in_act is not None:
+                dx = N.conv2d_dgrad(dyc, w, x.shape, 1, 1, act_src=x, act_slope=0.0 if in_act[0] == ACT_RELU else in_act[1])
+            else:
+                dx = N.conv2d_dgrad(dyc, w, x.shape, 1, 1)
+        want_w, want_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        if want_w and want_b:
+            sw, sb = _sink(ctx.w_ref), _sink(ctx.bias_ref)
+            dw, db = N.conv2d_wgrad_bias(dyc, x, w.shape, 1, 1, out=sw, db_out=sb)
+            dw = None if sw is not None else dw
+            db = None if sb is not None else db
+        elif want_w:
+            sink = _sink(ctx.w_ref)
+            dw = N.conv2d_wgrad(dyc, x, w.shape, 1, 1, out=sink)
+            if sink is not None:
+                dw = None
+        elif want_b:
+            sink = _sink(ctx.bias_ref)
+            db = N.bias_grad_nchw(dyc, out=sink)
+            if sink is not None:
+                db = None
+        return dx, dw, db, None, None
+
+
 class LinearFn(Function):
     @staticmethod
     def forward(ctx, x, w, b, act, defer=False):

@@ -83,6 +83,8 @@ struct WinoEpi {
     const float *mask_src;
     float mask_slope;
     int dbg;   // ablation knob (SCDA_WINO_DBG): 1 = no epilogue, 2 = no K loop
+    float *pool_y;          // non-null: FUSED 2x2 max-pool -- the tile's four outputs are one pooling window; only the pooled value
+    unsigned char *pool_idx;   // [batch, M, H/2, W/2] and the winner 0..3 are stored (scda_maxpool2x2_fwd_hip's conventions), not the map
 };
 
 typedef float wino_f4 __attribute__((ext_vector_type(4)));
@@ -315,6 +317,17 @@ __global__ __launch_bounds__(512, (MB == 2 ? 2 : 4)) void conv_wino_kernel(const
             if (e.bias) { const float bv = e.bias[m]; y00 += bv; y01 += bv; y10 += bv; y11 += bv; }
             y00 = apply_act(y00, e.act, e.slope); y01 = apply_act(y01, e.act, e.slope);
             y10 = apply_act(y10, e.act, e.slope); y11 = apply_act(y11, e.act, e.slope);
+            if (e.pool_y) {      // the window's winner: first maximum in (0,0) (0,1) (1,0) (1,1) order, NaN wins (maxpool2_fwd_kernel)
+                float mv = y00;
+                int kk = 0;
+                if (y01 > mv || y01 != y01) { mv = y01; kk = 1; }
+                if (y10 > mv || y10 != y10) { mv = y10; kk = 2; }
+                if (y11 > mv || y11 != y11) { mv = y11; kk = 3; }
+                const size_t po = ((size_t)img * g.M + m) * (size_t)(plane >> 2) + (size_t)(oy >> 1) * (g.W >> 1) + (ox >> 1);
+                e.pool_y[po] = mv;
+                e.pool_idx[po] = (unsigned char)kk;
+                continue;
+            }
             if (e.mask_src) {
                 const wino_f2 k0 = *reinterpret_cast<const wino_f2 *>(e.mask_src + o), k1 = *reinterpret_cast<const wino_f2 *>(e.mask_src + o + g.W);
                 y00 = k0[0] > 0.f ? y00 : y00 * e.mask_slope; y01 = k0[1] > 0.f ? y01 : y01 * e.mask_slope;
@@ -624,10 +637,10 @@ SCDA_API int scda_conv2d_wino_pack_hip(const float *w, float *out, int Cout, int
 }
 
 // y [batch, M, H, W] = act(conv3x3(x [batch, C, H, W], stride 1, pad 1) + bias) (* act'(mask_src)); u = scda_conv2d_wino_pack_hip
-SCDA_API int scda_conv2d_wino_hip(const float *x, const float *u, const float *bias, float *y, int batch, int C, int H, int W, int M,
-                                  int act, float slope, const float *mask_src, float mask_slope, int for_dgrad, void *ws, size_t ws_bytes,
-                                  void *stream) {
-    if (!x || !u || !y) { set_error("scda_conv2d_wino_hip: bad arguments"); return SCDA_EINVAL; }
+static int wino_launch(const float *x, const float *u, const float *bias, float *y, int batch, int C, int H, int W, int M, int act,
+                       float slope, const float *mask_src, float mask_slope, int for_dgrad, void *ws, size_t ws_bytes, void *stream,
+                       float *pool_y, unsigned char *pool_idx) {
+    if (!x || !u || (!y && !pool_y)) { set_error("scda_conv2d_wino_hip: bad arguments"); return SCDA_EINVAL; }
     if (!scda_conv2d_wino_supported(batch, C, H, W, M)) {
         set_error("scda_conv2d_wino_hip: needs C %% 8 == 0, even H and W and tensors below 2 GB per image (C=%d H=%d W=%d)", C, H, W);
         return SCDA_EINVAL;
@@ -662,10 +675,11 @@ SCDA_API int scda_conv2d_wino_hip(const float *x, const float *u, const float *b
     else if (tiles < 200) splits = (int)std::min<long long>((256 * (3 - MBv) + tiles / 2) / tiles, g.n_slab / 4 > 0 ? g.n_slab / 4 : 1);   // two 32-row workgroups per CU: conv5_x 65 -> 61 us   // (32-row tiles at one per CU: the decoders' 256-tile launches run 10 % faster unsplit, and without a reduce launch)
     if (splits < 1) splits = 1;
     while (splits > 1 && (size_t)splits * M * batch * H * W * sizeof(float) > ws_bytes) --splits;
+    if (pool_y) splits = 1;      // (the fused pool needs finished values in the epilogue; its callers are the 256+-tile VGG layers)
     g.slabs_per_split = (g.n_slab + splits - 1) / splits;
     splits = (g.n_slab + g.slabs_per_split - 1) / g.slabs_per_split;
     static const int dbg = getenv("SCDA_WINO_DBG") ? atoi(getenv("SCDA_WINO_DBG")) : 0;
-    WinoEpi e{y, (float *)ws, bias, act, slope, splits, mask_src, mask_slope, dbg};
+    WinoEpi e{y, (float *)ws, bias, act, slope, splits, mask_src, mask_slope, dbg, pool_y, pool_idx};
     // flops = the MFMA work the kernel EXECUTES (16 products per 2x2 tile and channel pair: the direct form's 36 / 2.25)
     prof_begin(for_dgrad ? PK_WINO_DGRAD : PK_WINO_FWD, 2.0 * M * (double)batch * H * W * C * 4, st,
                4.0 * ((double)batch * C * H * W + 9.0 * M * C + (double)batch * M * H * W));
@@ -722,4 +736,19 @@ SCDA_API int scda_conv2d_wino_wgrad_hip(const float *dy, const float *x, float *
     int rc = launch_status("conv_wino_wgrad_kernel");
     if (rc) return rc;
     return launch_wgrad_reduce(wsf, splits, (long long)Cout * Cin * 9, Cin * 9, accumulate, dw, db_ws, db, Cout, db_accumulate, st);
+}
+
+SCDA_API int scda_conv2d_wino_hip(const float *x, const float *u, const float *bias, float *y, int batch, int C, int H, int W, int M,
+                                  int act, float slope, const float *mask_src, float mask_slope, int for_dgrad, void *ws, size_t ws_bytes,
+                                  void *stream) {
+    return wino_launch(x, u, bias, y, batch, C, H, W, M, act, slope, mask_src, mask_slope, for_dgrad, ws, ws_bytes, stream, nullptr, nullptr);
+}
+
+// conv3x3 + bias + activation + 2x2/2 max-pool in one launch: pool_y [batch, M, H/2, W/2] and pool_idx (uint8, winner 0..3 as
+// scda_maxpool2x2_fwd_hip writes it) -- the full-resolution map is never written (vgg_adver_expansion_cluster.py:101-114: the pools
+// behind conv1_2 / conv2_2 / conv3_3 / conv4_3).  A Winograd tile IS a pooling window.
+SCDA_API int scda_conv2d_wino_pool_hip(const float *x, const float *u, const float *bias, float *pool_y, unsigned char *pool_idx, int batch,
+                                       int C, int H, int W, int M, int act, float slope, void *stream) {
+    if (!pool_y || !pool_idx) { set_error("scda_conv2d_wino_pool_hip: bad arguments"); return SCDA_EINVAL; }
+    return wino_launch(x, u, bias, nullptr, batch, C, H, W, M, act, slope, nullptr, 0.f, 0, nullptr, 0, stream, pool_y, pool_idx);
 }

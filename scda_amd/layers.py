@@ -30,8 +30,18 @@ class Conv2d(nn.Conv2d):
         # > 0: the input is a vertical stack of independent maps of that many rows (the channel-major RoI-head layout
         # [1, C, R*7, 7] of the ResNet-C4 detector); set per call by the owner (dropin/models/mask_rcnn/resnet.py)
         self.row_period = 0
+        # fusion plan: a MaxPool2x2 consumes this conv's ReLU output (plan_act_fusion): the pool can run in this conv's epilogue
+        self.pool_next = False
 
     def forward(self, x):
+        if self.pool_next and A.replay is None and self.fused_act == A.ACT_RELU and self.defer_act_bwd:
+            B, Cin, IH, IW = x.shape
+            if x.is_cuda and N.conv_pool_fusable(B, Cin, IH, IW, self.out_channels, self.kernel_size[0], self.kernel_size[1],
+                                                 self.stride[0], self.padding[0], self.row_period):
+                # conv + ReLU + the 2x2 max-pool behind it in one launch; the pool module recognises the pooled tensor and passes it on
+                y = A.ConvPoolFn.apply(x, self.weight, self.bias, self.slope, self.input_act)
+                y._scda_pooled = True
+                return y
         return A.conv2d(x, self.weight, self.bias, self.stride[0], self.padding[0], self.fused_act, self.slope,
                         (self.input_act, self.defer_act_bwd), self.row_period)
 
@@ -99,6 +109,8 @@ class MaxPool2x2(nn.Module):
     relu_input = False             # fusion plan: this pool's backward also applies the ReLU gradient of the conv in front of it
 
     def forward(self, x):
+        if getattr(x, "_scda_pooled", False):     # the producing conv already pooled (layers.Conv2d.forward / A.ConvPoolFn)
+            return x
         return A.MaxPool2x2Fn.apply(x, self.relu_input)
 
     def extra_repr(self):
@@ -179,6 +191,7 @@ def plan_act_fusion(*sequentials):
                 a.defer_act_bwd, b.input_act = True, (a.fused_act, a.slope)
             elif isinstance(a, Conv2d) and a.fused_act == A.ACT_RELU and isinstance(b, MaxPool2x2):
                 a.defer_act_bwd, b.relu_input = True, True
+                a.pool_next = True
             elif isinstance(a, Linear) and a.fused_act == A.ACT_RELU and isinstance(b, Dropout):
                 a.defer_act_bwd, b.relu_input = True, True
             else:

@@ -432,6 +432,24 @@ def conv2d_wino(x, u, bias, M, act=ACT_NONE, slope=0.01, mask_src=None, mask_slo
     return y
 
 
+def conv_pool_fusable(B, Cin, IH, IW, Cout, KH, KW, stride, pad, row_period=0):
+    """conv3x3 + activation + 2x2 max-pool can run as one Winograd launch: an eligible layer on an even map with enough tiles to fill the
+    chip without split-K (the fused epilogue needs finished values).  SCDA_CONV_POOL_FUSE=0 keeps the pool a launch of its own."""
+    if os.environ.get("SCDA_CONV_POOL_FUSE", "1") == "0" or not wino_ok(B, Cin, IH, IW, Cout, KH, KW, stride, pad, row_period):
+        return False
+    return ((Cout + 63) // 64) * B * ((IH + 7) // 8) * ((IW + 31) // 32) >= 200
+
+
+def conv2d_wino_pool(x, u, bias, M, act=ACT_NONE, slope=0.01):
+    """-> (pooled [B, M, H/2, W/2], winner uint8 [B, M, H/2, W/2]) of maxpool2x2(act(conv3x3(x) + bias)), one launch"""
+    B, C, H, W = x.shape
+    y = torch.empty(B, M, H // 2, W // 2, dtype=torch.float32, device=x.device)
+    idx = torch.empty(B, M, H // 2, W // 2, dtype=torch.uint8, device=x.device)
+    _check(lib().scda_conv2d_wino_pool_hip(_p(x), _p(u), _p(bias), _p(y), _p(idx), i32(B), i32(C), i32(H), i32(W), i32(M), i32(act),
+                                           f32(slope), _stream()), "scda_conv2d_wino_pool_hip")
+    return y, idx
+
+
 def conv2d_pack_all(flat):
     """Re-pack every conv weight of a FlatParams bucket (forward and data-gradient layouts) with ONE launch and seed the
     pack cache with the results.  Called by FlatAdam.step(): the lazy per-layer path above then never misses in the

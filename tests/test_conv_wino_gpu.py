@@ -146,3 +146,54 @@ def test_wino_wgrad_routes_through_conv2d_entry_points(cuda):
     assert torch.equal(dw, dw1)
     assert not native.wino_wgrad_ok(1, 32, 32, 64, 64, 3, 3, 1, 1) and not native.wino_wgrad_ok(1, 64, 32, 64, 64, 3, 3, 2, 1)
     assert native.wino_wgrad_ok(1, 64, 32, 72, 64, 3, 3, 1, 1) and not native.wino_wgrad_ok(1, 64, 32, 71, 64, 3, 3, 1, 1)
+
+
+def test_conv_pool_fusion_is_bit_identical_to_separate_launches(cuda, monkeypatch):
+    """conv3x3 + ReLU + MaxPool2d(2, 2) in the Winograd kernel's epilogue (scda_conv2d_wino_pool_hip, layers.Conv2d.pool_next) against
+    the same chain with the pool as its own launch (SCDA_CONV_POOL_FUSE=0): pooled values, winners and every gradient bit for bit --
+    ties inside a window included (ReLU zeros) -- and against torch on the CPU at the kernels' usual tolerance."""
+    import torch.nn as nn
+    from scda_amd import layers as L
+    from scda_amd import native
+    from scda_amd.autograd_ops import ACT_RELU
+    g = torch.Generator().manual_seed(21)
+    x0 = torch.randn(1, 64, 256, 256, generator=g)
+    up = torch.randn(1, 32, 64, 64, generator=g)
+
+    def build():
+        torch.manual_seed(5)
+        seq = nn.Sequential(L.Conv2d(64, 64, 3, padding=1, fused_act=ACT_RELU), L.FusedAct(), L.Conv2d(64, 128, 3, padding=1, fused_act=ACT_RELU),
+                            L.FusedAct(), L.MaxPool2x2(), L.Conv2d(128, 32, 3, padding=1, fused_act=ACT_RELU), L.FusedAct(), L.MaxPool2x2())
+        L.plan_act_fusion(seq)
+        return seq.to(cuda)
+
+    res = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("SCDA_CONV_POOL_FUSE", fuse)
+        net = build()
+        assert net[2].pool_next and net[5].pool_next and not net[0].pool_next
+        x = x0.to(cuda).requires_grad_()
+        native.prof_enable(["conv_wino_kernel<fwd>"])
+        y = net(x)
+        torch.cuda.synchronize()
+        native.prof_enable(False)
+        launches = native.prof_collect()["conv_wino_kernel<fwd>"][0]
+        (y * up.to(cuda)).sum().backward()
+        res[fuse] = (y.detach().clone(), x.grad.clone(), [p.grad.clone() for p in net.parameters()], launches)
+    assert res["1"][3] == res["0"][3] == 3
+    assert torch.equal(res["1"][0], res["0"][0]) and torch.equal(res["1"][1], res["0"][1])
+    for a, b in zip(res["1"][2], res["0"][2]):
+        assert torch.equal(a, b)
+    # ... and the chain itself against torch (CPU, fp32)
+    net = build().cpu()
+    ref = nn.Sequential(nn.Conv2d(64, 64, 3, padding=1), nn.ReLU(), nn.Conv2d(64, 128, 3, padding=1), nn.ReLU(), nn.MaxPool2d(2, 2),
+                        nn.Conv2d(128, 32, 3, padding=1), nn.ReLU(), nn.MaxPool2d(2, 2))
+    ref.load_state_dict(net.state_dict(), strict=True)       # same Sequential indices: convs at 0, 2, 5
+    xr = x0.clone().requires_grad_()
+    yr = ref(xr)
+    (yr * up).sum().backward()
+    close(res["1"][0], yr)
+    # the input gradient in relative L2: a pre-activation within round-off of zero may flip its ReLU / pool decision between two
+    # correct implementations, which moves single elements by far more than rounding (tests/test_train_step_gpu.py discusses it)
+    d = (res["1"][1].cpu().double() - xr.grad.double()).norm() / xr.grad.double().norm()
+    assert float(d) < 2e-3, float(d)
