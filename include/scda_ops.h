@@ -386,6 +386,20 @@ int scda_adam_hip(float *param, const float *grad, float *exp_avg, float *exp_av
 int scda_adam_limited_hip(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long long n, float lr,
                           float beta1, float beta2, float eps, float weight_decay, int step, int max_blocks, void *stream);
 
+/* ---- data path: one image from 8-bit interleaved pixels to the network's input tensor ------------------------------
+ * datasets/example_dataset.py:76-100,106-131 and datasets/target_dataset.py:23-71: PIL `img.resize((new_w, new_h))`, optional
+ * FLIP_LEFT_RIGHT, ToTensor (/ 255) and Normalize ((x - mean) / std).  Pillow's resize is a two-pass separable convolution in
+ * fixed point (22 fractional bits) with an 8-bit intermediate image; the caller builds its per-output-coordinate tables
+ * (scda_amd/device_image.py: bounds = [xmin, n] pairs, kk = n weights each, `ksize` entries per coordinate) and the two launches
+ * reproduce it bit for bit.  src [H, W, C] uint8 (C = 1 or 3: modes L and RGB; PIL pre-multiplies alpha modes before resizing, those are not supported), tmp >= scda_image_resize_tmp_bytes(rows, out_w, C) bytes holds the
+ * horizontally resized rows [row0, row0 + rows) -- the rows the vertical tables reach --, out [C, out_h, out_w] float.
+ * normalize = 0 stops after ToTensor.  All pointers are device pointers. */
+size_t scda_image_resize_tmp_bytes(int rows, int out_w, int C);
+int scda_image_resize_normalize_hip(const unsigned char *src, int H, int W, int C, const int *bounds_h, const int *kk_h,
+                                    int ksize_h, int out_w, const int *bounds_v, const int *kk_v, int ksize_v, int out_h,
+                                    int row0, int rows, unsigned char *tmp, size_t tmp_bytes, int normalize, float mean,
+                                    float stdv, int flip, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

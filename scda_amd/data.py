@@ -74,28 +74,51 @@ class ExampleTransform(object):
             b[:, 2:4] = np.ceil(b[:, 2:4] * scale)
         return b
 
-    def __call__(self, img, bbox, ignores):
-        from PIL import Image
-        w, h = img.size
+    def plan(self, w, h):
+        """the transform's random decisions for a w x h image, drawn in the reference's order (randint, then random when flip is
+        on): (new_w, new_h, scale, flipped)"""
         size = np.random.randint(self.scale_min, self.scale_max + 1)
         scale = min(size / min(w, h), self.max_size / max(w, h))
         new_w, new_h = int(w * scale), int(h * scale)
-        img = img.resize((new_w, new_h))
+        flipped = bool(self.flip and np.random.random() < 0.5)
+        return new_w, new_h, scale, flipped
+
+    def boxes(self, bbox, ignores, scale, new_w, flipped):
         bbox = self._scale_boxes(bbox, scale)
         ignores = self._scale_boxes(ignores, scale)
-        if self.flip and np.random.random() < 0.5:
-            img = img.transpose(Image.FLIP_LEFT_RIGHT)
+        if flipped:
             bbox[:, 0], bbox[:, 2] = new_w - bbox[:, 2], new_w - bbox[:, 0]
             if ignores.shape[0] > 0:
                 ignores[:, 0], ignores[:, 2] = new_w - ignores[:, 2], new_w - ignores[:, 0]
+        return bbox, ignores
+
+    def __call__(self, img, bbox, ignores):
+        from PIL import Image
+        w, h = img.size
+        new_w, new_h, scale, flipped = self.plan(w, h)
+        img = img.resize((new_w, new_h))
+        if flipped:
+            img = img.transpose(Image.FLIP_LEFT_RIGHT)
+        bbox, ignores = self.boxes(bbox, ignores, scale, new_w, flipped)
         return img, bbox, scale, ignores
 
 
-class ExampleDataset(Dataset):
-    """item = [image [1,3,h,w] in [-1,1], tensor([h, w, scale]), boxes [G,5] (x1,y1,x2,y2,label), ignores [I,4], filename]"""
+def _device_image(img, new_w, new_h, device, normalize_fn, flipped=False):
+    """resize + flip + ToTensor + Normalize of one decoded image on the device (device_image.py): what the lines
+    `to_tensor(img.resize(..)[.transpose(..)])`, `normalize_fn(t)` produce, bit for bit, from the image's bytes"""
+    from . import device_image
+    if normalize_fn is not None and normalize_fn is not normalize:
+        raise ValueError("the device data path applies this module's normalize ((x - 0.5) / 0.5) or none; got another normalize_fn")
+    return device_image.resize_to_tensor(img, new_w, new_h, device, normalize=normalize_fn is not None, flip=flipped)
 
-    def __init__(self, root_dir, list_file, transform_fn, normalize_fn=normalize):
-        self.root_dir, self.transform_fn, self.normalize_fn = root_dir, transform_fn, normalize_fn
+
+class ExampleDataset(Dataset):
+    """item = [image [1,3,h,w] in [-1,1], tensor([h, w, scale]), boxes [G,5] (x1,y1,x2,y2,label), ignores [I,4], filename]
+    device given: the image is resized / flipped / converted / normalised ON that device from its decoded bytes (identical values; the
+    item's image is a device tensor) -- in the loading process itself, so use it with num_workers = 0"""
+
+    def __init__(self, root_dir, list_file, transform_fn, normalize_fn=normalize, device=None):
+        self.root_dir, self.transform_fn, self.normalize_fn, self.device = root_dir, transform_fn, normalize_fn, device
         self.metas = parse_meta(list_file)
         self.num = len(self.metas)
         self.aspect_ratios = [float(m[1]) / m[2] for m in self.metas]
@@ -112,11 +135,16 @@ class ExampleDataset(Dataset):
         if img.mode == 'L':
             img = img.convert('RGB')
         assert img.size[0] == w and img.size[1] == h, "image size differs from the meta file"
-        img, bbox, scale, ignores = self.transform_fn(img, bbox, ignores)
-        new_w, new_h = img.size
-        t = to_tensor(img)
-        if self.normalize_fn is not None:
-            t = self.normalize_fn(t)
+        if self.device is not None:
+            new_w, new_h, scale, flipped = self.transform_fn.plan(w, h)
+            bbox, ignores = self.transform_fn.boxes(bbox, ignores, scale, new_w, flipped)
+            t = _device_image(img, new_w, new_h, self.device, self.normalize_fn, flipped)
+        else:
+            img, bbox, scale, ignores = self.transform_fn(img, bbox, ignores)
+            new_w, new_h = img.size
+            t = to_tensor(img)
+            if self.normalize_fn is not None:
+                t = self.normalize_fn(t)
         bbox = np.hstack([bbox.reshape(-1, 4), labels[:, np.newaxis]])
         return [t.unsqueeze(0), torch.Tensor([new_h, new_w, scale]), torch.from_numpy(bbox), torch.from_numpy(ignores), filename]
 
@@ -124,8 +152,8 @@ class ExampleDataset(Dataset):
 class TargetDataset(Dataset):
     """unlabelled target-domain images, resized to exactly new_w x new_h (target_dataset.py:23-71)"""
 
-    def __init__(self, root_dir, list_file, normalize_fn=normalize, new_w=1024, new_h=512):
-        self.root_dir, self.normalize_fn, self.new_w, self.new_h = root_dir, normalize_fn, new_w, new_h
+    def __init__(self, root_dir, list_file, normalize_fn=normalize, new_w=1024, new_h=512, device=None):
+        self.root_dir, self.normalize_fn, self.new_w, self.new_h, self.device = root_dir, normalize_fn, new_w, new_h, device
         with open(list_file) as f:
             self.metas = [x.strip() for x in f.readlines()]
         self.num = len(self.metas)
@@ -138,6 +166,8 @@ class TargetDataset(Dataset):
         img = Image.open(os.path.join(self.root_dir, self.metas[idx]))
         if img.mode == 'L':
             img = img.convert('RGB')
+        if self.device is not None:
+            return _device_image(img, self.new_w, self.new_h, self.device, self.normalize_fn)
         t = to_tensor(img.resize((self.new_w, self.new_h)))
         return self.normalize_fn(t) if self.normalize_fn is not None else t
 
@@ -167,13 +197,16 @@ class ExampleDataLoader(DataLoader):
 
 
 def build_data_loaders(datadir, train_meta_file, val_meta_file, target_meta_file, cfg, batch_size=1, workers=0,
-                       distributed=False, new_w=1024, new_h=512):
-    """(train_loader, val_loader, target_loader) as the reference's build_data_loader (faster_rcnn_train_val.py:191-248)"""
+                       distributed=False, new_w=1024, new_h=512, device=None):
+    """(train_loader, val_loader, target_loader) as the reference's build_data_loader (faster_rcnn_train_val.py:191-248).
+    device given: images are resized and normalised on that device (same values; batches arrive as device tensors)"""
     from torch.utils.data.distributed import DistributedSampler
+    if device is not None and workers != 0:
+        raise ValueError("the device data path runs in the loading process: workers must be 0")
     scales, max_size = cfg['shared']['scales'], cfg['shared']['max_size']
-    train = ExampleDataset(datadir, train_meta_file, ExampleTransform(scales, max_size, flip=True))
-    val = ExampleDataset(datadir, val_meta_file, ExampleTransform(max(scales), max_size, flip=False))
-    target = TargetDataset(datadir, target_meta_file, new_w=new_w, new_h=new_h)
+    train = ExampleDataset(datadir, train_meta_file, ExampleTransform(scales, max_size, flip=True), device=device)
+    val = ExampleDataset(datadir, val_meta_file, ExampleTransform(max(scales), max_size, flip=False), device=device)
+    target = TargetDataset(datadir, target_meta_file, new_w=new_w, new_h=new_h, device=device)
     ts, vs, gs = (DistributedSampler(d) for d in (train, val, target)) if distributed else (None, None, None)
     return (ExampleDataLoader(train, batch_size=batch_size, shuffle=ts is None, num_workers=workers, sampler=ts),
             ExampleDataLoader(val, batch_size=1, shuffle=False, num_workers=workers, sampler=vs),

@@ -1045,6 +1045,28 @@ def prof_collect():
             for k in range(n) if launches[k] > 0}
 
 
+# ------------------------------------------------------------ data path -----
+def image_resize_normalize(src, tables, out_h, out_w, normalize=True, mean=0.5, std=0.5, flip=False):
+    """src uint8 [H, W, C] (device) -> float32 [C, out_h, out_w]: PIL resize + optional flip + ToTensor + Normalize on the device
+    (scda_image_resize_normalize_hip; datasets/example_dataset.py:76-131).  `tables` = (bounds_h, kk_h, ksize_h, bounds_v, kk_v,
+    ksize_v, row0, rows): device int32 tensors and ints from device_image.resize_tables."""
+    _req(src, "src", torch.uint8)
+    H, W, C = src.shape
+    bh, kh, ksh, bv, kv, ksv, row0, rows = tables
+    for t, name in ((bh, "bounds_h"), (kh, "kk_h"), (bv, "bounds_v"), (kv, "kk_v")):
+        _req(t, name, torch.int32)
+    L = lib()
+    L.scda_image_resize_tmp_bytes.restype = ctypes.c_size_t
+    nb = int(L.scda_image_resize_tmp_bytes(i32(rows), i32(out_w), i32(C)))
+    tmp = torch.empty(nb, dtype=torch.uint8, device=src.device)
+    out = torch.empty(C, out_h, out_w, dtype=torch.float32, device=src.device)
+    _check(L.scda_image_resize_normalize_hip(_p(src), i32(H), i32(W), i32(C), _p(bh), _p(kh), i32(ksh), i32(out_w), _p(bv), _p(kv),
+                                             i32(ksv), i32(out_h), i32(row0), i32(rows), _p(tmp), ctypes.c_size_t(nb),
+                                             i32(1 if normalize else 0), f32(mean), f32(std), i32(1 if flip else 0), _p(out), _stream()),
+           "scda_image_resize_normalize_hip")
+    return out
+
+
 # ------------------------------------------------------- host -> device ------
 def upload(array_or_tensor, device, dtype=None):
     """numpy array / CPU tensor -> device tensor through a pinned staging buffer with a non-blocking copy.

@@ -19,5 +19,5 @@ fi
 cd $R/scda_amd/csrc
 for n in 4 8 16 28 32 64 128 224; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wno-unused-function -DSCDA_WINO_ABLATE=$n -c conv_wino.hip -o $O/conv_wino_A$n.o &&
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $O/libscda_ops_A$n.so detection_ops.o box_ops.o conv_gemm.o $O/conv_wino_A$n.o nn_ops.o && echo built $n
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $O/libscda_ops_A$n.so detection_ops.o box_ops.o conv_gemm.o $O/conv_wino_A$n.o nn_ops.o image_ops.o && echo built $n
 done
