@@ -256,6 +256,7 @@ def test_gradients_with_replayed_selections(cuda, H, W):
             e = rel_l2(pg[k], rg[k])
             if e > worst.get(name, ('', 0.0))[1]:
                 worst[name] = (k, e)
+    print("worst gradient tensor per net (relative L2):", worst)     # pytest -s: the margin against the 1e-4 bound
     assert all(e <= 1e-4 for _, e in worst.values()), worst
 
 
