@@ -661,13 +661,16 @@ static int wino_launch(const float *x, const float *u, const float *bias, float 
     g.n_mt = (M + 32 * MBv - 1) / (32 * MBv); g.n_slab = C / WBK;
     const int nbx = (W + 31) / 32, nby = (H + 7) / 8, npb = batch * nby * nbx;   // blocks on the right / bottom edge may be partial
     g.dNMT = Div(g.n_mt); g.dNPB = Div(npb); g.dNB = Div(nby * nbx); g.dNBX = Div(nbx);
-    // XCD order: pixel-block-major when every m-tile's filters fit one XCD's 4 MB L2 beside the patches (<= 3 MB: every layer below
-    // 512 x 512 channels), m-tile-major otherwise (SCDA_WINO_ORDER=m|p forces one: A/B, counter passes)
+    // XCD order: pixel-block-major when all m-tiles' filters can stream through one XCD's 4 MB L2 beside the patches (<= 4.5 MB: every
+    // layer below 512 output channels; conv3_2's 4.2 MB: 290 -> 109 MB read per launch), m-tile-major otherwise
+    // (SCDA_WINO_ORDER=m|p forces one: A/B, counter passes).  ALSO with a single m-tile (conv1_2, the decoders' up-sampling stages):
+    // dealt round-robin, row neighbours run on different XCDs and each fetches the two extra 128-byte lines its 136-byte patch rows
+    // straddle -- conv1_2 read 422 MB for a 134 MB input, 183 MB as contiguous runs (and the decoders' stages run 4 - 9 % faster).
     static const char *order_env = getenv("SCDA_WINO_ORDER");
     g.npb = npb; g.per_xcd = 0;
-    // (... and only for launches of >= 32 pixel blocks per XCD: the runs leave up to 7 idle workgroups per m-tile, and a small
+    // (... and only for launches of >= 16 pixel blocks per XCD: the runs leave up to 7 idle workgroups per m-tile, and a small
     // launch -- the decoders' 64 blocks -- lost 13 % to the imbalance)
-    g.pixel_major = order_env ? (order_env[0] == 'p') : (g.n_mt > 1 && npb >= 256 && 16.0 * g.n_mbg * 32 * C * 4 <= 3.0e6);
+    g.pixel_major = order_env ? (order_env[0] == 'p') : (npb >= 128 && 16.0 * g.n_mbg * 32 * C * 4 <= 4.5e6);
     // split-K: a launch below one workgroup per CU splits the channel loop (>= 4 slabs per split), slabs in the natural pixel order
     const long long tiles = (long long)g.n_mt * npb;
     int splits = 1;

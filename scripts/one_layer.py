@@ -5,7 +5,8 @@ import torch
 from scda_amd import native
 L = {"conv1_2": (1, 64, 512, 1024, 64), "conv2_2": (1, 128, 256, 512, 128), "conv3_2": (1, 256, 128, 256, 256),
      "conv4_2": (1, 512, 64, 128, 512), "conv5_x": (1, 512, 32, 64, 512), "dec_res": (4, 128, 64, 64, 128),
-     "dec_up2": (4, 64, 256, 256, 32), "conv3_1": (1, 128, 128, 256, 256)}
+     "dec_up2": (4, 64, 256, 256, 32), "conv3_1": (1, 128, 128, 256, 256), "conv2_1": (1, 64, 256, 512, 128),
+     "conv4_1": (1, 256, 64, 128, 512), "dec_up1": (4, 128, 128, 128, 64)}
 name, what, n = sys.argv[1], sys.argv[2], int(sys.argv[3])
 B, Cin, H, W, Cout = L[name]
 dev = torch.device("cuda:0")
