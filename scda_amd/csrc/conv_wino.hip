@@ -72,6 +72,8 @@ struct WinoGeom {
     Div dNMT, dNPB, dNB, dNBX;   // m-tiles; pixel blocks of the launch; per image; per block row
     int pixel_major, npb, per_xcd;   // XCD-aware order with the pixel block outermost (see the kernel); pixel blocks of the launch;
                                      // (split, pixel block) items per XCD
+    int gm_mask, gm_shift;           // ... with the 8 XCDs split gm x (8 / gm) over m-tile groups x pixel-block runs: gm - 1, log2(gm)
+    Div dNML;                        // m-tiles per XCD (n_mt / gm)
 };
 
 struct WinoEpi {
@@ -108,10 +110,14 @@ __global__ __launch_bounds__(512, (MB == 2 ? 2 : 4)) void conv_wino_kernel(const
         // when all 16 x M x C of them fit an L2.  An XCD owns a CONTIGUOUS run of (split, pixel block) items -- row neighbours run side
         // by side on it and share the 128-byte lines their 136-byte patch rows straddle (the halo columns make every row touch three
         // lines: dealt round-robin, neighbouring blocks landed on different XCDs and each fetched the shared lines itself).
+        // With the filters too large for that (conv4_x: 8 - 17 MB) the XCDs are split gm x (8 / gm): XCD x serves the m-tiles
+        // mt % gm == x % gm on run x / gm of the pixel blocks -- each XCD streams 1 / gm of the filters and reads 1 / (8 / gm) of
+        // the input, instead of one m-tile's filters and the WHOLE input (m-tile-major).
         const int x = (int)(blockIdx.x & 7), j = (int)(blockIdx.x >> 3);
-        int pl;
-        g.dNMT.divmod(j, pl, mt);
-        rest = x * g.per_xcd + pl;
+        int pl, ml;
+        g.dNML.divmod(j, pl, ml);
+        mt = (ml << g.gm_shift) + (x & g.gm_mask);
+        rest = (x >> g.gm_shift) * g.per_xcd + pl;
         if (pl >= g.per_xcd || rest >= g.npb * e.splits) return;
         g.dNPB.divmod(rest, sp, pb);
     } else {
@@ -670,7 +676,28 @@ static int wino_launch(const float *x, const float *u, const float *bias, float 
     g.npb = npb; g.per_xcd = 0;
     // (... and only for launches of >= 16 pixel blocks per XCD: the runs leave up to 7 idle workgroups per m-tile, and a small
     // launch -- the decoders' 64 blocks -- lost 13 % to the imbalance)
-    g.pixel_major = order_env ? (order_env[0] == 'p') : (npb >= 128 && 16.0 * g.n_mbg * 32 * C * 4 <= 4.5e6);
+    const double u_bytes = 16.0 * g.n_mbg * 32 * C * 4, in_bytes = 4.0 * batch * C * H * W;
+    g.pixel_major = order_env ? (order_env[0] == 'p') : (npb >= 128 && u_bytes <= 4.5e6);
+    // filters beyond one L2: split the XCDs gm x (8 / gm) over m-tile groups x pixel-block runs where that moves fewer bytes than
+    // m-tile-major (filters x (8 / gm) + input x gm against filters + input x min(n_mt, 8)) and every XCD still streams <= 4.5 MB
+    // of filters (SCDA_WINO_GM=2|4 forces a split, 0 none)
+    int gm = 1;
+    if (!g.pixel_major && !order_env) {
+        static const char *gm_env = getenv("SCDA_WINO_GM");
+        const int gm_legacy = g.n_mt >= 8 ? 8 : g.n_mt;
+        // (fewer than 8 m-tiles: a block's row neighbours land on different XCDs and each fetches the straddled lines itself)
+        double best = u_bytes * (8.0 / gm_legacy) + in_bytes * gm_legacy * (g.n_mt >= 8 ? 1.0 : 2.0);
+        for (int c = 2; c <= 4; c *= 2) {
+            const long long items = (long long)npb;     // (the split count is not known yet: launches that split are small, see below)
+            if (g.n_mt % c != 0 || items % (8 / c) != 0 || items / (8 / c) < 8 || u_bytes / c > 4.5e6) continue;
+            const double cost = u_bytes * (8.0 / c) + in_bytes * c;
+            if (gm_env ? atoi(gm_env) == c : cost < best) { best = cost; gm = c; }
+        }
+        if (gm_env && atoi(gm_env) == 0) gm = 1;
+        if (gm > 1) g.pixel_major = 1;
+    }
+    g.gm_mask = gm - 1; g.gm_shift = gm == 4 ? 2 : gm == 2 ? 1 : 0;
+    g.dNML = Div(g.n_mt / gm);
     // split-K: a launch below one workgroup per CU splits the channel loop (>= 4 slabs per split), slabs in the natural pixel order
     const long long tiles = (long long)g.n_mt * npb;
     int splits = 1;
@@ -687,9 +714,10 @@ static int wino_launch(const float *x, const float *u, const float *bias, float 
     prof_begin(for_dgrad ? PK_WINO_DGRAD : PK_WINO_FWD, 2.0 * M * (double)batch * H * W * C * 4, st,
                4.0 * ((double)batch * C * H * W + 9.0 * M * C + (double)batch * M * H * W));
     long long wgs = tiles * splits;
-    if (g.pixel_major) {      // 8 runs of per_xcd (split, pixel block) items x n_mt m-tiles; the last run may hold idle workgroups
-        g.per_xcd = (int)(((long long)npb * splits + 7) / 8);
-        wgs = 8LL * g.per_xcd * g.n_mt;
+    if (g.pixel_major) {      // 8 / gm runs of per_xcd (split, pixel block) items x n_mt m-tiles; the last run may hold idle workgroups
+        const int gp = 8 / gm;
+        g.per_xcd = (int)(((long long)npb * splits + gp - 1) / gp);
+        wgs = 8LL * g.per_xcd * (g.n_mt / gm);
     }
     if (MBv == 2) hipLaunchKernelGGL(conv_wino_kernel<2>, dim3((unsigned)wgs), dim3(512), 0, st, u, x, g, e);
     else hipLaunchKernelGGL(conv_wino_kernel<1>, dim3((unsigned)wgs), dim3(512), 0, st, u, x, g, e);
