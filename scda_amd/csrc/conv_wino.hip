@@ -372,7 +372,8 @@ struct WinoWgradGeom {
     int n_ct, TY, TX;            // input-channel tiles; tile rows per image (H / 2); slabs per tile row (W / 16)
     int n_slab, slabs_per_split; // slabs of the launch (batch * TY * TX)
     int splits, splits_per_xcd;
-    Div dNMT, dNCT, dTX, dTY;
+    int sp_mask, sp_shift;       // fewer than 8 splits (2 or 4): XCD x serves split x & sp_mask and m-tile group x >> sp_shift (-1: off)
+    Div dNMT, dNCT, dTX, dTY, dNML;   // dNML: m-tiles per group
 };
 
 __global__ __launch_bounds__(512, 2) void conv_wino_wgrad_kernel(const float *__restrict__ dY, const float *__restrict__ X,
@@ -390,7 +391,16 @@ __global__ __launch_bounds__(512, 2) void conv_wino_wgrad_kernel(const float *__
         g.dNMT.divmod(j, rest, mt);
         g.dNCT.divmod(rest, sl, ct);
         sp = x * g.splits_per_xcd + sl;
-    } else {      // fewer than 8 splits (512 x 512 channels: 64 tile pairs x 4): tile pairs across the XCDs, as they come
+    } else if (g.sp_shift >= 0) {
+        // 2 or 4 splits (512 x 512 channels: 64 tile pairs x 4): an XCD serves ONE split -- a quarter of the pixels -- and one group of
+        // the m-tiles with all c-tiles: it reads its pixels of X once and a group's rows of dY (dealt as they come, every XCD read
+        // every pixel of X: conv4_2 219 MB for 34 MB of operands)
+        const int x = (int)(blockIdx.x & 7), j = (int)(blockIdx.x >> 3);
+        int ml;
+        sp = x & g.sp_mask;
+        g.dNML.divmod(j, ct, ml);
+        mt = ml * (8 >> g.sp_shift) + (x >> g.sp_shift);
+    } else {      // tile pairs across the XCDs, as they come
         g.dNMT.divmod((int)blockIdx.x, rest, mt);
         g.dNCT.divmod(rest, sp, ct);
     }
@@ -762,6 +772,12 @@ SCDA_API int scda_conv2d_wino_wgrad_hip(const float *dy, const float *x, float *
     float *db_ws = db ? wsf + (size_t)splits * Cout * Cin * 9 : nullptr;
     prof_begin(PK_WINO_WGRAD, 2.0 * Cout * (double)batch * H * W * Cin * 4, st);
     g.splits = splits; g.splits_per_xcd = (splits % 8) == 0 ? splits / 8 : 0;
+    g.sp_mask = 0; g.sp_shift = -1; g.dNML = Div(1);
+    static const bool no_groups = getenv("SCDA_WINO_WGRAD_NO_GROUPS") != nullptr;    // A/B knob
+    if (!no_groups && (splits == 2 || splits == 4) && n_mt % (8 / splits) == 0) {
+        g.sp_mask = splits - 1; g.sp_shift = splits == 4 ? 2 : 1;
+        g.dNML = Div(n_mt / (8 / splits));
+    }
     hipLaunchKernelGGL(conv_wino_wgrad_kernel, dim3((unsigned)(tiles * splits)), dim3(512), 0, st, dy, x, g, wsf, db_ws);
     prof_end(st);
     int rc = launch_status("conv_wino_wgrad_kernel");
