@@ -52,6 +52,10 @@ int scda_prof_collect(long long *launches, double *ms, double *flops, double *by
 /* test aid: {tile rows, tile cols, split-K count, 1 = direct-to-LDS kernel family} of the calling thread's most recent conv /
  * GEMM launch (the planner's choice, or the SCDA_PLAN_FORCE="bm,bn,splits" override when that is legal for the shape) */
 void scda_debug_last_plan(int *out4);
+/* test aid: launch order of the calling thread's most recent Winograd launches -- forward / data gradient {tile rows / 32,
+ * 1 = contiguous pixel-block runs per XCD, gm (XCDs split gm x 8/gm over m-tile groups x runs; 1 = none), split-K count}, weight
+ * gradient {K-splits, 0 = dealt as they come / 1 = whole splits per XCD / 2 = one split + one m-tile group per XCD} */
+void scda_debug_wino_last_order(int *out6);
 
 /* ---------------------------------------------------------------- NMS ---- */
 /* replaces  int gpu_nms(THLongTensor* keep, THLongTensor* num_out, THCudaTensor* boxes, float thresh)

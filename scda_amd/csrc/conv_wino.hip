@@ -653,6 +653,10 @@ SCDA_API int scda_conv2d_wino_pack_hip(const float *w, float *out, int Cout, int
 }
 
 // y [batch, M, H, W] = act(conv3x3(x [batch, C, H, W], stride 1, pad 1) + bias) (* act'(mask_src)); u = scda_conv2d_wino_pack_hip
+// test aid (scda_debug_wino_last_order): the launch order the calling thread's most recent launches took
+static thread_local int g_wino_last[4] = {0, 0, 0, 0};          // forward / data gradient: tile rows / 32, pixel-block-major?, gm, splits
+static thread_local int g_wino_wgrad_last[2] = {0, 0};          // weight gradient: splits, 0 as they come / 1 whole splits per XCD / 2 split + m-tile group
+
 static int wino_launch(const float *x, const float *u, const float *bias, float *y, int batch, int C, int H, int W, int M, int act,
                        float slope, const float *mask_src, float mask_slope, int for_dgrad, void *ws, size_t ws_bytes, void *stream,
                        float *pool_y, unsigned char *pool_idx) {
@@ -693,7 +697,7 @@ static int wino_launch(const float *x, const float *u, const float *bias, float 
     // of filters (SCDA_WINO_GM=2|4 forces a split, 0 none)
     int gm = 1;
     if (!g.pixel_major && !order_env) {
-        static const char *gm_env = getenv("SCDA_WINO_GM");
+        const char *gm_env = getenv("SCDA_WINO_GM");      // (read per launch: tests/test_conv_wino_gpu.py forces every split)
         const int gm_legacy = g.n_mt >= 8 ? 8 : g.n_mt;
         // (fewer than 8 m-tiles: a block's row neighbours land on different XCDs and each fetches the straddled lines itself)
         double best = u_bytes * (8.0 / gm_legacy) + in_bytes * gm_legacy * (g.n_mt >= 8 ? 1.0 : 2.0);
@@ -729,6 +733,7 @@ static int wino_launch(const float *x, const float *u, const float *bias, float 
         g.per_xcd = (int)(((long long)npb * splits + gp - 1) / gp);
         wgs = 8LL * g.per_xcd * (g.n_mt / gm);
     }
+    g_wino_last[0] = MBv; g_wino_last[1] = g.pixel_major; g_wino_last[2] = gm; g_wino_last[3] = splits;
     if (MBv == 2) hipLaunchKernelGGL(conv_wino_kernel<2>, dim3((unsigned)wgs), dim3(512), 0, st, u, x, g, e);
     else hipLaunchKernelGGL(conv_wino_kernel<1>, dim3((unsigned)wgs), dim3(512), 0, st, u, x, g, e);
     prof_end(st);
@@ -773,16 +778,22 @@ SCDA_API int scda_conv2d_wino_wgrad_hip(const float *dy, const float *x, float *
     prof_begin(PK_WINO_WGRAD, 2.0 * Cout * (double)batch * H * W * Cin * 4, st);
     g.splits = splits; g.splits_per_xcd = (splits % 8) == 0 ? splits / 8 : 0;
     g.sp_mask = 0; g.sp_shift = -1; g.dNML = Div(1);
-    static const bool no_groups = getenv("SCDA_WINO_WGRAD_NO_GROUPS") != nullptr;    // A/B knob
+    const bool no_groups = getenv("SCDA_WINO_WGRAD_NO_GROUPS") != nullptr;    // A/B knob (read per launch: the tests compare both orders)
     if (!no_groups && (splits == 2 || splits == 4) && n_mt % (8 / splits) == 0) {
         g.sp_mask = splits - 1; g.sp_shift = splits == 4 ? 2 : 1;
         g.dNML = Div(n_mt / (8 / splits));
     }
+    g_wino_wgrad_last[0] = splits; g_wino_wgrad_last[1] = g.splits_per_xcd > 0 ? 1 : g.sp_shift >= 0 ? 2 : 0;
     hipLaunchKernelGGL(conv_wino_wgrad_kernel, dim3((unsigned)(tiles * splits)), dim3(512), 0, st, dy, x, g, wsf, db_ws);
     prof_end(st);
     int rc = launch_status("conv_wino_wgrad_kernel");
     if (rc) return rc;
     return launch_wgrad_reduce(wsf, splits, (long long)Cout * Cin * 9, Cin * 9, accumulate, dw, db_ws, db, Cout, db_accumulate, st);
+}
+
+SCDA_API void scda_debug_wino_last_order(int *out6) {
+    for (int i = 0; i < 4; ++i) out6[i] = g_wino_last[i];
+    out6[4] = g_wino_wgrad_last[0]; out6[5] = g_wino_wgrad_last[1];
 }
 
 SCDA_API int scda_conv2d_wino_hip(const float *x, const float *u, const float *bias, float *y, int batch, int C, int H, int W, int M,

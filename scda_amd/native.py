@@ -1009,6 +1009,13 @@ def last_plan():
     return out[0], out[1], out[2], bool(out[3])
 
 
+def wino_last_order():
+    """launch order of this thread's most recent Winograd launches: ((tile rows / 32, pixel-block-major?, gm, splits), (wgrad splits, wgrad order))"""
+    out = (ctypes.c_int * 6)()
+    lib().scda_debug_wino_last_order(out)
+    return (out[0], bool(out[1]), out[2], out[3]), (out[4], out[5])
+
+
 # ------------------------------------------------------------ profiler ------
 def prof_kernel_names():
     L = lib()

@@ -197,3 +197,49 @@ def test_conv_pool_fusion_is_bit_identical_to_separate_launches(cuda, monkeypatc
     # correct implementations, which moves single elements by far more than rounding (tests/test_train_step_gpu.py discusses it)
     d = (res["1"][1].cpu().double() - xr.grad.double()).norm() / xr.grad.double().norm()
     assert float(d) < 2e-3, float(d)
+
+
+@pytest.mark.parametrize("case,gm", [((1, 64, 64, 128, 512), 2), ((1, 64, 64, 128, 512), 4), ((1, 128, 64, 128, 256), 2),
+                                     ((1, 128, 64, 128, 256), 4), ((2, 64, 64, 64, 128), 2), ((2, 64, 64, 64, 128), 4)])
+def test_wino_xcd_split_orders_give_the_same_result(cuda, case, gm, monkeypatch):
+    """the launch order (which XCD runs which (m-tile, pixel block): csrc/conv_wino.hip wino_launch) is a pure renumbering of the
+    workgroups: every forced split of the XCDs over m-tile groups x pixel-block runs gives the bits of the plain order"""
+    from scda_amd import native
+    B, Cin, H, W, Cout = case
+    g = torch.Generator().manual_seed(sum(case) + gm)
+    x = torch.randn(B, Cin, H, W, generator=g).to(cuda)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).to(cuda)
+    b = torch.randn(Cout, generator=g).to(cuda)
+    u = native.conv2d_wino_pack(w, False)
+    monkeypatch.setenv("SCDA_WINO_GM", "0")
+    y0 = native.conv2d_wino(x, u, b, Cout, 1, 0.0)
+    assert native.wino_last_order()[0][1:3] == (False, 1)
+    monkeypatch.setenv("SCDA_WINO_GM", str(gm))
+    y1 = native.conv2d_wino(x, u, b, Cout, 1, 0.0)
+    assert native.wino_last_order()[0][1:3] == (True, gm)        # the split order WAS taken
+    assert torch.equal(y0, y1)
+    close(y1, F.relu(F.conv2d(x.cpu(), w.cpu(), b.cpu(), stride=1, padding=1)))
+
+
+@pytest.mark.parametrize("case,splits", [((1, 64, 32, 64, 512), 2), ((1, 64, 32, 64, 512), 4), ((1, 128, 16, 64, 256), 2),
+                                         ((1, 512, 32, 64, 512), 4), ((2, 64, 16, 64, 128), 4)])
+def test_wino_wgrad_split_groups_give_the_same_result(cuda, case, splits, monkeypatch):
+    """2 or 4 K-splits: one split and one m-tile group per XCD (conv_wino_wgrad_kernel's index decode) -- the same partial slabs,
+    the same fixed-order reduce: bit-identical to the launch dealt over the XCDs as it comes"""
+    from scda_amd import native
+    B, Cin, H, W, Cout = case
+    g = torch.Generator().manual_seed(sum(case) + splits)
+    x = torch.randn(B, Cin, H, W, generator=g); dy = torch.randn(B, Cout, H, W, generator=g)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).requires_grad_()
+    bias = torch.zeros(Cout, requires_grad=True)
+    F.conv2d(x, w, bias, stride=1, padding=1).backward(dy)
+    monkeypatch.setenv("SCDA_WINO_WGRAD_SPLITS", str(splits))
+    monkeypatch.setenv("SCDA_WINO_WGRAD_NO_GROUPS", "1")
+    dw0, db0 = native.conv2d_wino_wgrad(dy.to(cuda), x.to(cuda), w.shape, want_bias=True)
+    assert native.wino_last_order()[1] == (splits, 0)
+    monkeypatch.delenv("SCDA_WINO_WGRAD_NO_GROUPS")
+    dw1, db1 = native.conv2d_wino_wgrad(dy.to(cuda), x.to(cuda), w.shape, want_bias=True)
+    assert native.wino_last_order()[1] == (splits, 2)            # one split + one m-tile group per XCD
+    assert torch.equal(dw0, dw1) and torch.equal(db0, db1)
+    close(dw1, w.grad); close(db1, bias.grad)
+
