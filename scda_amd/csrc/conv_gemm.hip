@@ -1785,6 +1785,12 @@ static int launch_conv(const float *Wm, const float *X, const ConvGeom &g0, Epi 
     g.k_per_split = round_k_per_split(g.K, splits);
     splits = cdiv(g.K, g.k_per_split);
     g.nx = cdiv(g.N, BNv); g.ny = cdiv(g.M, BMt); g.swz = xcd_swizzle_enabled();
+    // many M-tiles whose weight panels together do not fit an XCD's L2 (the ResNet RoI head's 512 -> 2048 1x1: 32 panels = 4.2 MB,
+    // walked M-tile-fastest they were re-fetched for every pixel tile: 762 MB read for a 51 MB input): the grouped order of the
+    // dense GEMMs (tile_coords: 8 M-tiles at a time across all pixel tiles -- the input is read once per group instead)
+    static const bool no_group = getenv("SCDA_CONV_NO_MGROUP") != nullptr;   // A/B knob
+    if (!no_group && g.swz && !parity && g.ny >= 16 && (long long)g.nx * g.ny >= 1024 && (double)g.M * g.K * sizeof(float) > 4e6)
+        g.swz |= 2;
     if (parity) {
         const int pq = (g.PH / 2) * (g.PW / 2);
         g.parity = 1;

@@ -7,13 +7,18 @@ L = {"conv1_2": (1, 64, 512, 1024, 64), "conv2_2": (1, 128, 256, 512, 128), "con
      "conv4_2": (1, 512, 64, 128, 512), "conv5_x": (1, 512, 32, 64, 512), "dec_res": (4, 128, 64, 64, 128),
      "dec_up2": (4, 64, 256, 256, 32), "conv3_1": (1, 128, 128, 256, 256), "conv2_1": (1, 64, 256, 512, 128),
      "conv4_1": (1, 256, 64, 128, 512), "dec_up1": (4, 128, 128, 128, 64)}
+# ResNet-50 C4 at 800 x 1344 (1x1 convolutions of the bottlenecks): name -> (B, Cin, H, W, Cout) with a "p" prefix
+P = {"p1_256_64": (1, 256, 200, 336, 64), "p1_64_256": (1, 64, 200, 336, 256), "p2_512_128": (1, 512, 100, 168, 128),
+     "p2_128_512": (1, 128, 100, 168, 512), "p3_1024_256": (1, 1024, 50, 84, 256), "p3_256_1024": (1, 256, 50, 84, 1024),
+     "p4_2048_512": (1, 2048, 3584, 7, 512), "p4_512_2048": (1, 512, 3584, 7, 2048)}
 name, what, n = sys.argv[1], sys.argv[2], int(sys.argv[3])
-B, Cin, H, W, Cout = L[name]
+ks, pad = (1, 0) if name in P else (3, 1)
+B, Cin, H, W, Cout = (P if name in P else L)[name]
 dev = torch.device("cuda:0")
-x = torch.randn(B, Cin, H, W, device=dev); w = torch.randn(Cout, Cin, 3, 3, device=dev) * 0.05; b = torch.randn(Cout, device=dev)
-y = native.conv2d_fwd(x, w, b, 1, 1, 1); dy = torch.randn_like(y)
-fn = {"fwd": lambda: native.conv2d_fwd(x, w, b, 1, 1, 1), "dgrad": lambda: native.conv2d_dgrad(dy, w, x.shape, 1, 1),
-      "wgrad": lambda: native.conv2d_wgrad(dy, x, w.shape, 1, 1)}[what]
+x = torch.randn(B, Cin, H, W, device=dev); w = torch.randn(Cout, Cin, ks, ks, device=dev) * 0.05; b = torch.randn(Cout, device=dev)
+y = native.conv2d_fwd(x, w, b, 1, pad, 1); dy = torch.randn_like(y)
+fn = {"fwd": lambda: native.conv2d_fwd(x, w, b, 1, pad, 1), "dgrad": lambda: native.conv2d_dgrad(dy, w, x.shape, 1, pad),
+      "wgrad": lambda: native.conv2d_wgrad(dy, x, w.shape, 1, pad)}[what]
 for _ in range(n):
     fn()
 torch.cuda.synchronize()
