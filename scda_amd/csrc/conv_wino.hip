@@ -56,6 +56,11 @@ __device__ __forceinline__ void wino_dma_b32(const void *, const unsigned, float
 #define SCDA_WINO_ABLATE 0     // timing ablations of conv_wino_kernel's K loop (scripts/ablate/wino_ablate.sh): 4 no barrier, 8 no patch DMA, 16 no LDS reads; weight gradient: 128 / 64 / 32
 #endif
 #define WINO_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+// An empty volatile asm that "rewrites" a register value: it is ordered among the side-effecting nodes (sched_barrier, s_barrier, the
+// other pins), so a PURE operation -- an MFMA, a VALU sum: nodes without a chain, which instruction selection is free to bunch up
+// across sched_barriers, and did in the {0, 3} column variant -- whose operand is pinned in front of it and whose result is pinned
+// behind it stays in the slot it was written in.  No instruction is emitted.
+#define WINO_PIN(x) asm volatile("" : "+v"(x))
 
 constexpr int WBK = WINO_BK;                    // channels per K-slab (8)
 constexpr int W_PR = 10, W_RS = 40;             // patch rows; row stride in floats: 17 even columns at 0.., 17 odd columns at 20..
@@ -143,11 +148,12 @@ __global__ __launch_bounds__(512, (MB == 2 ? 2 : 4)) void conv_wino_kernel(const
         dma_off[i] = ok ? (unsigned)((ch * plane + gy * g.W + gx) * 4) : 0x80000000u;
     }
     const char *xbase = reinterpret_cast<const char *>(X + (size_t)img * g.C * plane);
+    auto issue_dma_one = [&](const int s, const int buf, const int i) {
+        wino_dma_b32(xbase, dma_off[i], lds + buf * W_STAGE + wave * (W_DMA * 64) + i * 64, s * (WBK * plane * 4));
+    };
     auto issue_dma = [&](const int s, const int buf) {
-        float *dst = lds + buf * W_STAGE + wave * (W_DMA * 64);
-        const int soff = s * (WBK * plane * 4);
 #pragma unroll
-        for (int i = 0; i < W_DMA; ++i) wino_dma_b32(xbase, dma_off[i], dst + i * 64, soff);
+        for (int i = 0; i < W_DMA; ++i) issue_dma_one(s, buf, i);
     };
 
     // ---- this wave's two positions ------------------------------------------------------------------------------------------------
@@ -169,11 +175,14 @@ __global__ __launch_bounds__(512, (MB == 2 ? 2 : 4)) void conv_wino_kernel(const
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
             ub[x][mb] = U + (size_t)((x ? xi1 : xi0) * n_mbg + mt * MB + mb) * g.n_slab * 256;
+    auto load_a_one = [&](const int s, const int x, const int mb, wino_f4 (&A)[2][MB]) {
+        A[x][mb] = *reinterpret_cast<const wino_f4 *>(ub[x][mb] + (size_t)s * 256 + lane * 4);
+    };
     auto load_a = [&](const int s, wino_f4 (&A)[2][MB]) {
 #pragma unroll
         for (int x = 0; x < 2; ++x)
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb) A[x][mb] = *reinterpret_cast<const wino_f4 *>(ub[x][mb] + (size_t)s * 256 + lane * 4);
+            for (int mb = 0; mb < MB; ++mb) load_a_one(s, x, mb, A);
     };
 
     f32x16 acc[2][MB][2];
@@ -186,86 +195,134 @@ __global__ __launch_bounds__(512, (MB == 2 ? 2 : 4)) void conv_wino_kernel(const
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[x][mb][tb][r] = 0.f;
 
-    // the K loop, compiled once per column set (BSEL: b in {1, 2} -- four reads per fragment pair -- or {0, 3} -- eight)
+    // the K loop, compiled once per column set (BSEL: b in {1, 2} -- four raw values per fragment pair -- or {0, 3} -- eight).
+    // A software pipeline over K-PAIRS (one K-pair = 2 channels = one MFMA per accumulator block), written slot by slot and pinned
+    // with sched_barriers: left to itself the scheduler sinks every ds_read next to its use and waits lgkmcnt(0) behind it, and
+    // issues the slab's 7 LDS-DMA + 2 MB U loads as one burst behind the barrier -- both waves of a SIMD then sit in the same
+    // LDS / issue latency at the same time and the matrix pipe idles (54 % busy, 62 % of the waves' cycles stalled at issue).
+    //   step i (K-pair i):  slot m = [MFMA m of K-pair i][a share of: VALU of K-pair i + 1, ds_reads of K-pair i + 2, one VMEM]
+    // A tile block's raw values are consumed (BT-row sums) in the first half of a step and re-read for the K-pair after next behind
+    // that, so a raw value is read 3 MB MFMAs (>= 192 cycles) before the VALU that consumes it, in the same registers, and a B
+    // fragment is formed one step before its MFMAs; the U loads of slab s + 1 ride in steps 0 - 1, the patch DMA of slab s + 3 in
+    // steps 2 - 3.  The hand-over (counted vmcnt + s_barrier) for slab s + 1 sits in the MIDDLE of slab s's MFMA stream, behind the
+    // first MFMA of step 2: the first reads of the next patch are issued there, a step and a half before they are needed.
     auto k_loop = [&](auto bsel_tag) {
         constexpr bool BSEL = decltype(bsel_tag)::value;
-        constexpr int NR = BSEL ? 4 : 8;
-        // One slab: barrier, issue the patch DMA of slab s + 2 and the U loads of slab s + 1 (UNCONDITIONALLY, with the slab index
-        // clamped to the last one: behind a branch the compiler's waitcnt pass must assume they were not issued and waits for the
-        // pending fragments with vmcnt(0) -- on the path where they were, that drains the prefetch it just started; the clamped
-        // tail loads go to a ring stage / registers nobody reads), then the MFMAs of slab s on Acur.
-        int buf = 0;
-        auto slab = [&](const int s, wino_f4 (&Acur)[2][MB], wino_f4 (&Anext)[2][MB]) {
-            // everything this wave issued before the previous slab has landed -- its share of THIS slab's patch in particular (the
-            // compiler is free to order a slab's DMA and U loads among themselves: count them all)
-            WINO_WAIT_VMCNT(W_DMA + 2 * MB);
-#if !(SCDA_WINO_ABLATE & 4)
-            __builtin_amdgcn_s_barrier();
-#endif
-#if !(SCDA_WINO_ABLATE & 8)
-            issue_dma(min(s + 2, s_end - 1), (buf + 2) & (W_NST - 1));
-#endif
-            load_a(min(s + 1, s_end - 1), Anext);
-            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch HERE: the scheduler sinks the loads to the end of the slab otherwise
-            const float *st = lds + buf * W_STAGE;
-            const float *r1 = st + ro1, *r2 = st + ro2;
-            float raw[2][2][NR];     // [register buffer][tile block][value]
-            auto read_raw = [&](const int kp, float (&R)[2][NR]) {
-#pragma unroll
-                for (int tb = 0; tb < 2; ++tb) {
+        constexpr int NR = BSEL ? 4 : 8;          // raw values per tile block and K-pair
+        constexpr int NSLOT = 4 * MB;             // MFMAs per K-pair
+        float raw[2][NR];                         // [tile block][value]: K-pair i + 1 until its sums are formed, then K-pair i + 2
+        float pt[2][4];                           // BT-row sums of the K-pair being formed
+        float v[2][2][2];                         // [ring of 2 K-pairs][position][tile block]
+        auto read_unit = [&](const float *st, const int kp, const int tb, const int q) {
 #if (SCDA_WINO_ABLATE & 16)
-                    for (int q = 0; q < NR; ++q) R[tb][q] = sgn;       // ablation: no LDS reads
-                    continue;
+            raw[tb][q] = sgn;                     // ablation: no LDS reads
+            return;
 #endif
-                    const int o = 2 * kp * W_CS + tb * 4 * W_RS;
-                    if (BSEL) {     // columns 1, 2
-                        R[tb][0] = r1[o + 20]; R[tb][1] = r1[o + 1]; R[tb][2] = r2[o + 20]; R[tb][3] = r2[o + 1];
-                    } else {        // columns 0, 2 and 1, 3
-                        R[tb][0] = r1[o]; R[tb][1] = r1[o + 1]; R[tb][2] = r1[o + 20]; R[tb][3] = r1[o + 21];
-                        R[tb][NR - 4] = r2[o]; R[tb][NR - 3] = r2[o + 1]; R[tb][NR - 2] = r2[o + 20]; R[tb][NR - 1] = r2[o + 21];
-                    }
-                }
-            };
-            read_raw(0, raw[0]);
+            const float *r = st + ((q >= NR / 2) ? ro2 : ro1) + 2 * kp * W_CS + tb * 4 * W_RS;
+            // patch columns: BSEL 1, 2 -- slots 20, 1;  otherwise 0, 2, 1, 3 -- slots 0, 1, 20, 21 (odd columns live at 20..)
+            const int qq = q % (NR / 2);
+            raw[tb][q] = r[BSEL ? (qq ? 1 : 20) : (qq == 0 ? 0 : qq == 1 ? 1 : qq == 2 ? 20 : 21)];
+        };
+        auto valu_a = [&](const int tb) {         // BT row a over the two patch rows
 #pragma unroll
-            for (int kp = 0; kp < WBK / 2; ++kp) {
-                const int cur = kp & 1;
-                if (kp + 1 < WBK / 2) read_raw(kp + 1, raw[cur ^ 1]);
-                float v[2][2];
-#pragma unroll
-                for (int tb = 0; tb < 2; ++tb) {
-                    const float (&R)[NR] = raw[cur][tb];
-                    if (BSEL) {
-                        const float p1 = R[0] + sgn * R[2], p2 = R[1] + sgn * R[3];
-                        v[0][tb] = p1 + p2;      // b = 1: d1 + d2
-                        v[1][tb] = p2 - p1;      // b = 2: d2 - d1
-                    } else {
-                        const float p0 = R[0] + sgn * R[NR - 4], p2 = R[1] + sgn * R[NR - 3], p1 = R[2] + sgn * R[NR - 2], p3 = R[3] + sgn * R[NR - 1];
-                        v[0][tb] = p0 - p2;      // b = 0: d0 - d2
-                        v[1][tb] = p1 - p3;      // b = 3: d1 - d3
-                    }
-                }
-#pragma unroll
-                for (int x = 0; x < 2; ++x)
-#pragma unroll
-                    for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                        for (int tb = 0; tb < 2; ++tb)
-                            acc[x][mb][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(Acur[x][mb][kp], v[x][tb], acc[x][mb][tb], 0, 0, 0);
+            for (int q = 0; q < NR / 2; ++q) {
+                WINO_PIN(raw[tb][q]);
+                pt[tb][q] = raw[tb][q] + sgn * raw[tb][q + NR / 2];
+                WINO_PIN(pt[tb][q]);
             }
-            buf = (buf + 1) & (W_NST - 1);
+        };
+        auto valu_b = [&](const int tb, float (&V)[2][2]) {
+            if (BSEL) {
+                V[0][tb] = pt[tb][0] + pt[tb][1];        // b = 1: d1 + d2
+                V[1][tb] = pt[tb][1] - pt[tb][0];        // b = 2: d2 - d1
+            } else {
+                V[0][tb] = pt[tb][0] - pt[tb][1];        // b = 0: d0 - d2
+                V[1][tb] = pt[tb][2] - pt[tb][3];        // b = 3: d1 - d3
+            }
+            WINO_PIN(V[0][tb]);
+            WINO_PIN(V[1][tb]);
+        };
+        // one step = the MFMAs of K-pair kp of the slab in ring stage `buf`
+        auto step = [&](const int kp, const int s, const int buf, wino_f4 (&Acur)[2][MB], wino_f4 (&Anext)[2][MB]) {
+            const float *rst = lds + ((buf + (kp >= 2 ? 1 : 0)) & (W_NST - 1)) * W_STAGE;
+            const int rkp = (kp + 2) & 3, rb = kp & 1;
+#pragma unroll
+            for (int m = 0; m < NSLOT; ++m) {
+                const int x = m / (2 * MB), mb = (m / 2) % MB, tb = m & 1;
+                WINO_PIN(v[rb][x][tb]);
+                acc[x][mb][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(Acur[x][mb][kp], v[rb][x][tb], acc[x][mb][tb], 0, 0, 0);
+                WINO_PIN(acc[x][mb][tb]);
+                if (kp == 2 && m == 0) {
+                    // hand-over for the NEXT slab behind an MFMA: this wave's share of its patch has landed -- younger than it are only
+                    // the U loads of two slabs and one slab's DMA
+                    __builtin_amdgcn_sched_barrier(0);
+                    WINO_WAIT_VMCNT(W_DMA + 4 * MB);
+#if !(SCDA_WINO_ABLATE & 4)
+                    __builtin_amdgcn_s_barrier();
+#endif
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // quarter h of the step: sums of tile block h >> 1 (h even), its fragments + its re-read (h odd)
+                const int h4 = m / MB, sub = m % MB;
+                if ((h4 & 1) == 0) {
+                    if (sub == MB - 1) valu_a(h4 >> 1);
+                } else {
+#pragma unroll
+                    for (int q = sub * (NR / MB); q < (sub + 1) * (NR / MB); ++q) read_unit(rst, rkp, h4 >> 1, q);
+                    if (sub == MB - 1) valu_b(h4 >> 1, v[rb ^ 1]);
+                }
+                // VMEM, issued UNCONDITIONALLY with clamped slab indices (behind a branch the compiler's waitcnt pass must assume the
+                // loads were not issued and drains the prefetch with vmcnt(0); the clamped tail loads go to a stage / registers nobody reads)
+                if (kp < 2) {
+                    const int um = (m == 0) ? 0 : (MB == 2 && m == 4) ? 1 : -1;
+                    if (um >= 0) load_a_one(min(s + 1, s_end - 1), kp, um, Anext);
+                } else {
+#if !(SCDA_WINO_ABLATE & 8)
+                    const int di = MB == 2 ? ((m & 1) ? -1 : (kp - 2) * 4 + (m >> 1)) : (kp - 2) * 4 + m;
+                    if (di >= 0 && di < W_DMA) issue_dma_one(min(s + 3, s_end - 1), (buf + 3) & (W_NST - 1), di);
+#endif
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        auto slab = [&](const int s, const int buf, wino_f4 (&Acur)[2][MB], wino_f4 (&Anext)[2][MB]) {
+#pragma unroll
+            for (int kp = 0; kp < WBK / 2; ++kp) step(kp, s, buf, Acur, Anext);
         };
         wino_f4 A0[2][MB], A1[2][MB];
+        // VMEM order of the start-up = the steady state's (patch, patch, U, patch): the compiler's counted waits for the U fragments at
+        // the loop head are the minimum over both ways into it
         issue_dma(s_begin, 0);
-        __builtin_amdgcn_sched_barrier(0);   // the first slab's patch is the OLDEST request: slab()'s counted wait relies on it
+        __builtin_amdgcn_sched_barrier(0);
         issue_dma(min(s_begin + 1, s_end - 1), 1);
+        __builtin_amdgcn_sched_barrier(0);
         load_a(s_begin, A0);
-        int s = s_begin;
-        for (; s + 1 < s_end; s += 2) {
-            slab(s, A0, A1);
-            slab(s + 1, A1, A0);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_dma(min(s_begin + 2, s_end - 1), 2);
+        __builtin_amdgcn_sched_barrier(0);
+        WINO_WAIT_VMCNT(2 * W_DMA + 2 * MB);
+        __builtin_amdgcn_s_barrier();
+        {   // fill the pipeline: B fragments of K-pair 0, raw values of K-pair 1
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+                for (int q = 0; q < NR; ++q) read_unit(lds, 0, tb, q);
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb) { valu_a(tb); valu_b(tb, v[0]); }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+                for (int q = 0; q < NR; ++q) read_unit(lds, 1, tb, q);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (s < s_end) slab(s, A0, A1);
+        int s = s_begin, buf = 0;
+        for (; s + 1 < s_end; s += 2) {
+            slab(s, buf, A0, A1);
+            slab(s + 1, (buf + 1) & (W_NST - 1), A1, A0);
+            buf = (buf + 2) & (W_NST - 1);
+        }
+        if (s < s_end) slab(s, buf, A0, A1);
         WINO_WAIT_VMCNT(0);              // the clamped tail DMA must not land in the exchange buffer below
     };
     if (!(e.dbg & 2)) { if (bsel) k_loop(std::true_type{}); else k_loop(std::false_type{}); }
