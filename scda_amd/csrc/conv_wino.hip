@@ -501,28 +501,30 @@ __global__ __launch_bounds__(512, 2) void conv_wino_wgrad_kernel(const float *__
         g.dTY.divmod(t, q_img, q_ty);
     }
     int q_s = s_begin;
-    auto issue_dma = [&](const int buf) {
-        const char *yb = reinterpret_cast<const char *>(dY + ((size_t)q_img * g.M + m0) * plane);
-        const char *xb = reinterpret_cast<const char *>(X + ((size_t)q_img * g.C + c0) * plane) - (g.W + 1) * 4;
-        const int soff = (2 * q_ty * g.W + 16 * q_tx) * 4;
-        const unsigned edge = (unsigned)(q_ty == 0) | ((unsigned)(q_ty == g.TY - 1) << 1) | ((unsigned)(q_tx == 0) << 2) | ((unsigned)(q_tx == g.TX - 1) << 3);
-        float *dst = lds + buf * G_STAGE + wave * (G_DMA * 64);
-        const bool part = rem != 0 && q_tx == g.TX - 1;
-        if (edge == 0 && !part) {     // interior slab (most): the lane offsets as they are
-#pragma unroll
-            for (int i = 0; i < G_DMA; ++i) wino_dma_b32(wave * G_DMA + i < G_YR ? yb : xb, dma_off[i], dst + i * 64, soff);
-        } else {
-            const unsigned pm = part ? pbits : 0u;
-#pragma unroll
-            for (int i = 0; i < G_DMA; ++i) {
-                const unsigned off = (((unsigned)(xbits >> (4 * i)) & edge) | ((pm >> i) & 1u)) ? 0x80000000u : dma_off[i];
-                wino_dma_b32(wave * G_DMA + i < G_YR ? yb : xb, off, dst + i * 64, soff);
-            }
-        }
+    // one slab's issue, in pieces the K loop spreads over its MFMA slots: the scalars of the slab under the cursor, one instruction
+    // at a time (the halo's validity: per-lane constant bits ANDed with the slab's edge scalar -- zero for interior slabs), the advance
+    const char *d_yb = nullptr, *d_xb = nullptr;
+    int d_soff = 0;
+    unsigned d_edge = 0, d_pm = 0;
+    auto dma_prepare = [&]() {
+        d_yb = reinterpret_cast<const char *>(dY + ((size_t)q_img * g.M + m0) * plane);
+        d_xb = reinterpret_cast<const char *>(X + ((size_t)q_img * g.C + c0) * plane) - (g.W + 1) * 4;
+        d_soff = (2 * q_ty * g.W + 16 * q_tx) * 4;
+        d_edge = (unsigned)(q_ty == 0) | ((unsigned)(q_ty == g.TY - 1) << 1) | ((unsigned)(q_tx == 0) << 2) | ((unsigned)(q_tx == g.TX - 1) << 3);
+        d_pm = (rem != 0 && q_tx == g.TX - 1) ? pbits : 0u;
         if (q_s + 1 < s_end) {
             ++q_s;
             if (++q_tx == g.TX) { q_tx = 0; if (++q_ty == g.TY) { q_ty = 0; ++q_img; } }
         }
+    };
+    auto dma_one = [&](const int buf, const int i) {
+        const unsigned off = (((unsigned)(xbits >> (4 * i)) & d_edge) | ((d_pm >> i) & 1u)) ? 0x80000000u : dma_off[i];
+        wino_dma_b32(wave * G_DMA + i < G_YR ? d_yb : d_xb, off, lds + buf * G_STAGE + wave * (G_DMA * 64) + i * 64, d_soff);
+    };
+    auto issue_dma = [&](const int buf) {
+        dma_prepare();
+#pragma unroll
+        for (int i = 0; i < G_DMA; ++i) dma_one(buf, i);
     };
 
     // ---- this wave's two positions ------------------------------------------------------------------------------------------------
@@ -550,83 +552,117 @@ __global__ __launch_bounds__(512, 2) void conv_wino_wgrad_kernel(const float *__
                 for (int r = 0; r < 16; ++r) acc[x][mb][cb][r] = 0.f;
     float rs[2] = {0.f, 0.f};
 
+    // The K loop: the forward kernel's slot pipeline (see there).  Step i = K-pair i (2 tiles): slot m = [MFMA m][a share of: VALU of
+    // K-pair i + 1 -- Z = A dY A^T and V = B^T d B on 8-byte register pairs --, the 8-byte ds_reads of K-pair i + 2 into the registers
+    // just consumed, one LDS-DMA of slab s + 3]; the hand-over for slab s + 1 behind the first MFMA of step 2.
     auto k_loop = [&](auto bsel_tag) {
         constexpr bool BSEL = decltype(bsel_tag)::value;
-        int buf = 0;
-        auto slab = [&]() {
-            WINO_WAIT_VMCNT(G_DMA);      // this wave's share of THIS slab's patches has landed (only the previous slab's issue is younger)
-#if !(SCDA_WINO_ABLATE & 128)
-            __builtin_amdgcn_s_barrier();
-#endif
-#if !(SCDA_WINO_ABLATE & 64)
-            issue_dma((buf + 2) & (G_NST - 1));
-#endif
-            __builtin_amdgcn_sched_barrier(0);
-            const float *st = lds + buf * G_STAGE;
-            // raw values stay in the 8-byte pairs they are read as; the transforms are written on the pairs (packed fp32 math on
-            // natural register pairs -- element-wise code made the compiler assemble pairs with ~50 v_mov per slab)
-            wino_f2 ry[2][2][2], rx[2][2][4];     // [register buffer][block][pair]
-            auto read_raw = [&](const int kp, wino_f2 (&Y)[2][2], wino_f2 (&R)[2][4]) {
-                // 8-byte reads at immediate offsets from three lane addresses (every offset below is a multiple of 2 floats)
+        // raw values stay in the 8-byte pairs they are read as; the transforms are written on the pairs (packed fp32 math on
+        // natural register pairs -- element-wise code made the compiler assemble pairs with ~50 v_mov per slab)
+        wino_f2 ry[2][2], rx[2][4];          // [block][pair]: K-pair i + 1 until consumed, then K-pair i + 2
+        float z[2][2][2], v[2][2][2];        // [ring of 2 K-pairs][position][block]
+        auto read_y = [&](const float *st, const int kp, const int mb) {
+            // 8-byte reads at immediate offsets from three lane addresses (every offset below is a multiple of 2 floats)
 #if (SCDA_WINO_ABLATE & 32)
-                for (int mb = 0; mb < 2; ++mb) { Y[mb][0] = wino_f2{sgn, ya}; Y[mb][1] = wino_f2{ya, sgn}; }
-                for (int cb = 0; cb < 2; ++cb) for (int q = 0; q < 4; ++q) R[cb][q] = wino_f2{sgn, yb2};
-                return;
+            ry[mb][0] = wino_f2{sgn, ya}; ry[mb][1] = wino_f2{ya, sgn};
+            return;
 #endif
-#pragma unroll
-                for (int mb = 0; mb < 2; ++mb) {
-                    const float *p = st + yo + mb * (32 * G_YS) + 4 * kp;
-                    Y[mb][0] = *reinterpret_cast<const wino_f2 *>(p);          // tile row 0: (q = 0, q = 1)
-                    Y[mb][1] = *reinterpret_cast<const wino_f2 *>(p + 16);     // tile row 1
-                }
-#pragma unroll
-                for (int cb = 0; cb < 2; ++cb) {
-                    const float *p1 = st + xo1 + cb * (32 * G_XS) + 4 * kp, *p2 = st + xo2 + cb * (32 * G_XS) + 4 * kp;
-                    R[cb][0] = *reinterpret_cast<const wino_f2 *>(p1);         // patch row i1: columns (0, 1)
-                    R[cb][1] = *reinterpret_cast<const wino_f2 *>(p1 + 2);     //               columns (2, 3)
-                    R[cb][2] = *reinterpret_cast<const wino_f2 *>(p2);         // patch row i2
-                    R[cb][3] = *reinterpret_cast<const wino_f2 *>(p2 + 2);
-                }
-            };
-            read_raw(0, ry[0], rx[0]);
-#pragma unroll
-            for (int kp = 0; kp < 4; ++kp) {
-                const int cur = kp & 1;
-                if (kp + 1 < 4) read_raw(kp + 1, ry[cur ^ 1], rx[cur ^ 1]);
-                float z[2][2], v[2][2];
-#pragma unroll
-                for (int mb = 0; mb < 2; ++mb) {
-                    const wino_f2 sq = ya * ry[cur][mb][0] + yb2 * ry[cur][mb][1];            // A row a over the tile's two rows: (s0, s1)
-                    if (BSEL) { z[0][mb] = sq[0] + sq[1]; z[1][mb] = sq[0] - sq[1]; }         // b = 1, 2
-                    else { z[0][mb] = sq[0]; z[1][mb] = -sq[1]; }                             // b = 0, 3
-                }
-#pragma unroll
-                for (int cb = 0; cb < 2; ++cb) {
-                    const wino_f2 p01 = rx[cur][cb][0] + sgn * rx[cur][cb][2], p23 = rx[cur][cb][1] + sgn * rx[cur][cb][3];   // BT row a: (p0, p1), (p2, p3)
-                    if (BSEL) {
-                        v[0][cb] = p01[1] + p23[0];       // b = 1: d1 + d2
-                        v[1][cb] = p23[0] - p01[1];       // b = 2: d2 - d1
-                    } else {
-                        const wino_f2 d = p01 - p23;      // b = 0: d0 - d2;  b = 3: d1 - d3
-                        v[0][cb] = d[0];
-                        v[1][cb] = d[1];
-                    }
-                }
-#pragma unroll
-                for (int x = 0; x < 2; ++x)
-#pragma unroll
-                    for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-                        for (int cb = 0; cb < 2; ++cb)
-                            acc[x][mb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(z[x][mb], v[x][cb], acc[x][mb][cb], 0, 0, 0);
-                if (BSEL && bias_wave) { rs[0] += z[0][0]; rs[1] += z[0][1]; }     // position (1, 1): the tile's four dY values summed
+            const float *p = st + yo + mb * (32 * G_YS) + 4 * kp;
+            ry[mb][0] = *reinterpret_cast<const wino_f2 *>(p);          // tile row 0: (q = 0, q = 1)
+            ry[mb][1] = *reinterpret_cast<const wino_f2 *>(p + 16);     // tile row 1
+        };
+        auto read_x = [&](const float *st, const int kp, const int cb) {
+#if (SCDA_WINO_ABLATE & 32)
+            for (int q = 0; q < 4; ++q) rx[cb][q] = wino_f2{sgn, yb2};
+            return;
+#endif
+            const float *p1 = st + xo1 + cb * (32 * G_XS) + 4 * kp, *p2 = st + xo2 + cb * (32 * G_XS) + 4 * kp;
+            rx[cb][0] = *reinterpret_cast<const wino_f2 *>(p1);         // patch row i1: columns (0, 1)
+            rx[cb][1] = *reinterpret_cast<const wino_f2 *>(p1 + 2);     //               columns (2, 3)
+            rx[cb][2] = *reinterpret_cast<const wino_f2 *>(p2);         // patch row i2
+            rx[cb][3] = *reinterpret_cast<const wino_f2 *>(p2 + 2);
+        };
+        auto valu_z = [&](const int mb, float (&Z)[2][2]) {
+            WINO_PIN(ry[mb][0]);
+            const wino_f2 sq = ya * ry[mb][0] + yb2 * ry[mb][1];                      // A row a over the tile's two rows: (s0, s1)
+            if (BSEL) { Z[0][mb] = sq[0] + sq[1]; Z[1][mb] = sq[0] - sq[1]; }         // b = 1, 2
+            else { Z[0][mb] = sq[0]; Z[1][mb] = -sq[1]; }                             // b = 0, 3
+            WINO_PIN(Z[0][mb]);
+            WINO_PIN(Z[1][mb]);
+        };
+        auto valu_v = [&](const int cb, float (&V)[2][2]) {
+            WINO_PIN(rx[cb][0]);
+            const wino_f2 p01 = rx[cb][0] + sgn * rx[cb][2], p23 = rx[cb][1] + sgn * rx[cb][3];   // BT row a: (p0, p1), (p2, p3)
+            if (BSEL) {
+                V[0][cb] = p01[1] + p23[0];       // b = 1: d1 + d2
+                V[1][cb] = p23[0] - p01[1];       // b = 2: d2 - d1
+            } else {
+                const wino_f2 d = p01 - p23;      // b = 0: d0 - d2;  b = 3: d1 - d3
+                V[0][cb] = d[0];
+                V[1][cb] = d[1];
             }
-            buf = (buf + 1) & (G_NST - 1);
+            WINO_PIN(V[0][cb]);
+            WINO_PIN(V[1][cb]);
+        };
+        auto step = [&](const int kp, const int buf) {
+            const float *rst = lds + ((buf + (kp >= 2 ? 1 : 0)) & (G_NST - 1)) * G_STAGE;
+            const int rkp = (kp + 2) & 3, rb = kp & 1;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const int x = m >> 2, mb = (m >> 1) & 1, cb = m & 1;
+                WINO_PIN(v[rb][x][cb]);
+                acc[x][mb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(z[rb][x][mb], v[rb][x][cb], acc[x][mb][cb], 0, 0, 0);
+                WINO_PIN(acc[x][mb][cb]);
+                if (kp == 2 && m == 0) {
+                    // hand-over for the NEXT slab behind an MFMA: this wave's share of its patches has landed (only one slab's issue is younger)
+                    __builtin_amdgcn_sched_barrier(0);
+                    WINO_WAIT_VMCNT(G_DMA);
+#if !(SCDA_WINO_ABLATE & 128)
+                    __builtin_amdgcn_s_barrier();
+#endif
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (kp == 1 && m == 4) dma_prepare();       // (scalar work only: the slab the issue-side cursor is on, ahead of the hand-over)
+                if (m == 0 && BSEL && bias_wave) { rs[0] += z[rb][0][0]; rs[1] += z[rb][0][1]; }     // position (1, 1): the tile's four dY values summed
+                if (m == 1) { valu_z(0, z[rb ^ 1]); valu_z(1, z[rb ^ 1]); }
+                if (m == 2) { read_y(rst, rkp, 0); read_y(rst, rkp, 1); }
+                if (m == 3) valu_v(0, v[rb ^ 1]);
+                if (m == 4) read_x(rst, rkp, 0);
+                if (m == 5) valu_v(1, v[rb ^ 1]);
+                if (m == 6) read_x(rst, rkp, 1);
+#if !(SCDA_WINO_ABLATE & 64)
+                if (kp >= 2) {
+                    const int di = (kp - 2) * 8 + m - (kp == 3 ? 1 : 0);      // 14 instructions over the 16 slots of steps 2 and 3
+                    if (di >= 0 && di < G_DMA && !(kp == 2 && m == 7)) dma_one((buf + 3) & (G_NST - 1), di);
+                }
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+            }
         };
         issue_dma(0);
         __builtin_amdgcn_sched_barrier(0);
         issue_dma(1);
-        for (int s = s_begin; s < s_end; ++s) slab();
+        __builtin_amdgcn_sched_barrier(0);
+        issue_dma(2);
+        __builtin_amdgcn_sched_barrier(0);
+        WINO_WAIT_VMCNT(2 * G_DMA);
+        __builtin_amdgcn_s_barrier();
+        {   // fill the pipeline: fragments of K-pair 0, raw values of K-pair 1
+#pragma unroll
+            for (int b = 0; b < 2; ++b) { read_y(lds, 0, b); read_x(lds, 0, b); }
+#pragma unroll
+            for (int b = 0; b < 2; ++b) { valu_z(b, z[0]); valu_v(b, v[0]); }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) { read_y(lds, 1, b); read_x(lds, 1, b); }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        int buf = 0;
+        for (int s = s_begin; s < s_end; ++s) {
+#pragma unroll
+            for (int kp = 0; kp < 4; ++kp) step(kp, buf);
+            buf = (buf + 1) & (G_NST - 1);
+        }
         WINO_WAIT_VMCNT(0);
     };
     if (bsel) k_loop(std::true_type{}); else k_loop(std::false_type{});
