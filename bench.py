@@ -58,7 +58,11 @@ for _k in CFG:
 H, W, G = 512, 1024, 12
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 F_ITER_TFLOP = 2.255          # necessary conv / FC / convT work of one iteration
-PMC_TRAFFIC_FILES = ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
+PMC_TRAFFIC_FILES = ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
+# Winograd-eligible share of F_iter (direct-form TFLOP of the launches the F(2x2,3x3) kernels take; scripts/wino_iteration_flops.py
+# sums the library's launch log of one iteration): detector forward + data gradient 0.9857, its weight gradients 0.3286, the SCDA
+# nets' stride-1 3x3 layers (decoder residual / up-sampling convolutions, forward + both gradients).  F_exec = F_iter - eligible * (1 - 1/2.25)
+WINO_ELIGIBLE_TFLOP = {"detector fwd + dgrad": 0.9857, "detector wgrad": 0.3286, "scda nets": 0.3600}
 DOMINANT_SMALL_TILES = "conv_igemm_glds_kernel<64,*,3,3,1,fwd>"
 DOMINANT = "conv_igemm_glds_kernel<128|256,*,3,3,1,fwd>"   # the instantiations with 128 or 256 tile rows (256 = 8 waves), any tile width, 3x3 stride 1, forward
 # with the Winograd kernel (the default): every stride-1 3x3 forward with >= 64 channels is a launch of this ONE kernel (VGG 12 + RPN 1
@@ -124,6 +128,12 @@ def synth_batch(rank, H=H, W=W):
 
 
 def pmc_traffic(kernel, prefix=""):
+    """-> (bytes per launch, source file, launches averaged, algorithmic bytes per launch of the SAME launches or None)"""
+    t = _pmc_traffic(kernel, prefix)
+    return t if t[0] is not None else (None, None, None, None)
+
+
+def _pmc_traffic(kernel, prefix=""):
     """L2 memory-side bytes per launch of the dominant kernel.  PMC counters cannot be sampled from inside the timed
     run; they come from the committed rocprofv3 passes of this same command (scripts/collect_profiles.sh ->
     profiles/r01_pmc_traffic.json: `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` in separate passes, FETCH_SIZE doubled as
@@ -133,12 +143,15 @@ def pmc_traffic(kernel, prefix=""):
             name = name.replace("_pmc_traffic", "_" + prefix + "pmc_traffic") if prefix else name
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 d = json.load(f)
-            if d["dominant"].get("kernel", DOMINANT).split("<")[0] != kernel.split("<")[0]:
-                continue              # a counter pass of another kernel says nothing about this one
-            return int(d["dominant"]["traffic_bytes_per_launch"]), "profiles/" + name
+            if d["dominant"].get("kernel", DOMINANT) != kernel:
+                continue              # a counter pass of another kernel (or another class of it) says nothing about this one
+            like = d.get("dominant_detector_launches")
+            if like:                  # joined per dispatch: exactly the launches the in-library profiler times (detector forward + data gradient)
+                return int(like["traffic_bytes_per_launch"]), "profiles/" + name, int(like["launches"]), int(like["algorithmic_bytes_per_launch"])
+            return int(d["dominant"]["traffic_bytes_per_launch"]), "profiles/" + name, int(d["dominant"].get("launches", 0)), None
         except Exception:
             continue
-    return None, None
+    return None, None, None, None
 
 
 def cpu_baseline():
@@ -359,12 +372,18 @@ def main():
         if dominant in prof:
             n, tms, fl, by = prof[dominant]
             ach = fl / (tms * 1e-3) / 1e12
-            traffic, src = pmc_traffic(dominant, "" if a.config == "vgg16" else "resnet50_")   # the committed counter passes of this configuration
+            # the committed counter passes of THIS configuration (none exist for the mask configuration: traffic stays null there)
+            traffic, src, t_n, t_alg = pmc_traffic(dominant, {"vgg16": "", "resnet50": "resnet50_", "maskrcnn": "maskrcnn_"}[a.config])
             it_ach = f_iter * world * a.steps / dt
+            f_exec = f_iter - sum(WINO_ELIGIBLE_TFLOP.values()) * (1.0 - 1.0 / WINO_RATIO) if (wino and a.config == "vgg16") else None
             roof = {"bound": "mfma", "kernel": dominant, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                     "traffic_unit": "bytes/launch (HBM+Infinity-Cache side of L2: 2*FETCH_SIZE + WRITE_SIZE)", "traffic_source": src,
                     "algorithmic_bytes_per_launch": round(by / n), "launches": n, "avg_launch_ms": round(tms / n, 4),
+                    # like for like: the counter passes' average over the same launch population (joined per dispatch with the layer
+                    # each ran), against THAT population's algorithmic bytes
+                    "traffic_launches": t_n, "traffic_algorithmic_bytes_per_launch": t_alg,
+                    "traffic_over_algorithmic": round(traffic / t_alg, 3) if traffic and t_alg else None,
                     "gflop_per_launch": round(fl / n / 1e9, 2),
                     **({"flop_definition": "MFMA work the Winograd F(2x2,3x3) kernel executes (16 products per 2x2 output tile and channel "
                                            "pair) = the direct convolution's / 2.25",
@@ -375,7 +394,12 @@ def main():
                     "template_all_tiles": template,
                     "iteration": {"achieved": round(it_ach / world, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s per GPU",
                                   "frac": round(it_ach / world / PEAK_F32_MFMA_TFLOPS, 4),
-                                  "definition": "F_iter (%.3f TFLOP of necessary conv/FC work per iteration) x iterations/s" % f_iter}}
+                                  "definition": "F_iter (%.3f TFLOP of necessary conv/FC work per iteration) x iterations/s" % f_iter},
+                    "iteration_executed": None if f_exec is None else {
+                        "achieved": round(f_exec * a.steps / dt, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s per GPU",
+                        "frac": round(f_exec * a.steps / dt / PEAK_F32_MFMA_TFLOPS, 4), "f_exec_tflop": round(f_exec, 3),
+                        "definition": "F_exec = F_iter with the Winograd-eligible %.3f TFLOP counted at the 16 / 36 of them the kernels "
+                                      "execute; x iterations/s -- a fraction of a bound again" % sum(WINO_ELIGIBLE_TFLOP.values())}}
         res = {
             "metric": "images/sec (fwd+bwd) VGG16 Faster-RCNN+SCDA 512x1024" if a.config == "vgg16" else
                       "images/sec (fwd+bwd) ResNet-50-C4 Faster-RCNN+SCDA 800x1344 (performance-only configuration)"

@@ -27,6 +27,7 @@
 // Epilogue: the 16 positions of an output tile live in 8 different waves: exchanged through LDS (32 rows at a time, 128 KB), then
 // every thread applies A^T . A to its (channel, tile) pairs and stores 2 x 2 pixels (+ bias, activation, the producer's act' mask
 // -- or a split-K slab in the natural pixel order, combined by conv_gemm.hip's reduce kernel).
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <algorithm>
@@ -750,6 +751,16 @@ SCDA_API int scda_conv2d_wino_pack_hip(const float *w, float *out, int Cout, int
 static thread_local int g_wino_last[4] = {0, 0, 0, 0};          // forward / data gradient: tile rows / 32, pixel-block-major?, gm, splits
 static thread_local int g_wino_wgrad_last[2] = {0, 0};          // weight gradient: splits, 0 as they come / 1 whole splits per XCD / 2 split + m-tile group
 
+// evidence aid (scripts/pmc_summary.py): SCDA_WINO_LOG=<file> appends one line per launch of the three kernels, in launch order --
+// kind, tile rows / 32, workgroups, shape, split count and the launch's ALGORITHMIC bytes (operands once + result once) -- so that
+// a counter pass's dispatches can be joined with the layers they ran
+static void wino_log(const char *kind, int mb, long long wgs, int batch, int C, int H, int W, int M, int splits, double bytes, double flops) {
+    static FILE *f = [] { const char *p = getenv("SCDA_WINO_LOG"); return p && *p ? fopen(p, "a") : (FILE *)nullptr; }();
+    if (!f) return;
+    fprintf(f, "%s %d %lld %d %d %d %d %d %d %.0f %.0f\n", kind, mb, wgs, batch, C, H, W, M, splits, bytes, flops);
+    fflush(f);
+}
+
 static int wino_launch(const float *x, const float *u, const float *bias, float *y, int batch, int C, int H, int W, int M, int act,
                        float slope, const float *mask_src, float mask_slope, int for_dgrad, void *ws, size_t ws_bytes, void *stream,
                        float *pool_y, unsigned char *pool_idx) {
@@ -818,8 +829,10 @@ static int wino_launch(const float *x, const float *u, const float *bias, float 
     static const int dbg = getenv("SCDA_WINO_DBG") ? atoi(getenv("SCDA_WINO_DBG")) : 0;
     WinoEpi e{y, (float *)ws, bias, act, slope, splits, mask_src, mask_slope, dbg, pool_y, pool_idx};
     // flops = the MFMA work the kernel EXECUTES (16 products per 2x2 tile and channel pair: the direct form's 36 / 2.25)
-    prof_begin(for_dgrad ? PK_WINO_DGRAD : PK_WINO_FWD, 2.0 * M * (double)batch * H * W * C * 4, st,
-               4.0 * ((double)batch * C * H * W + 9.0 * M * C + (double)batch * M * H * W));
+    // algorithmic bytes: input once, filters once, result once (fused pool: the pooled map and its winners instead of the full map)
+    const double out_bytes = pool_y ? 1.25 * batch * M * H * W : 4.0 * batch * M * H * W;
+    const double alg_bytes = 4.0 * ((double)batch * C * H * W + 9.0 * M * C) + out_bytes;
+    prof_begin(for_dgrad ? PK_WINO_DGRAD : PK_WINO_FWD, 2.0 * M * (double)batch * H * W * C * 4, st, alg_bytes);
     long long wgs = tiles * splits;
     if (g.pixel_major) {      // 8 / gm runs of per_xcd (split, pixel block) items x n_mt m-tiles; the last run may hold idle workgroups
         const int gp = 8 / gm;
@@ -827,6 +840,7 @@ static int wino_launch(const float *x, const float *u, const float *bias, float 
         wgs = 8LL * g.per_xcd * (g.n_mt / gm);
     }
     g_wino_last[0] = MBv; g_wino_last[1] = g.pixel_major; g_wino_last[2] = gm; g_wino_last[3] = splits;
+    wino_log(pool_y ? "fwd_pool" : for_dgrad ? "dgrad" : "fwd", MBv, wgs, batch, C, H, W, M, splits, alg_bytes, 2.0 * M * (double)batch * H * W * C * 4);
     if (MBv == 2) hipLaunchKernelGGL(conv_wino_kernel<2>, dim3((unsigned)wgs), dim3(512), 0, st, u, x, g, e);
     else hipLaunchKernelGGL(conv_wino_kernel<1>, dim3((unsigned)wgs), dim3(512), 0, st, u, x, g, e);
     prof_end(st);
@@ -877,6 +891,8 @@ SCDA_API int scda_conv2d_wino_wgrad_hip(const float *dy, const float *x, float *
         g.dNML = Div(n_mt / (8 / splits));
     }
     g_wino_wgrad_last[0] = splits; g_wino_wgrad_last[1] = g.splits_per_xcd > 0 ? 1 : g.sp_shift >= 0 ? 2 : 0;
+    wino_log("wgrad", 2, tiles * splits, batch, Cin, H, W, Cout, splits, 4.0 * ((double)batch * (Cin + Cout) * H * W + 9.0 * Cout * Cin),
+             2.0 * Cout * (double)batch * H * W * Cin * 4);
     hipLaunchKernelGGL(conv_wino_wgrad_kernel, dim3((unsigned)(tiles * splits)), dim3(512), 0, st, dy, x, g, wsf, db_ws);
     prof_end(st);
     int rc = launch_status("conv_wino_wgrad_kernel");

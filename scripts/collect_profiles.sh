@@ -14,8 +14,10 @@ python $R/bench.py --steps 30 --warmup 8 > $OUT/bench_1gpu.json 2> $OUT/bench_1g
 export SCDA_BENCH_NO_TEMPLATE_PASS=1   # the traces below hold exactly warm-up + timed iterations
 rocprofv3 --kernel-trace --stats -d $OUT/kt -o prof -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/kt.log 2>&1
 grep '^{' $OUT/kt.log > $OUT/bench_under_rocprof.json
+# (graphs off + the library's launch log: every Winograd dispatch of these two passes is joined with its layer by pmc_summary.py)
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_$c.log 2>&1
+  rm -f $OUT/wino_log_$c.txt
+  SCDA_GAN_GRAPH=0 SCDA_WINO_LOG=$OUT/wino_log_$c.txt rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_$c.log 2>&1
 done
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_mfma -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_mfma.log 2>&1
 cd $R
