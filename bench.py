@@ -410,7 +410,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "collective": {"backend": ("rccl (torch.distributed 'nccl')" if backend == "nccl" else backend) if world > 1 else None,
                            "ranks": dist.get_world_size() if world > 1 else 1,
-                           "all_reduces_per_step": 4 if world > 1 else 0},
+                           # dis, dis_patch, dec + the detector's bucket in two pieces (classifier + heads from inside the backward)
+                           "all_reduces_per_step": (5 if getattr(tr, "_det_early_span", lambda: None)() else 4) if world > 1 else 0},
             "config": {"workload": ("vgg16_FasterRCNN + 4-cluster SCDA, synthetic Cityscapes->Foggy 512x1024, batch=1/GPU "
                                     "(BASELINE.json configs[1]); 1 step = 1 source + 1 target image, 4 optimiser phases")
                        if a.config == "vgg16" else

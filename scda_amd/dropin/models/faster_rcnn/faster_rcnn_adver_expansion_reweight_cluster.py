@@ -194,7 +194,11 @@ class FasterRCNN_AdEx(nn.Module):
         rois, cls_targets, loc_targets, loc_weights = fn['proposal_target_fn'](proposals)
         mark('src_proposal_targets')
         assert rois.shape[1] == 5
-        x_fea, rcnn_cls, rcnn_loc = self.rcnn(feat, rois)
+        self._head_grad_hook = input.get('_after_head_backward')     # '_after_head_backward': see VGG.rcnn / SegmentedReduce
+        try:
+            x_fea, rcnn_cls, rcnn_loc = self.rcnn(feat, rois)
+        finally:
+            self._head_grad_hook = None
         mark('src_rcnn_enqueued')
         rcnn_loss_cls, rcnn_loss_loc, rcnn_acc = self._add_rcnn_loss(rcnn_cls, rcnn_loc, cls_targets, loc_targets, loc_weights)
         losses = [rpn_loss_cls, rpn_loss_loc, rcnn_loss_cls, rcnn_loss_loc]

@@ -40,6 +40,10 @@ def make_layers(plan, batch_norm=False):
 
 
 class VGG(FasterRCNN_AdEx):
+    # parameters whose gradients are final once the RoI-pooled features' gradient exists (everything behind the pooling): the
+    # data-parallel step starts their share of the gradient all-reduce from a hook there (SegmentedReduce)
+    EARLY_REDUCE_PREFIXES = ('classifier.', 'fc_rcnn_cls.', 'fc_rcnn_loc.')
+
     def __init__(self, features, cfg):
         super().__init__(cfg['gan_model_flag'])
         # the last pooling layer is dropped so that the feature stride is 16 (reference :38)
@@ -66,6 +70,9 @@ class VGG(FasterRCNN_AdEx):
     def rcnn(self, x, rois):
         assert rois.shape[1] == 5
         pooled = self.roipooling(x, rois)          # [R, 512, 7, 7]
+        hook = getattr(self, '_head_grad_hook', None)      # (set by FasterRCNN_AdEx.forward for the source pass of a data-parallel step)
+        if hook is not None and pooled.requires_grad:
+            pooled.register_hook(lambda g: hook())       # fires behind FC6's backward: every gradient kernel of the head is enqueued
         x_fea = self.classifier(pooled.view(pooled.size(0), -1))  # [R, 4096]
         return x_fea, self.fc_rcnn_cls(x_fea), self.fc_rcnn_loc(x_fea)
 

@@ -45,6 +45,39 @@ def average_gradients(model, async_op=False):
     return dist.all_reduce(flat.grad, async_op=async_op)
 
 
+class SegmentedReduce:
+    """The SUM all-reduce of one flat gradient bucket in pieces, so that it can START inside the backward pass that fills it
+    (the 547 MB detector reduction overlapped with the VGG-body backward).  Parameters enter the bucket in
+    module order, so the detector's classifier + heads (FC6 / FC7 / cls / loc: 480 of the 547 MB) are one contiguous slice whose
+    gradients are final as soon as FC6's weight gradient has been enqueued -- `launch_early()` is called from a tensor hook on the
+    RoI-pooled features (scda_amd.train_step), `launch_rest()` after backward() for what lies in front of / behind the slice, and
+    `wait()` before the optimiser step.  Element-wise the result is the single collective's (a sum over ranks per element).
+    `average_gradients(model)` -- the reference's one call -- stays the single collective."""
+
+    def __init__(self, flat, early):
+        self.flat, self.early, self.works, self.early_done = flat, early, [], False
+
+    def launch_early(self):
+        lo, hi = self.early
+        self.flat.finalize_grads((lo, hi))
+        self.works.append(dist.all_reduce(self.flat.grad[lo:hi], async_op=True))
+        self.early_done = True
+
+    def launch_rest(self):
+        self.flat.check_aliases()
+        self.flat.finalize_grads()
+        lo, hi = self.early if self.early_done else (0, 0)     # (the hook did not fire: nothing differentiable reached the slice)
+        for a, b in ((0, lo), (hi, self.flat.numel)):
+            if b > a:
+                self.works.append(dist.all_reduce(self.flat.grad[a:b], async_op=True))
+        return self
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        self.works = []
+
+
 def broadcast_params(model):
     """rank 0's parameters and buffers to everyone"""
     from scda_amd.layers import flush_counters

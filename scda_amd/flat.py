@@ -28,8 +28,10 @@ class FlatParams:
         self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
         self.params = params
         off = 0
+        self.offset = {}     # id(parameter) -> first element of its slice in both buckets
         for p, sz in zip(params, sizes):
             n = p.numel()
+            self.offset[id(p)] = off
             self.data[off:off + n].copy_(p.data.reshape(-1))
             p.data = self.data[off:off + n].view_as(p.data)
             if keep_grads and p.grad is not None:
@@ -81,13 +83,27 @@ class FlatParams:
             return True
         return False
 
-    def finalize_grads(self):
-        """before the bucket is read as a whole (all-reduce, optimiser step, tests): zero what no backward kernel wrote"""
+    def finalize_grads(self, span=None):
+        """before the bucket (or its element range `span`) is read as a whole (all-reduce, optimiser step, tests): zero what no
+        backward kernel wrote"""
         if self.fresh:
             for p in self.lazy:
-                if id(p) in self.fresh:
+                if id(p) in self.fresh and (span is None or span[0] <= self.offset[id(p)] < span[1]):
                     p.grad.zero_()
-            self.fresh.clear()
+                    self.fresh.discard(id(p))
+
+    def span_of(self, params):
+        """-> (first, end) element range of the bucket that holds exactly `params` (their slices must be adjacent: no other
+        parameter in between), or None"""
+        ids = {id(p) for p in params}
+        if not ids or not ids <= set(self.offset):
+            return None
+        inside = [p for p in self.params if id(p) in ids]
+        lo = min(self.offset[id(p)] for p in inside)
+        hi = max(self.offset[id(p)] + (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN for p in inside)
+        if any(lo <= self.offset[id(p)] < hi for p in self.params if id(p) not in ids):
+            return None
+        return lo, hi
 
     def zero_grad(self):
         if self.lazy:

@@ -27,7 +27,7 @@ from ._timing import mark
 from .dropin.models.faster_rcnn.faster_rcnn_adver_expansion_reweight_cluster import (GAN_decoder_AE, GAN_dis_AE,
                                                                                      GAN_dis_AE_patch)
 from .dropin.models.faster_rcnn.vgg_adver_expansion_cluster import vgg16
-from .dropin.utils.distributed_utils import average_gradients
+from .dropin.utils.distributed_utils import SegmentedReduce, average_gradients
 
 
 def get_corner_from_center(center, recon_size, new_w, new_h):
@@ -272,6 +272,7 @@ class ScdaTrainer:
         active_test_hooks(fail=os.environ.get("SCDA_ALLOW_TEST_HOOKS") != "1")
         self.cfg, self.device = cfg, device
         self.collectives = (world_size > 1) if collectives is None else bool(collectives)
+        self.early_reduces = 0      # all-reduces launched from inside a detector backward (SegmentedReduce) so far
         from .hostenv import configure_host_threads
         configure_host_threads()
         self.cluster_num, self.threshold, self.recon = cluster_num, threshold, (recon_hw or recon_size)
@@ -372,6 +373,17 @@ class ScdaTrainer:
         if self.collectives:
             return average_gradients(module, async_op=async_op)
         return None
+
+    def _det_early_span(self):
+        """element range of the detector bucket whose gradients are final behind the RoI head's backward (the model names the
+        parameters: VGG.EARLY_REDUCE_PREFIXES), or None (SCDA_SEGMENTED_REDUCE=0, other detectors, a non-contiguous layout)"""
+        if not hasattr(self, '_early_span'):
+            self._early_span = None
+            pre = getattr(self.model, 'EARLY_REDUCE_PREFIXES', None)
+            flat = getattr(self.model, '_scda_flat', None)
+            if pre and flat is not None and os.environ.get("SCDA_SEGMENTED_REDUCE", "1") != "0":
+                self._early_span = flat.span_of([p for n, p in self.model.named_parameters() if n.startswith(tuple(pre)) and p.requires_grad])
+        return self._early_span
 
     def _reduce(self, module, async_op):
         self._finish_grads(module)
@@ -521,11 +533,27 @@ class ScdaTrainer:
             self.opt['det'].zero_grad()
             det_loss.backward()
             pending['det_loss'] = det_loss.detach()
-            pending['w4'] = self._reduce(self.model, async_op=True)
+            seg = pending.get('seg')
+            if seg is not None:          # the head's slice left from inside the backward; the conv body's (and what else is left) now
+                self._finish_grads(self.model)
+                pending['w4'] = seg.launch_rest()
+            else:
+                pending['w4'] = self._reduce(self.model, async_op=True)
 
         if self.early_backward:
             x['_after_source_losses'] = detector_backward
             x['_side_stream'] = self.side
+        # data parallel: the detector's all-reduce in two pieces, the classifier + heads (480 of 547 MB, final behind FC6's weight
+        # gradient) from a hook inside the backward, the rest behind it (not under gradient capture: the tests' per-rank traces
+        # are taken from the whole bucket at the end of the backward)
+        span = self._det_early_span() if (self.collectives and not self.capture) else None
+        if span is not None:
+            pending['seg'] = SegmentedReduce(self.model._scda_flat, span)
+
+            def head_gradients_enqueued():
+                pending['seg'].launch_early()
+                self.early_reduces += 1
+            x['_after_head_backward'] = head_gradients_enqueued
         mark('step_begin')
         outputs = self.model(x, target)
         ctr_s, ctr_t = outputs['cluster_centers']

@@ -74,7 +74,31 @@ def _worker(rank, world, port, results):
     work = average_gradients(m2, async_op=True)
     work.wait()
     ok_plain &= all(bool((p.grad == 15).all()) and flat2._inside(p.grad, flat2.grad) for p in m2.parameters())
-    results[rank] = (ok_bcast, ok_bn, ok_sum, ok_async, ok_plain)
+    # the reduction of one bucket in pieces, the first launched from a hook INSIDE the backward pass (SegmentedReduce): the
+    # parameters behind the hooked activation are one contiguous slice; same sums as the single collective on a twin
+    from scda_amd.dropin.utils.distributed_utils import SegmentedReduce
+    torch.manual_seed(7)
+    m3, m4 = Tiny(), Tiny()
+    m4.load_state_dict(m3.state_dict())
+    f3, f4 = FlatParams(m3), FlatParams(m4)
+    span = f3.span_of(list(m3.bn.parameters()) + list(m3.b.parameters()))
+    ok_seg = span is not None and f3.span_of(list(m3.a.parameters()) + list(m3.b.parameters())) is None   # (a, b) are not adjacent
+    seg = SegmentedReduce(f3, span)
+    xin = torch.randn(6, 5, generator=torch.Generator().manual_seed(20 + rank))
+    for mm, early in ((m3, seg), (m4, None)):
+        hcur = mm.a(xin)
+        if early is not None:
+            state = {}
+            def hook(g, early=early, state=state):
+                state['head'] = [p.grad.clone() for p in list(m3.bn.parameters()) + list(m3.b.parameters())]
+                early.launch_early()
+            hcur.register_hook(hook)
+        mm.b(mm.bn(hcur)).square().sum().backward()
+    ok_seg &= all(bool(g.abs().sum() > 0) for g in state['head'])       # the slice's gradients existed when the hook fired
+    seg.launch_rest().wait()
+    average_gradients(m4)
+    ok_seg &= torch.equal(f3.grad, f4.grad) and len(seg.works) == 0
+    results[rank] = (ok_bcast, ok_bn, ok_sum, ok_async, ok_plain, ok_seg)
     dist.destroy_process_group()
 
 
@@ -96,7 +120,7 @@ def test_world_size_2_gloo():
         for p in procs:
             p.join(120)
             assert p.exitcode == 0
-        assert dict(results) == {0: (True,) * 5, 1: (True,) * 5}
+        assert dict(results) == {0: (True,) * 6, 1: (True,) * 6}, dict(results)
 
 
 def test_flat_params_views_and_adam_bucket_alignment():

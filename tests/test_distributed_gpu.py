@@ -63,7 +63,10 @@ def _worker(rank, world, port, out_dir):
     torch.cuda.synchronize()
     sums = {k: [float(f.data.double().sum()), float(f.data.double().abs().sum())] for k, f in tr.flat.items()}
     bn = float(tr.dis_patch.state_dict()['model_A_patch.0.model.1.running_mean'].double().sum())
-    torch.save({'sums': sums, 'losses': losses, 'bn': bn}, os.path.join(out_dir, "rank%d.pt" % rank))
+    span = tr._det_early_span()
+    torch.save({'sums': sums, 'losses': losses, 'bn': bn, 'early_reduces': tr.early_reduces,
+                'early_mb': 0.0 if span is None else (span[1] - span[0]) * 4 / 1e6, 'bucket_mb': tr.flat['det'].numel * 4 / 1e6},
+               os.path.join(out_dir, "rank%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -76,6 +79,25 @@ def test_two_ranks_stay_identical(cuda, tmp_path):
     assert r0['losses'] != r1['losses']                                  # ... although the ranks saw different data
     assert all(np.isfinite(v) for v in r0['losses'] + r1['losses'])
     assert r0['bn'] != r1['bn']      # BN running statistics of the patch discriminator stay per-rank, as in the reference
+    # the detector's reduction left in two pieces, the classifier + heads (most of the bucket) from inside each backward
+    assert r0['early_reduces'] == r1['early_reduces'] == 2 and r0['early_mb'] > 0.8 * r0['bucket_mb'], r0
+
+
+def test_segmented_detector_reduce_equals_single_collective(cuda, tmp_path, monkeypatch):
+    """the detector's all-reduce started inside the backward (classifier + heads behind FC6's weight gradient, the conv body at the
+    end: distributed_utils.SegmentedReduce) leaves every parameter bucket bit-identical to ONE collective after the backward"""
+    world = 2
+    res = {}
+    for mode in ("1", "0"):
+        d = tmp_path / ("seg" + mode)
+        d.mkdir()
+        monkeypatch.setenv("SCDA_SEGMENTED_REDUCE", mode)
+        mp.spawn(_worker, args=(world, _free_port(), str(d)), nprocs=world, join=True)
+        res[mode] = [torch.load(str(d / ("rank%d.pt" % r))) for r in range(world)]
+    assert res["1"][0]['early_reduces'] == 2 and res["0"][0]['early_reduces'] == 0
+    for r in range(world):
+        assert res["1"][r]['sums'] == res["0"][r]['sums'], (r, res["1"][r]['sums'], res["0"][r]['sums'])
+        assert res["1"][r]['losses'] == res["0"][r]['losses']
 
 
 def _grad_worker(rank, world, port, out_dir):
