@@ -26,6 +26,11 @@ CONV_CASES = [
     # B, Cin, H, W, Cout, k, s, p
     (1, 3, 32, 64, 64, 3, 1, 1),      # conv1_1-like: K=27 (ragged K), M=64
     (1, 64, 32, 48, 64, 3, 1, 1),
+    # 3 input channels, stride 1 (VGG conv1_1): the direct vector-unit weight gradient (conv_wgrad_small_cin_kernel) -- ragged last
+    # column strip, output channels that are no multiple of a wave's four / a workgroup's sixteen, several row blocks
+    (2, 3, 37, 53, 40, 3, 1, 1),
+    (1, 3, 50, 200, 7, 3, 1, 1),
+    (1, 3, 128, 256, 64, 3, 1, 1),
     (2, 16, 20, 28, 40, 3, 1, 1),     # ragged everything, batch 2, non-pow2 extents
     (1, 128, 16, 32, 256, 3, 1, 1),   # M=256 (two 128 tiles)
     (1, 512, 8, 16, 512, 3, 1, 1),    # split-K path (few tiles)
