@@ -56,6 +56,9 @@ void scda_debug_last_plan(int *out4);
  * 1 = contiguous pixel-block runs per XCD, gm (XCDs split gm x 8/gm over m-tile groups x runs; 1 = none), split-K count}, weight
  * gradient {K-splits, 0 = dealt as they come / 1 = whole splits per XCD / 2 = one split + one m-tile group per XCD} */
 void scda_debug_wino_last_order(int *out6);
+/* ... and whether the calling thread's most recent forward / data-gradient launch was the PERSISTENT form (one workgroup per CU walking
+ * the tiles: launches of more 64-row tiles than CUs; SCDA_WINO_PERSIST=0 turns it off): 1 / 0 */
+int scda_debug_wino_last_persistent(void);
 
 /* ---------------------------------------------------------------- NMS ---- */
 /* replaces  int gpu_nms(THLongTensor* keep, THLongTensor* num_out, THCudaTensor* boxes, float thresh)

@@ -62,6 +62,9 @@ __device__ __forceinline__ void wino_dma_b32(const void *, const unsigned, float
 // across sched_barriers, and did in the {0, 3} column variant -- whose operand is pinned in front of it and whose result is pinned
 // behind it stays in the slot it was written in.  No instruction is emitted.
 #define WINO_PIN(x) asm volatile("" : "+v"(x))
+// LDS hand-over inside a workgroup WITHOUT draining the vector-memory counter: __syncthreads() is fence + barrier, and the fence
+// waits vmcnt(0) -- for the persistent kernel's epilogue that is the next tile's patch requests and the previous passes' stores
+#define WINO_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 constexpr int WBK = WINO_BK;                    // channels per K-slab (8)
 constexpr int W_PR = 10, W_RS = 40;             // patch rows; row stride in floats: 17 even columns at 0.., 17 odd columns at 20..
@@ -78,6 +81,7 @@ struct WinoGeom {
     Div dNMT, dNPB, dNB, dNBX;   // m-tiles; pixel blocks of the launch; per image; per block row
     int pixel_major, npb, per_xcd;   // XCD-aware order with the pixel block outermost (see the kernel); pixel blocks of the launch;
                                      // (split, pixel block) items per XCD
+    int n_wg;                        // tiles (workgroup slots) of the launch: what a one-tile-per-workgroup grid would be
     int gm_mask, gm_shift;           // ... with the 8 XCDs split gm x (8 / gm) over m-tile groups x pixel-block runs: gm - 1, log2(gm)
     Div dNML;                        // m-tiles per XCD (n_mt / gm)
 };
@@ -98,63 +102,91 @@ struct WinoEpi {
 typedef float wino_f4 __attribute__((ext_vector_type(4)));
 typedef float wino_f2 __attribute__((ext_vector_type(2)));
 
-// MB = 32-row blocks of output channels per workgroup.  2: 64 x 64 tile, 128 accumulator registers per wave, 128 KB of exchange
-// buffer -- one workgroup per CU; every U and V fragment feeds two MFMAs.  1: 32 x 64 tile, 64 accumulators, 64 KB -- TWO
-// workgroups per CU (4 waves per SIMD at <= 128 registers): one's start-up (first patch + U round trip, ~5 us) and epilogue
-// (~5 us) run underneath the other's K loop, which is what a layer with a short channel loop or few tiles per CU loses on MB = 2.
-template <int MB>
+// MB = 32-row blocks of output channels per workgroup.  2: 64 x 64 tile, 128 accumulator registers per wave -- one workgroup per
+// CU; every U and V fragment feeds two MFMAs.  1: 32 x 64 tile, 64 accumulators, 64 KB of LDS -- TWO workgroups per CU (4 waves per
+// SIMD at <= 128 registers): for layers with <= 32 output rows and launches that would not fill the chip with 64-row tiles.
+//
+// PERSIST (MB = 2, launches of more tiles than CUs): one workgroup per CU walks tiles b = blockIdx.x, + gridDim.x, ... (gridDim.x a
+// multiple of 8: the XCD a tile runs on, and with it the launch orders below, are those of the one-tile-per-workgroup launch).  What
+// a tile costs outside its K loop -- 6 us of start-up (workgroup dispatch, first patch + U round trip) and 6 us of epilogue on top
+// of conv1_2's 17 us of K loop, with all workgroups of a round storing at the same time -- is taken apart:
+//   * the exchange buffer is 16 rows per pass (64 KB, four passes) and the ring lies BEHIND it, so the next tile's first three
+//     patches and its first U fragments are requested before the current tile's epilogue and have landed when it ends;
+//   * the epilogue's stores are unconditional buffer stores (tiles / rows outside the tensor get an offset the descriptor's range
+//     check drops) and nothing waits for them by name: they drain underneath the next tile's K loop.  The counted waits of that K
+//     loop count LOADS only (patch LDS-DMA and U fragments, which retire in issue order); a first version added the epilogue's 16
+//     stores to the counts of the next tile's first two hand-overs (stores being younger than the patches they wait for) and was
+//     wrong one launch in a few hundred -- a replayed-graph iteration differed from the eager one in the last bits to the third
+//     digit: on gfx950 store acknowledgements (and certainly range-dropped stores) do NOT retire in issue order with older LDS-DMA
+//     loads, so "at most N outstanding" says nothing about a load once stores are among the N.  With loads-only counts a wait is
+//     at worst early-satisfied by nothing and at best released by stores retiring early; either way the patch it names has landed.
+
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef int wino_i2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wino_rsrc(const void *base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)0x80000000u, 0x00020000);
+}
+#endif
+
+// EPI: what the epilogue does with a finished 2 x 2 output tile, a compile-time choice so that every variant is straight-line code
+// with a known number of vector-memory instructions (the compiler's counted waits are the minimum over the paths it sees):
+// 0 bias + activation, 1 + the producer's activation mask (data gradient), 2 + fused 2x2 max-pool, 3 a split-K slab
+enum { WEPI_PLAIN = 0, WEPI_MASK = 1, WEPI_POOL = 2, WEPI_SPLIT = 3 };
+
+template <int MB, bool PERSIST, int EPI>
 __global__ __launch_bounds__(512, (MB == 2 ? 2 : 4)) void conv_wino_kernel(const float *__restrict__ U, const float *__restrict__ X,
                                                                         const WinoGeom g, const WinoEpi e) {
-    __shared__ __attribute__((aligned(16))) float lds[W_MX * MB];
+#if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(!PERSIST || MB == 2, "the persistent form is the one-workgroup-per-CU tile");
+    constexpr int RP = PERSIST ? 16 : 16 * MB;         // output-channel rows per exchange pass
+    constexpr int NPASS = 32 * MB / RP;
+    constexpr int NRG = RP / 2;                        // accumulator registers per tile and pass
+    constexpr int XCH = 16 * RP * 64;                  // exchange buffer (floats): [position][row][64 tiles]
+    constexpr int RING = PERSIST ? XCH : 0;            // first float of the ring: behind the exchange buffer, or aliasing it
+    static_assert(PERSIST || W_NST * W_STAGE <= XCH, "the ring lives inside the exchange buffer");
+    constexpr int BIAS = PERSIST ? XCH + W_NST * W_STAGE : XCH;     // 2 x 64 floats behind everything: the bias values of this tile and of the next
+    __shared__ __attribute__((aligned(16))) float lds[BIAS + 128];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int rest, mt, sp, pb, img, bi, by, bx;
-    if (g.pixel_major) {
-        // workgroup b runs on XCD b % 8.  Inside an XCD's sequence the m-tile is fastest and a pixel block's m-tiles are consecutive:
-        // one XCD's L2 fetches a patch once for all of them (m-tile-major puts the m-tiles of a block on DIFFERENT XCDs: the input
-        // crosses the fabric n_mt times); the XCD then needs every m-tile's filters, which is why the launcher only picks this order
-        // when all 16 x M x C of them fit an L2.  An XCD owns a CONTIGUOUS run of (split, pixel block) items -- row neighbours run side
-        // by side on it and share the 128-byte lines their 136-byte patch rows straddle (the halo columns make every row touch three
-        // lines: dealt round-robin, neighbouring blocks landed on different XCDs and each fetched the shared lines itself).
-        // With the filters too large for that (conv4_x: 8 - 17 MB) the XCDs are split gm x (8 / gm): XCD x serves the m-tiles
-        // mt % gm == x % gm on run x / gm of the pixel blocks -- each XCD streams 1 / gm of the filters and reads 1 / (8 / gm) of
-        // the input, instead of one m-tile's filters and the WHOLE input (m-tile-major).
-        const int x = (int)(blockIdx.x & 7), j = (int)(blockIdx.x >> 3);
-        int pl, ml;
-        g.dNML.divmod(j, pl, ml);
-        mt = (ml << g.gm_shift) + (x & g.gm_mask);
-        rest = (x >> g.gm_shift) * g.per_xcd + pl;
-        if (pl >= g.per_xcd || rest >= g.npb * e.splits) return;
-        g.dNPB.divmod(rest, sp, pb);
-    } else {
-        g.dNMT.divmod((int)blockIdx.x, rest, mt);
-        g.dNPB.divmod(rest, sp, pb);
-    }
-    g.dNB.divmod(pb, img, bi);
-    g.dNBX.divmod(bi, by, bx);
-    const int y0 = by * 8, x0 = bx * 32;
-    const int s_begin = sp * g.slabs_per_split, s_end = min(g.n_slab, s_begin + g.slabs_per_split);
     const int plane = g.H * g.W;
+    const int N = g.batch * plane;
 
-    // ---- this wave's share of the patch LDS-DMA: slot -> (channel, patch row, column), fixed for the whole kernel ---------------
-    unsigned dma_off[W_DMA];
-#pragma unroll
-    for (int i = 0; i < W_DMA; ++i) {
-        const int slot = (wave * W_DMA + i) * 64 + lane;
-        const int ch = slot / W_CS, rem = slot - ch * W_CS;
-        const int row = rem / W_RS, sl = rem - row * W_RS;
-        const int col = sl < 17 ? 2 * sl : (sl >= 20 && sl < 37) ? 2 * (sl - 20) + 1 : -1;
-        const int gy = y0 - 1 + row, gx = x0 - 1 + col;
-        const bool ok = ch < WBK && col >= 0 && (unsigned)gy < (unsigned)g.H && (unsigned)gx < (unsigned)g.W;
-        dma_off[i] = ok ? (unsigned)((ch * plane + gy * g.W + gx) * 4) : 0x80000000u;
-    }
-    const char *xbase = reinterpret_cast<const char *>(X + (size_t)img * g.C * plane);
-    auto issue_dma_one = [&](const int s, const int buf, const int i) {
-        wino_dma_b32(xbase, dma_off[i], lds + buf * W_STAGE + wave * (W_DMA * 64) + i * 64, s * (WBK * plane * 4));
+    // ---- tile b of the launch -> (m-tile, split, image, pixel block); false: an idle slot of an XCD's run ---------------------------
+    struct Tile { int mt, sp, img, y0, x0, s_begin, s_end; };
+    auto decode = [&](const int b, Tile &t) -> bool {
+        int rest, pb, bi, by, bx;
+        if (g.pixel_major) {
+            // workgroup b runs on XCD b % 8.  Inside an XCD's sequence the m-tile is fastest and a pixel block's m-tiles are consecutive:
+            // one XCD's L2 fetches a patch once for all of them (m-tile-major puts the m-tiles of a block on DIFFERENT XCDs: the input
+            // crosses the fabric n_mt times); the XCD then needs every m-tile's filters, which is why the launcher only picks this order
+            // when all 16 x M x C of them fit an L2.  An XCD owns a CONTIGUOUS run of (split, pixel block) items -- row neighbours run side
+            // by side on it and share the 128-byte lines their 136-byte patch rows straddle (the halo columns make every row touch three
+            // lines: dealt round-robin, neighbouring blocks landed on different XCDs and each fetched the shared lines itself).
+            // With the filters too large for that (conv4_x: 8 - 17 MB) the XCDs are split gm x (8 / gm): XCD x serves the m-tiles
+            // mt % gm == x % gm on run x / gm of the pixel blocks -- each XCD streams 1 / gm of the filters and reads 1 / (8 / gm) of
+            // the input, instead of one m-tile's filters and the WHOLE input (m-tile-major).
+            const int x = b & 7, j = b >> 3;
+            int pl, ml;
+            g.dNML.divmod(j, pl, ml);
+            t.mt = (ml << g.gm_shift) + (x & g.gm_mask);
+            rest = (x >> g.gm_shift) * g.per_xcd + pl;
+            if (pl >= g.per_xcd || rest >= g.npb * e.splits) return false;
+            g.dNPB.divmod(rest, t.sp, pb);
+        } else {
+            g.dNMT.divmod(b, rest, t.mt);
+            g.dNPB.divmod(rest, t.sp, pb);
+        }
+        g.dNB.divmod(pb, t.img, bi);
+        g.dNBX.divmod(bi, by, bx);
+        t.y0 = by * 8; t.x0 = bx * 32;
+        t.s_begin = t.sp * g.slabs_per_split; t.s_end = min(g.n_slab, t.s_begin + g.slabs_per_split);
+        return true;
     };
-    auto issue_dma = [&](const int s, const int buf) {
-#pragma unroll
-        for (int i = 0; i < W_DMA; ++i) issue_dma_one(s, buf, i);
+    auto next_tile = [&](int &b, Tile &t) -> bool {     // the next tile of this workgroup behind b, if any
+        if (!PERSIST) return false;
+        for (b += (int)gridDim.x; b < g.n_wg; b += (int)gridDim.x)
+            if (decode(b, t)) return true;
+        return false;
     };
 
     // ---- this wave's two positions ------------------------------------------------------------------------------------------------
@@ -166,35 +198,84 @@ __global__ __launch_bounds__(512, (MB == 2 ? 2 : 4)) void conv_wino_kernel(const
     const int i1 = a == 0 ? 0 : a == 2 ? 2 : 1, i2 = a == 0 ? 2 : a == 1 ? 2 : a == 2 ? 1 : 3;
     const float sgn = a == 1 ? 1.f : -1.f;
     const int j = lane & 31, h = lane >> 5;
-    const int lane_base = h * W_CS + (2 * (j >> 4)) * W_RS + (j & 15);
+    const int lane_base = RING + h * W_CS + (2 * (j >> 4)) * W_RS + (j & 15);
     const int ro1 = lane_base + i1 * W_RS, ro2 = lane_base + i2 * W_RS;
     const int n_mbg = g.n_mbg;
-    // U fragments: wave-uniform base per (position, 32-row block) + lane * 4 floats; one slab = 256 floats further on
-    const float *ub[2][MB];
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
-            ub[x][mb] = U + (size_t)((x ? xi1 : xi0) * n_mbg + mt * MB + mb) * g.n_slab * 256;
-    auto load_a_one = [&](const int s, const int x, const int mb, wino_f4 (&A)[2][MB]) {
-        A[x][mb] = *reinterpret_cast<const wino_f4 *>(ub[x][mb] + (size_t)s * 256 + lane * 4);
+
+    // ---- what the K loop needs of a tile: patch offsets, image base, U bases, slab range -----------------------------------------------
+    struct Ctx {
+        unsigned dma_off[W_DMA];
+        const char *xbase;
+        unsigned uoff[2][MB];        // U fragments: wave-uniform byte offset per (position, 32-row block); + lane * 16; one slab = 1 KB further on
+        int s_begin, s_end;
     };
-    auto load_a = [&](const int s, wino_f4 (&A)[2][MB]) {
+    auto setup = [&](const Tile &t, Ctx &c) {
+        // this wave's share of the patch LDS-DMA: slot -> (channel, patch row, column) is fixed, the tile moves the patch (recomputed
+        // per tile: ~70 VALU against seven registers held across the K loop)
+        int ln = lane;
+        WINO_PIN(ln);       // (opaque per call: hoisted out of the tile loop, the seven decompositions were SPILLED across it)
+#pragma unroll
+        for (int i = 0; i < W_DMA; ++i) {
+            const int slot = (wave * W_DMA + i) * 64 + ln;
+            const int ch = slot / W_CS, rem = slot - ch * W_CS;
+            const int row = rem / W_RS, sl = rem - row * W_RS;
+            const int col = sl < 17 ? 2 * sl : (sl >= 20 && sl < 37) ? 2 * (sl - 20) + 1 : -1;
+            const int gy = t.y0 - 1 + row, gx = t.x0 - 1 + col;
+            const bool ok = ch < WBK && col >= 0 && (unsigned)gy < (unsigned)g.H && (unsigned)gx < (unsigned)g.W;
+            c.dma_off[i] = ok ? (unsigned)((ch * plane + gy * g.W + gx) * 4) : 0x80000000u;
+        }
+        c.xbase = reinterpret_cast<const char *>(X + (size_t)t.img * g.C * plane);
 #pragma unroll
         for (int x = 0; x < 2; ++x)
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb) load_a_one(s, x, mb, A);
+            for (int mb = 0; mb < MB; ++mb)
+                c.uoff[x][mb] = (unsigned)(((x ? xi1 : xi0) * n_mbg + t.mt * MB + mb) * g.n_slab) * 1024u;
+        c.s_begin = t.s_begin; c.s_end = t.s_end;
+    };
+    auto issue_dma_one = [&](const Ctx &c, const int s, const int buf, const int i) {
+        wino_dma_b32(c.xbase, c.dma_off[i], lds + RING + buf * W_STAGE + wave * (W_DMA * 64) + i * 64, s * (WBK * plane * 4));
+    };
+    auto issue_dma = [&](const Ctx &c, const int s, const int buf) {
+#pragma unroll
+        for (int i = 0; i < W_DMA; ++i) issue_dma_one(c, s, buf, i);
+    };
+    // (a buffer load: descriptor + scalar offset + one lane offset shared by all of them -- as global loads the compiler kept a 64-bit
+    // lane address per (position, block) in registers across the loop and added the slab offset on the vector unit)
+    const __amdgpu_buffer_rsrc_t r_u = wino_rsrc(U);
+    auto load_a_one = [&](const Ctx &c, const int s, const int x, const int mb, wino_f4 (&A)[2][MB]) {
+#if defined(WINO_DBG_U_GLOBAL)
+        A[x][mb] = *reinterpret_cast<const wino_f4 *>(reinterpret_cast<const char *>(U) + c.uoff[x][mb] + (size_t)s * 1024 + lane * 16);
+        return;
+#endif
+        A[x][mb] = __builtin_bit_cast(wino_f4, __builtin_amdgcn_raw_buffer_load_b128(r_u, lane * 16, (int)(c.uoff[x][mb] + (unsigned)s * 1024u), 0));
     };
 
     f32x16 acc[2][MB][2];
+    wino_f4 A0[2][MB], A1[2][MB];
+    // a tile's first requests: patches of its first three slabs into ring stages 0 - 2, the U fragments of its first slab.  VMEM order
+    // = the steady state's (patch, patch, U, patch): the compiler's counted waits for the U fragments at the loop head are the
+    // minimum over the ways into it
+    // (the bias goes the same way, as the OLDEST request: 64 rows = one LDS-DMA instruction, issued by every wave alike -- the counted
+    // waits below count per wave.  Not a scalar load: the scalar cache kept last iteration's values inside a replayed hipGraph; not
+    // a vector load in the epilogue: its result could only be waited for together with every older request and store)
+    auto first_requests = [&](const Ctx &c, const Tile &t, const int par) {
+        if (EPI != WEPI_SPLIT) {
+            const int m = t.mt * (32 * MB) + lane;
+            wino_dma_b32(e.bias, (e.bias && lane < 32 * MB && m < g.M) ? (unsigned)(m * 4) : 0x80000000u, lds + BIAS + 64 * par, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        issue_dma(c, c.s_begin, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_dma(c, min(c.s_begin + 1, c.s_end - 1), 1);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int x = 0; x < 2; ++x)
+        for (int x = 0; x < 2; ++x)
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-            for (int tb = 0; tb < 2; ++tb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[x][mb][tb][r] = 0.f;
+            for (int mb = 0; mb < MB; ++mb) load_a_one(c, c.s_begin, x, mb, A0);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_dma(c, min(c.s_begin + 2, c.s_end - 1), 2);
+        __builtin_amdgcn_sched_barrier(0);
+    };
 
     // the K loop, compiled once per column set (BSEL: b in {1, 2} -- four raw values per fragment pair -- or {0, 3} -- eight).
     // A software pipeline over K-PAIRS (one K-pair = 2 channels = one MFMA per accumulator block), written slot by slot and pinned
@@ -207,10 +288,11 @@ __global__ __launch_bounds__(512, (MB == 2 ? 2 : 4)) void conv_wino_kernel(const
     // fragment is formed one step before its MFMAs; the U loads of slab s + 1 ride in steps 0 - 1, the patch DMA of slab s + 3 in
     // steps 2 - 3.  The hand-over (counted vmcnt + s_barrier) for slab s + 1 sits in the MIDDLE of slab s's MFMA stream, behind the
     // first MFMA of step 2: the first reads of the next patch are issued there, a step and a half before they are needed.
-    auto k_loop = [&](auto bsel_tag) {
+    auto k_loop = [&](auto bsel_tag, const Ctx &c) {
         constexpr bool BSEL = decltype(bsel_tag)::value;
         constexpr int NR = BSEL ? 4 : 8;          // raw values per tile block and K-pair
         constexpr int NSLOT = 4 * MB;             // MFMAs per K-pair
+        const int s_end = c.s_end;
         float raw[2][NR];                         // [tile block][value]: K-pair i + 1 until its sums are formed, then K-pair i + 2
         float pt[2][4];                           // BT-row sums of the K-pair being formed
         float v[2][2][2];                         // [ring of 2 K-pairs][position][tile block]
@@ -276,11 +358,11 @@ __global__ __launch_bounds__(512, (MB == 2 ? 2 : 4)) void conv_wino_kernel(const
                 // loads were not issued and drains the prefetch with vmcnt(0); the clamped tail loads go to a stage / registers nobody reads)
                 if (kp < 2) {
                     const int um = (m == 0) ? 0 : (MB == 2 && m == 4) ? 1 : -1;
-                    if (um >= 0) load_a_one(min(s + 1, s_end - 1), kp, um, Anext);
+                    if (um >= 0) load_a_one(c, min(s + 1, s_end - 1), kp, um, Anext);
                 } else {
 #if !(SCDA_WINO_ABLATE & 8)
                     const int di = MB == 2 ? ((m & 1) ? -1 : (kp - 2) * 4 + (m >> 1)) : (kp - 2) * 4 + m;
-                    if (di >= 0 && di < W_DMA) issue_dma_one(min(s + 3, s_end - 1), (buf + 3) & (W_NST - 1), di);
+                    if (di >= 0 && di < W_DMA) issue_dma_one(c, min(s + 3, s_end - 1), (buf + 3) & (W_NST - 1), di);
 #endif
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -290,74 +372,90 @@ __global__ __launch_bounds__(512, (MB == 2 ? 2 : 4)) void conv_wino_kernel(const
 #pragma unroll
             for (int kp = 0; kp < WBK / 2; ++kp) step(kp, s, buf, Acur, Anext);
         };
-        wino_f4 A0[2][MB], A1[2][MB];
-        // VMEM order of the start-up = the steady state's (patch, patch, U, patch): the compiler's counted waits for the U fragments at
-        // the loop head are the minimum over both ways into it
-        issue_dma(s_begin, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        issue_dma(min(s_begin + 1, s_end - 1), 1);
-        __builtin_amdgcn_sched_barrier(0);
-        load_a(s_begin, A0);
-        __builtin_amdgcn_sched_barrier(0);
-        issue_dma(min(s_begin + 2, s_end - 1), 2);
-        __builtin_amdgcn_sched_barrier(0);
+        // the first patch has landed (this wave's share: younger LOADS are two patches and the U fragments)
         WINO_WAIT_VMCNT(2 * W_DMA + 2 * MB);
         __builtin_amdgcn_s_barrier();
         {   // fill the pipeline: B fragments of K-pair 0, raw values of K-pair 1
+            const float *st0 = lds;
 #pragma unroll
             for (int tb = 0; tb < 2; ++tb)
 #pragma unroll
-                for (int q = 0; q < NR; ++q) read_unit(lds, 0, tb, q);
+                for (int q = 0; q < NR; ++q) read_unit(st0, 0, tb, q);
 #pragma unroll
             for (int tb = 0; tb < 2; ++tb) { valu_a(tb); valu_b(tb, v[0]); }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int tb = 0; tb < 2; ++tb)
 #pragma unroll
-                for (int q = 0; q < NR; ++q) read_unit(lds, 1, tb, q);
+                for (int q = 0; q < NR; ++q) read_unit(st0, 1, tb, q);
             __builtin_amdgcn_sched_barrier(0);
         }
-        int s = s_begin, buf = 0;
+        int s = c.s_begin, buf = 0;
         for (; s + 1 < s_end; s += 2) {
             slab(s, buf, A0, A1);
             slab(s + 1, (buf + 1) & (W_NST - 1), A1, A0);
             buf = (buf + 2) & (W_NST - 1);
         }
         if (s < s_end) slab(s, buf, A0, A1);
-        WINO_WAIT_VMCNT(0);              // the clamped tail DMA must not land in the exchange buffer below
+        if (!PERSIST) WINO_WAIT_VMCNT(0);      // the clamped tail DMA must not land in the exchange buffer below (PERSIST: the ring is its own)
     };
-    if (!(e.dbg & 2)) { if (bsel) k_loop(std::true_type{}); else k_loop(std::false_type{}); }
-    if (e.dbg & 1) { if (acc[0][0][0][0] == 123.456f) e.out[0] = 1.f; return; }
 
     // ---- epilogue: exchange the 16 positions through LDS, output transform, store ---------------------------------------------------
-    // two passes: MB = 2: one 32-row block each (all 16 accumulator registers of a tile); MB = 1: rows 16 p .. 16 p + 15 of the
-    // one block = accumulator registers 8 p .. 8 p + 7 (frag_row: (r & 3) + 8 * (r >> 2) + 4 * h)
-    constexpr int RP = 16 * MB, NRG = 8 * MB;        // rows per pass; accumulator registers per tile and pass
-    const int N = g.batch * plane;
+    // NPASS passes of RP output-channel rows: accumulator registers r with frag_row(r) = (r & 3) + 8 * (r >> 2) + 4 * h in the pass's
+    // rows.  Stores are buffer stores with the range check as the guard (no branch around a memory instruction: a wave issues the same
+    // stores for every tile).
+    auto epilogue = [&](const Tile &t, const int par) {
+        // (lane-derived constants of the epilogue are re-derived per tile from an opaque copy of the lane id: hoisted out of the tile
+        // loop they would be live across the K loop, which has no register to spare)
+        int ln = lane;
+        WINO_PIN(ln);
+        const int j = ln & 31, h = ln >> 5;
+        const __amdgpu_buffer_rsrc_t r_out = wino_rsrc(EPI == WEPI_SPLIT ? (const void *)(e.ws + (size_t)t.sp * g.M * N + (size_t)t.img * plane)
+                                                       : EPI == WEPI_POOL ? (const void *)(e.pool_y + (size_t)t.img * g.M * (plane >> 2))
+                                                                          : (const void *)(e.out + (size_t)t.img * g.M * plane));
+        const __amdgpu_buffer_rsrc_t r_idx = wino_rsrc(EPI == WEPI_POOL ? (const void *)(e.pool_idx + (size_t)t.img * g.M * (plane >> 2)) : (const void *)e.out);
+        const __amdgpu_buffer_rsrc_t r_msk = wino_rsrc(EPI == WEPI_MASK ? (const void *)(e.mask_src + (size_t)t.img * g.M * plane) : (const void *)e.out);
+        const int oy = t.y0 + 2 * (ln >> 4), ox = t.x0 + 2 * (ln & 15);
+        const bool in_img = oy < g.H && ox < g.W;      // (H, W even: a tile is inside the image or outside, never across)
+        const unsigned pix = (unsigned)(oy * g.W + ox);
+        auto out_off = [&](const int pass, const int q) -> unsigned {     // byte offset of (row m, this lane's tile) in the full-resolution map
+            const int m = t.mt * (32 * MB) + pass * RP + q * 8 + wave;
+            return (in_img && m < g.M) ? (unsigned)(((size_t)m * plane + pix) * 4) : 0x80000000u;
+        };
+        // the producer's activation mask of the data gradient: loaded ONE PASS AHEAD, so that waiting for it does not wait for this
+        // pass's stores
+        wino_f2 mk[RP / 8][2];
+        auto load_mask = [&](const int pass) {
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        const int mb = MB == 2 ? pass : 0;
-        __syncthreads();    // the ring (first pass) / the previous pass's reads are done
+            for (int q = 0; q < RP / 8; ++q) {
+                const unsigned o = out_off(pass, q);
+                mk[q][0] = __builtin_bit_cast(wino_f2, __builtin_amdgcn_raw_buffer_load_b64(r_msk, o, 0, 0));
+                mk[q][1] = __builtin_bit_cast(wino_f2, __builtin_amdgcn_raw_buffer_load_b64(r_msk, o, g.W * 4, 0));
+            }
+        };
+        constexpr bool masked = EPI == WEPI_MASK;
+        if (masked) load_mask(0);
 #pragma unroll
-        for (int x = 0; x < 2; ++x) {
-            float *mx = lds + (x ? xi1 : xi0) * (RP * 64) + j;
+        for (int pass = 0; pass < NPASS; ++pass) {
+            const int mb = pass * RP / 32, r0 = (pass * RP % 32) / 2;      // 32-row block; first accumulator register of the pass
+            WINO_LDS_BARRIER();    // the ring (first pass, non-persistent) / the previous pass's reads are done
 #pragma unroll
-            for (int tb = 0; tb < 2; ++tb)
+            for (int x = 0; x < 2; ++x) {
+                float *mx = lds + (x ? xi1 : xi0) * (RP * 64) + j;
 #pragma unroll
-                for (int rr = 0; rr < NRG; ++rr) {
-                    const int r = MB == 2 ? rr : 8 * pass + rr;
-                    const int row = MB == 2 ? (r & 3) + 8 * (r >> 2) + 4 * h : (r & 3) + 8 * ((r >> 2) & 1) + 4 * h;
-                    mx[row * 64 + tb * 32] = acc[x][mb][tb][r];
-                }
-        }
-        __syncthreads();
+                for (int tb = 0; tb < 2; ++tb)
 #pragma unroll
-        for (int q = 0; q < RP / 8; ++q) {
-            const int ml = q * 8 + wave, t = lane;
-            const int m = mt * (32 * MB) + pass * RP + ml;
-            const float *mp = lds + ml * 64 + t;
-            float y00, y01, y10, y11;
-            {
+                    for (int rr = 0; rr < NRG; ++rr) {
+                        const int r = r0 + rr;
+                        const int row = ((r & 3) + 8 * (r >> 2) + 4 * h) - (pass * RP % 32);
+                        mx[row * 64 + tb * 32] = acc[x][mb][tb][r];
+                    }
+            }
+            WINO_LDS_BARRIER();
+            float y[RP / 8][4];
+#pragma unroll
+            for (int q = 0; q < RP / 8; ++q) {
+                const float *mp = lds + (q * 8 + wave) * 64 + ln;
                 float t0[4], t1[4];
 #pragma unroll
                 for (int aa = 0; aa < 4; ++aa) {
@@ -365,42 +463,88 @@ __global__ __launch_bounds__(512, (MB == 2 ? 2 : 4)) void conv_wino_kernel(const
                     t0[aa] = m0 + m1 + m2;
                     t1[aa] = m1 - m2 - m3;
                 }
-                y00 = t0[0] + t0[1] + t0[2]; y01 = t1[0] + t1[1] + t1[2];
-                y10 = t0[1] - t0[2] - t0[3]; y11 = t1[1] - t1[2] - t1[3];
+                y[q][0] = t0[0] + t0[1] + t0[2]; y[q][1] = t1[0] + t1[1] + t1[2];
+                y[q][2] = t0[1] - t0[2] - t0[3]; y[q][3] = t1[1] - t1[2] - t1[3];
             }
-            const int oy = y0 + 2 * (t >> 4), ox = x0 + 2 * (t & 15);
-            if (m >= g.M || oy >= g.H || ox >= g.W) continue;      // (H, W even: a tile is inside the image or outside, never across)
-            const size_t pix = (size_t)oy * g.W + ox;
-            if (e.splits > 1) {
-                float *o = e.ws + ((size_t)sp * g.M + m) * N + (size_t)img * plane + pix;
-                *reinterpret_cast<wino_f2 *>(o) = wino_f2{y00, y01};
-                *reinterpret_cast<wino_f2 *>(o + g.W) = wino_f2{y10, y11};
-                continue;
+            wino_f2 mcur[RP / 8][2];
+            if (masked) {
+#pragma unroll
+                for (int q = 0; q < RP / 8; ++q) { mcur[q][0] = mk[q][0]; mcur[q][1] = mk[q][1]; }
+                if (pass + 1 < NPASS) load_mask(pass + 1);
             }
-            const size_t o = ((size_t)img * g.M + m) * plane + pix;
-            if (e.bias) { const float bv = e.bias[m]; y00 += bv; y01 += bv; y10 += bv; y11 += bv; }
-            y00 = apply_act(y00, e.act, e.slope); y01 = apply_act(y01, e.act, e.slope);
-            y10 = apply_act(y10, e.act, e.slope); y11 = apply_act(y11, e.act, e.slope);
-            if (e.pool_y) {      // the window's winner: first maximum in (0,0) (0,1) (1,0) (1,1) order, NaN wins (maxpool2_fwd_kernel)
-                float mv = y00;
-                int kk = 0;
-                if (y01 > mv || y01 != y01) { mv = y01; kk = 1; }
-                if (y10 > mv || y10 != y10) { mv = y10; kk = 2; }
-                if (y11 > mv || y11 != y11) { mv = y11; kk = 3; }
-                const size_t po = ((size_t)img * g.M + m) * (size_t)(plane >> 2) + (size_t)(oy >> 1) * (g.W >> 1) + (ox >> 1);
-                e.pool_y[po] = mv;
-                e.pool_idx[po] = (unsigned char)kk;
-                continue;
+#pragma unroll
+            for (int q = 0; q < RP / 8; ++q) {
+                const int m = t.mt * (32 * MB) + pass * RP + q * 8 + wave;
+                float y00 = y[q][0], y01 = y[q][1], y10 = y[q][2], y11 = y[q][3];
+                const unsigned o = out_off(pass, q);
+                if (EPI == WEPI_SPLIT) {      // a split-K slab in the natural pixel order: ws[split][m][image][pixel]
+                    const unsigned os = (in_img && m < g.M) ? (unsigned)(((size_t)m * N + pix) * 4) : 0x80000000u;
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(wino_i2, wino_f2{y00, y01}), r_out, os, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(wino_i2, wino_f2{y10, y11}), r_out, os, g.W * 4, 0);
+                    continue;
+                }
+#if defined(WINO_DBG_BIAS_VEC)
+                if (e.bias) { const float bv = e.bias[min(m, g.M - 1)]; y00 += bv; y01 += bv; y10 += bv; y11 += bv; }
+#else
+                if (e.bias) { const float bv = lds[BIAS + 64 * par + pass * RP + q * 8 + wave]; y00 += bv; y01 += bv; y10 += bv; y11 += bv; }
+#endif
+                y00 = apply_act(y00, e.act, e.slope); y01 = apply_act(y01, e.act, e.slope);
+                y10 = apply_act(y10, e.act, e.slope); y11 = apply_act(y11, e.act, e.slope);
+                if (EPI == WEPI_POOL) {      // the window's winner: first maximum in (0,0) (0,1) (1,0) (1,1) order, NaN wins (maxpool2_fwd_kernel)
+                    float mv = y00;
+                    int kk = 0;
+                    if (y01 > mv || y01 != y01) { mv = y01; kk = 1; }
+                    if (y10 > mv || y10 != y10) { mv = y10; kk = 2; }
+                    if (y11 > mv || y11 != y11) { mv = y11; kk = 3; }
+                    const unsigned po = (unsigned)((size_t)m * (plane >> 2) + (size_t)(oy >> 1) * (g.W >> 1) + (ox >> 1));
+                    const bool ok = in_img && m < g.M;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, mv), r_out, ok ? po * 4u : 0x80000000u, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b8((unsigned char)kk, r_idx, ok ? po : 0x80000000u, 0, 0);
+                    continue;
+                }
+                if (masked) {
+                    const wino_f2 k0 = mcur[q][0], k1 = mcur[q][1];
+                    y00 = k0[0] > 0.f ? y00 : y00 * e.mask_slope; y01 = k0[1] > 0.f ? y01 : y01 * e.mask_slope;
+                    y10 = k1[0] > 0.f ? y10 : y10 * e.mask_slope; y11 = k1[1] > 0.f ? y11 : y11 * e.mask_slope;
+                }
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(wino_i2, wino_f2{y00, y01}), r_out, o, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(wino_i2, wino_f2{y10, y11}), r_out, o, g.W * 4, 0);
             }
-            if (e.mask_src) {
-                const wino_f2 k0 = *reinterpret_cast<const wino_f2 *>(e.mask_src + o), k1 = *reinterpret_cast<const wino_f2 *>(e.mask_src + o + g.W);
-                y00 = k0[0] > 0.f ? y00 : y00 * e.mask_slope; y01 = k0[1] > 0.f ? y01 : y01 * e.mask_slope;
-                y10 = k1[0] > 0.f ? y10 : y10 * e.mask_slope; y11 = k1[1] > 0.f ? y11 : y11 * e.mask_slope;
-            }
-            *reinterpret_cast<wino_f2 *>(e.out + o) = wino_f2{y00, y01};
-            *reinterpret_cast<wino_f2 *>(e.out + o + g.W) = wino_f2{y10, y11};
         }
+    };
+
+    // ---- the tile loop ---------------------------------------------------------------------------------------------------------------
+    Tile tile, tnext;
+    Ctx cur;
+    int b = (int)blockIdx.x;
+    bool have = decode(b, tile);
+    if (!have) have = next_tile(b, tile);
+    if (!have) return;
+    setup(tile, cur);
+    int par = 0;        // which of the two bias areas the current tile uses
+    if (!(e.dbg & 2)) first_requests(cur, tile, par);
+    for (;;) {
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[x][mb][tb][r] = 0.f;
+        if (!(e.dbg & 2)) { if (bsel) k_loop(std::true_type{}, cur); else k_loop(std::false_type{}, cur); }
+        const bool more = next_tile(b, tnext);
+        if (more) {     // its first patches and U fragments are requested now and land underneath this tile's epilogue
+            setup(tnext, cur);
+            if (!(e.dbg & 2)) first_requests(cur, tnext, par ^ 1);
+        }
+        if (e.dbg & 1) { if (acc[0][0][0][0] == 123.456f) e.out[0] = 1.f; }
+        else epilogue(tile, par);
+        if (!more) break;
+        tile = tnext;
+        par ^= 1;
     }
+#endif
 }
 
 // ---- weight gradient --------------------------------------------------------------------------------------------------------------
@@ -749,6 +893,7 @@ SCDA_API int scda_conv2d_wino_pack_hip(const float *w, float *out, int Cout, int
 // y [batch, M, H, W] = act(conv3x3(x [batch, C, H, W], stride 1, pad 1) + bias) (* act'(mask_src)); u = scda_conv2d_wino_pack_hip
 // test aid (scda_debug_wino_last_order): the launch order the calling thread's most recent launches took
 static thread_local int g_wino_last[4] = {0, 0, 0, 0};          // forward / data gradient: tile rows / 32, pixel-block-major?, gm, splits
+static thread_local int g_wino_last_persist = 0;
 static thread_local int g_wino_wgrad_last[2] = {0, 0};          // weight gradient: splits, 0 as they come / 1 whole splits per XCD / 2 split + m-tile group
 
 // evidence aid (scripts/pmc_summary.py): SCDA_WINO_LOG=<file> appends one line per launch of the three kernels, in launch order --
@@ -824,6 +969,7 @@ static int wino_launch(const float *x, const float *u, const float *bias, float 
     if (splits < 1) splits = 1;
     while (splits > 1 && (size_t)splits * M * batch * H * W * sizeof(float) > ws_bytes) --splits;
     if (pool_y) splits = 1;      // (the fused pool needs finished values in the epilogue; its callers are the 256+-tile VGG layers)
+    if ((size_t)M * batch * H * W * sizeof(float) >= ((size_t)1 << 31)) splits = 1;      // (a slab is addressed with 32-bit byte offsets)
     g.slabs_per_split = (g.n_slab + splits - 1) / splits;
     splits = (g.n_slab + g.slabs_per_split - 1) / g.slabs_per_split;
     static const int dbg = getenv("SCDA_WINO_DBG") ? atoi(getenv("SCDA_WINO_DBG")) : 0;
@@ -841,8 +987,27 @@ static int wino_launch(const float *x, const float *u, const float *bias, float 
     }
     g_wino_last[0] = MBv; g_wino_last[1] = g.pixel_major; g_wino_last[2] = gm; g_wino_last[3] = splits;
     wino_log(pool_y ? "fwd_pool" : for_dgrad ? "dgrad" : "fwd", MBv, wgs, batch, C, H, W, M, splits, alg_bytes, 2.0 * M * (double)batch * H * W * C * 4);
-    if (MBv == 2) hipLaunchKernelGGL(conv_wino_kernel<2>, dim3((unsigned)wgs), dim3(512), 0, st, u, x, g, e);
-    else hipLaunchKernelGGL(conv_wino_kernel<1>, dim3((unsigned)wgs), dim3(512), 0, st, u, x, g, e);
+    // more 64-row tiles than CUs: one persistent workgroup per CU walks them (see the kernel); SCDA_WINO_PERSIST=0 turns it off
+    static const int n_cu = [] { int d = 0, n = 0; if (hipGetDevice(&d) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || n < 8) n = 256; return n / 8 * 8; }();
+    const char *pe = getenv("SCDA_WINO_PERSIST");
+    const bool persist = MBv == 2 && wgs > n_cu && g.slabs_per_split >= 2 && g.n_slab >= 2 && !(pe && pe[0] == '0') &&
+                         (size_t)M * batch * H * W * sizeof(float) < ((size_t)1 << 31);
+    g.n_wg = (int)wgs;
+    g_wino_last_persist = persist ? 1 : 0;
+    const int epi = splits > 1 ? WEPI_SPLIT : pool_y ? WEPI_POOL : mask_src ? WEPI_MASK : WEPI_PLAIN;
+#define WINO_LAUNCH(MB_, P_, E_) hipLaunchKernelGGL((conv_wino_kernel<MB_, P_, E_>), dim3((unsigned)((P_) ? n_cu : wgs)), dim3(512), 0, st, u, x, g, e)
+#define WINO_LAUNCH_EPI(MB_, P_)                                                      \
+    do {                                                                              \
+        if (epi == WEPI_SPLIT) { if (!(P_)) WINO_LAUNCH(MB_, false, WEPI_SPLIT); }    \
+        else if (epi == WEPI_POOL) WINO_LAUNCH(MB_, P_, WEPI_POOL);                   \
+        else if (epi == WEPI_MASK) WINO_LAUNCH(MB_, P_, WEPI_MASK);                   \
+        else WINO_LAUNCH(MB_, P_, WEPI_PLAIN);                                        \
+    } while (0)
+    if (persist) WINO_LAUNCH_EPI(2, true);       // (a persistent launch never splits: it has more tiles than CUs)
+    else if (MBv == 2) WINO_LAUNCH_EPI(2, false);
+    else WINO_LAUNCH_EPI(1, false);
+#undef WINO_LAUNCH_EPI
+#undef WINO_LAUNCH
     prof_end(st);
     int rc = launch_status("conv_wino_kernel");
     if (rc || splits == 1) return rc;
@@ -899,6 +1064,8 @@ SCDA_API int scda_conv2d_wino_wgrad_hip(const float *dy, const float *x, float *
     if (rc) return rc;
     return launch_wgrad_reduce(wsf, splits, (long long)Cout * Cin * 9, Cin * 9, accumulate, dw, db_ws, db, Cout, db_accumulate, st);
 }
+
+SCDA_API int scda_debug_wino_last_persistent(void) { return g_wino_last_persist; }
 
 SCDA_API void scda_debug_wino_last_order(int *out6) {
     for (int i = 0; i < 4; ++i) out6[i] = g_wino_last[i];

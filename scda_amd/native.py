@@ -1009,6 +1009,11 @@ def last_plan():
     return out[0], out[1], out[2], bool(out[3])
 
 
+def wino_last_persistent():
+    """was this thread's most recent Winograd forward / data-gradient launch the persistent form (one workgroup per CU walking the tiles)?"""
+    return bool(lib().scda_debug_wino_last_persistent())
+
+
 def wino_last_order():
     """launch order of this thread's most recent Winograd launches: ((tile rows / 32, pixel-block-major?, gm, splits), (wgrad splits, wgrad order))"""
     out = (ctypes.c_int * 6)()

@@ -31,6 +31,7 @@ WINO_CASES = [
     (1, 64, 6, 20, 64),       # one PARTIAL block: 6 of 8 rows, 20 of 32 columns
     (2, 128, 50, 84, 128),    # ResNet layer3's 50 x 84 maps: partial blocks on the right and bottom edges, batch 2
     (1, 32, 100, 168, 72),    # layer2's 100 x 168
+    (3, 64, 70, 200, 72),     # 378 tiles of 64 rows: the PERSISTENT form on three images, partial blocks on both edges, a partial second m-tile
 ]
 
 
@@ -243,3 +244,29 @@ def test_wino_wgrad_split_groups_give_the_same_result(cuda, case, splits, monkey
     assert torch.equal(dw0, dw1) and torch.equal(db0, db1)
     close(dw1, w.grad); close(db1, bias.grad)
 
+
+
+@pytest.mark.parametrize("case", [(1, 256, 128, 256, 256), (3, 72, 70, 200, 72), (1, 64, 256, 512, 64)])
+def test_wino_persistent_form_is_bit_identical_to_one_tile_per_workgroup(cuda, case, monkeypatch):
+    """launches of more 64-row tiles than CUs run as one persistent workgroup per CU that walks the tiles (next tile's patches requested
+    before the epilogue, stores left to drain under the next K loop): forward (bias + activation), data gradient with the fused
+    activation mask, and conv + pool -- same bits as the one-tile-per-workgroup launch, and the form is really taken"""
+    from scda_amd import native
+    B, Cin, H, W, Cout = case
+    g = torch.Generator().manual_seed(sum(case) + 9)
+    x = torch.randn(B, Cin, H, W, generator=g).to(cuda)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).to(cuda)
+    b = torch.randn(Cout, generator=g).to(cuda)
+    dy = torch.randn(B, Cout, H, W, generator=g).to(cuda)
+    uf, ud = native.conv2d_wino_pack(w, False), native.conv2d_wino_pack(w, True)
+    got = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SCDA_WINO_PERSIST", mode)
+        y = native.conv2d_wino(x, uf, b, Cout, 1, 0.01)
+        assert native.wino_last_persistent() == (mode == "1") and native.wino_last_order()[0][0] == 2
+        dx = native.conv2d_wino(dy, ud, None, Cin, mask_src=x, mask_slope=0.1, for_dgrad=True)
+        assert native.wino_last_persistent() == (mode == "1")
+        yp = native.conv2d_wino_pool(x, uf, b, Cout, 1, 0.01) if H % 4 == 0 and W % 4 == 0 else (y, y)
+        got[mode] = (y, dx) + tuple(yp)
+    for a, c in zip(got["1"], got["0"]):
+        assert torch.equal(a, c)
