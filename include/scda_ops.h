@@ -271,6 +271,12 @@ int scda_conv2d_wino_hip(const float *x, const float *u, const float *bias, floa
 /* conv3x3 + bias + activation + nn.MaxPool2d(2, 2) in ONE launch (a Winograd tile is a pooling window): pool_y [batch,M,H/2,W/2] and
  * pool_idx (uint8 winner 0..3, scda_maxpool2x2_fwd_hip's convention: the backward is scda_maxpool2x2_bwd[_relu]_hip as usual); the
  * full-resolution map is never written.  The pools of vgg_adver_expansion_cluster.py:101-114 behind conv1_2 / 2_2 / 3_3 / 4_3. */
+/* the same on x [1, C, maps * 7, 7] read as a vertical STACK of `maps` independent 7 x 7 maps (row period 7, see scda_conv2d_fwd_hip's
+ * row_period: the channel-major RoI head of models/mask_rcnn/resnet.py:131-148): four maps per pixel block, as 8 x 8 each with row /
+ * column 7 discarded; y [1, M, maps * 7, 7].  scda_conv2d_wino_stacked_supported: C % 8 == 0, tensors below 2 GB. */
+int scda_conv2d_wino_stacked_supported(int maps, int C, int M);
+int scda_conv2d_wino_stacked_hip(const float *x, const float *u, const float *bias, float *y, int maps, int C, int M, int act, float slope,
+                                 const float *mask_src, float mask_slope, int for_dgrad, void *ws, size_t ws_bytes, void *stream);
 int scda_conv2d_wino_pool_hip(const float *x, const float *u, const float *bias, float *pool_y, unsigned char *pool_idx, int batch, int C,
                               int H, int W, int M, int act, float slope, void *stream);
 /* ... and the weight gradient in the same (transposed) algorithm: dw [Cout,Cin,3,3] (+)= G^T [ sum over 2x2 tiles (A dy A^T) .*

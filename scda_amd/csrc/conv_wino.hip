@@ -82,6 +82,12 @@ struct WinoGeom {
     int pixel_major, npb, per_xcd;   // XCD-aware order with the pixel block outermost (see the kernel); pixel blocks of the launch;
                                      // (split, pixel block) items per XCD
     int n_wg;                        // tiles (workgroup slots) of the launch: what a one-tile-per-workgroup grid would be
+    int stack;                       // > 0: the image [1, C, stack * 7, 7] is a vertical stack of that many independent 7 x 7 maps (row
+                                     // period 7: the channel-major RoI head of the ResNet-50 C4 detector).  A pixel block = FOUR maps side
+                                     // by side as 8 x 8 each (4 x 4 tiles, row / column 7 discarded): in patch coordinates a map's columns
+                                     // sit at 8 k + 1 .. 8 k + 7 with ONE zero column between neighbours -- it is the left padding of map
+                                     // k and the (non-existent) column 7 of map k - 1 at once -- and rows 1 .. 7 between two zero rows, so
+                                     // the K loop is the plain one; only the patch offsets and the output addressing differ
     int gm_mask, gm_shift;           // ... with the 8 XCDs split gm x (8 / gm) over m-tile groups x pixel-block runs: gm - 1, log2(gm)
     Div dNML;                        // m-tiles per XCD (n_mt / gm)
 };
@@ -220,6 +226,12 @@ __global__ __launch_bounds__(512, (MB == 2 ? 2 : 4)) void conv_wino_kernel(const
             const int ch = slot / W_CS, rem = slot - ch * W_CS;
             const int row = rem / W_RS, sl = rem - row * W_RS;
             const int col = sl < 17 ? 2 * sl : (sl >= 20 && sl < 37) ? 2 * (sl - 20) + 1 : -1;
+            if (g.stack) {      // patch column col >= 1: map (col - 1) / 8 of the block's four, its column (col - 1) % 8; row - 1 = its row
+                const int map = (t.y0 >> 1) + ((col - 1) >> 3), mx = (col - 1) & 7, my = row - 1;
+                const bool ok = ch < WBK && col >= 1 && col <= 32 && mx < 7 && (unsigned)my < 7u && map < g.stack;
+                c.dma_off[i] = ok ? (unsigned)((ch * plane + (map * 7 + my) * 7 + mx) * 4) : 0x80000000u;
+                continue;
+            }
             const int gy = t.y0 - 1 + row, gx = t.x0 - 1 + col;
             const bool ok = ch < WBK && col >= 0 && (unsigned)gy < (unsigned)g.H && (unsigned)gx < (unsigned)g.W;
             c.dma_off[i] = ok ? (unsigned)((ch * plane + gy * g.W + gx) * 4) : 0x80000000u;
@@ -415,8 +427,12 @@ __global__ __launch_bounds__(512, (MB == 2 ? 2 : 4)) void conv_wino_kernel(const
                                                                           : (const void *)(e.out + (size_t)t.img * g.M * plane));
         const __amdgpu_buffer_rsrc_t r_idx = wino_rsrc(EPI == WEPI_POOL ? (const void *)(e.pool_idx + (size_t)t.img * g.M * (plane >> 2)) : (const void *)e.out);
         const __amdgpu_buffer_rsrc_t r_msk = wino_rsrc(EPI == WEPI_MASK ? (const void *)(e.mask_src + (size_t)t.img * g.M * plane) : (const void *)e.out);
-        const int oy = t.y0 + 2 * (ln >> 4), ox = t.x0 + 2 * (ln & 15);
-        const bool in_img = oy < g.H && ox < g.W;      // (H, W even: a tile is inside the image or outside, never across)
+        // stacked 7 x 7 maps: tile column tc of the block belongs to map tc >> 2; the tile's pixels (row 2 tr + a, column 2 (tc & 3) + b)
+        // exist where the coordinate is < 7 -- four single stores with their own range checks instead of two pairs
+        const int s_map = (t.y0 >> 1) + ((ln & 15) >> 2), s_y = 2 * (ln >> 4), s_x = 2 * (ln & 3);
+        const int oy = g.stack ? s_map * 7 + s_y : t.y0 + 2 * (ln >> 4), ox = g.stack ? s_x : t.x0 + 2 * (ln & 15);
+        const bool in_img = g.stack ? s_map < g.stack : (oy < g.H && ox < g.W);      // (H, W even: a tile is inside the image or outside, never across)
+        const bool s_row1 = s_y + 1 < 7, s_col1 = s_x + 1 < 7;
         const unsigned pix = (unsigned)(oy * g.W + ox);
         auto out_off = [&](const int pass, const int q) -> unsigned {     // byte offset of (row m, this lane's tile) in the full-resolution map
             const int m = t.mt * (32 * MB) + pass * RP + q * 8 + wave;
@@ -425,13 +441,33 @@ __global__ __launch_bounds__(512, (MB == 2 ? 2 : 4)) void conv_wino_kernel(const
         // the producer's activation mask of the data gradient: loaded ONE PASS AHEAD, so that waiting for it does not wait for this
         // pass's stores
         wino_f2 mk[RP / 8][2];
+        auto stack_off = [&](const unsigned o, const int k) -> unsigned {      // element k = 2 a + b of a stacked map's tile
+            const bool ok = o != 0x80000000u && (!(k & 1) || s_col1) && (!(k >> 1) || s_row1);
+            return ok ? o + (unsigned)(((k >> 1) * 7 + (k & 1)) * 4) : 0x80000000u;
+        };
         auto load_mask = [&](const int pass) {
 #pragma unroll
             for (int q = 0; q < RP / 8; ++q) {
                 const unsigned o = out_off(pass, q);
+                if (g.stack) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        mk[q][k >> 1][k & 1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_msk, stack_off(o, k), 0, 0));
+                    continue;
+                }
                 mk[q][0] = __builtin_bit_cast(wino_f2, __builtin_amdgcn_raw_buffer_load_b64(r_msk, o, 0, 0));
                 mk[q][1] = __builtin_bit_cast(wino_f2, __builtin_amdgcn_raw_buffer_load_b64(r_msk, o, g.W * 4, 0));
             }
+        };
+        auto store4 = [&](const __amdgpu_buffer_rsrc_t r, const unsigned o, const float a, const float b2, const float c2, const float d) {
+            if (g.stack) {
+                const float v[4] = {a, b2, c2, d};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v[k]), r, stack_off(o, k), 0, 0);
+                return;
+            }
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(wino_i2, wino_f2{a, b2}), r, o, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(wino_i2, wino_f2{c2, d}), r, o, g.W * 4, 0);
         };
         constexpr bool masked = EPI == WEPI_MASK;
         if (masked) load_mask(0);
@@ -479,8 +515,7 @@ __global__ __launch_bounds__(512, (MB == 2 ? 2 : 4)) void conv_wino_kernel(const
                 const unsigned o = out_off(pass, q);
                 if (EPI == WEPI_SPLIT) {      // a split-K slab in the natural pixel order: ws[split][m][image][pixel]
                     const unsigned os = (in_img && m < g.M) ? (unsigned)(((size_t)m * N + pix) * 4) : 0x80000000u;
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(wino_i2, wino_f2{y00, y01}), r_out, os, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(wino_i2, wino_f2{y10, y11}), r_out, os, g.W * 4, 0);
+                    store4(r_out, os, y00, y01, y10, y11);
                     continue;
                 }
 #if defined(WINO_DBG_BIAS_VEC)
@@ -507,8 +542,7 @@ __global__ __launch_bounds__(512, (MB == 2 ? 2 : 4)) void conv_wino_kernel(const
                     y00 = k0[0] > 0.f ? y00 : y00 * e.mask_slope; y01 = k0[1] > 0.f ? y01 : y01 * e.mask_slope;
                     y10 = k1[0] > 0.f ? y10 : y10 * e.mask_slope; y11 = k1[1] > 0.f ? y11 : y11 * e.mask_slope;
                 }
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(wino_i2, wino_f2{y00, y01}), r_out, o, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(wino_i2, wino_f2{y10, y11}), r_out, o, g.W * 4, 0);
+                store4(r_out, o, y00, y01, y10, y11);
             }
         }
     };
@@ -906,17 +940,20 @@ static void wino_log(const char *kind, int mb, long long wgs, int batch, int C, 
     fflush(f);
 }
 
+SCDA_API int scda_conv2d_wino_stacked_supported(int maps, int C, int M);
+
 static int wino_launch(const float *x, const float *u, const float *bias, float *y, int batch, int C, int H, int W, int M, int act,
                        float slope, const float *mask_src, float mask_slope, int for_dgrad, void *ws, size_t ws_bytes, void *stream,
-                       float *pool_y, unsigned char *pool_idx) {
+                       float *pool_y, unsigned char *pool_idx, int stack = 0) {
     if (!x || !u || (!y && !pool_y)) { set_error("scda_conv2d_wino_hip: bad arguments"); return SCDA_EINVAL; }
-    if (!scda_conv2d_wino_supported(batch, C, H, W, M)) {
-        set_error("scda_conv2d_wino_hip: needs C %% 8 == 0, even H and W and tensors below 2 GB per image (C=%d H=%d W=%d)", C, H, W);
+    if (stack > 0 ? !(scda_conv2d_wino_stacked_supported(stack, C, M) && batch == 1 && H == stack * 7 && W == 7 && !pool_y)
+                  : !scda_conv2d_wino_supported(batch, C, H, W, M)) {
+        set_error("scda_conv2d_wino_hip: needs C %% 8 == 0, even H and W (or a stack of 7 x 7 maps) and tensors below 2 GB per image (C=%d H=%d W=%d)", C, H, W);
         return SCDA_EINVAL;
     }
     hipStream_t st = as_stream(stream);
     WinoGeom g;
-    g.batch = batch; g.C = C; g.H = H; g.W = W; g.M = M;
+    g.batch = batch; g.C = C; g.H = H; g.W = W; g.M = M; g.stack = stack;
     // tile rows: 64 (every fragment feeds two MFMAs), or 32 for layers with <= 32 output rows (the decoders' 64 -> 32 stage: half of
     // a 64-row tile would multiply padding).  Measured on every VGG / decoder layer (scripts/bench_wino.py, SCDA_WINO_MB=1|2): the
     // two are within 3 % of each other everywhere else -- two co-resident 32-row workgroups start and finish together, so one's
@@ -924,11 +961,12 @@ static int wino_launch(const float *x, const float *u, const float *bias, float 
     static const int force_mb = getenv("SCDA_WINO_MB") ? atoi(getenv("SCDA_WINO_MB")) : 0;
     // ... and for launches that would not fill the chip with 64-row tiles (the decoders' batch-4 residual convolutions: 128 tiles;
     // conv5_x / the RPN: 64): twice the workgroups first, split-K (slabs + a reduce launch) only for what is still missing
-    const long long tiles64 = (long long)((M + 63) / 64) * batch * ((H + 7) / 8) * ((W + 31) / 32);
+    // (a stack of 7 x 7 maps: one block column, a block row per four maps)
+    const int nbx = stack ? 1 : (W + 31) / 32, nby = stack ? (stack + 3) / 4 : (H + 7) / 8, npb = batch * nby * nbx;   // blocks on the right / bottom edge may be partial
+    const long long tiles64 = (long long)((M + 63) / 64) * npb;
     const int MBv = force_mb == 1 || force_mb == 2 ? force_mb : ((M <= 32 || tiles64 < 200) ? 1 : 2);
     g.n_mbg = (M + 63) / 64 * 2;
     g.n_mt = (M + 32 * MBv - 1) / (32 * MBv); g.n_slab = C / WBK;
-    const int nbx = (W + 31) / 32, nby = (H + 7) / 8, npb = batch * nby * nbx;   // blocks on the right / bottom edge may be partial
     g.dNMT = Div(g.n_mt); g.dNPB = Div(npb); g.dNB = Div(nby * nbx); g.dNBX = Div(nbx);
     // XCD order: pixel-block-major when all m-tiles' filters can stream through one XCD's 4 MB L2 beside the patches (<= 4.5 MB: every
     // layer below 512 output channels; conv3_2's 4.2 MB: 290 -> 109 MB read per launch), m-tile-major otherwise
@@ -1012,6 +1050,18 @@ static int wino_launch(const float *x, const float *u, const float *bias, float 
     int rc = launch_status("conv_wino_kernel");
     if (rc || splits == 1) return rc;
     return launch_conv_reduce((const float *)ws, splits, M, batch * H * W, H * W, bias, act, slope, y, mask_src, mask_slope, st);
+}
+
+SCDA_API int scda_conv2d_wino_stacked_supported(int maps, int C, int M) {
+    return maps > 0 && M > 0 && C >= WBK && (C % WBK) == 0 && (long long)C * maps * 49 * 4 < (1LL << 31) && (long long)M * maps * 49 * 4 < (1LL << 31);
+}
+
+// the same on x [1, C, maps * 7, 7] read as a vertical stack of `maps` independent 7 x 7 maps (row period 7: no tap reaches from one
+// map into the next) -- the 3x3 convolutions of the ResNet-50 C4 detector's channel-major RoI head (models/mask_rcnn/resnet.py:131-148)
+SCDA_API int scda_conv2d_wino_stacked_hip(const float *x, const float *u, const float *bias, float *y, int maps, int C, int M, int act,
+                                          float slope, const float *mask_src, float mask_slope, int for_dgrad, void *ws, size_t ws_bytes,
+                                          void *stream) {
+    return wino_launch(x, u, bias, y, 1, C, maps * 7, 7, M, act, slope, mask_src, mask_slope, for_dgrad, ws, ws_bytes, stream, nullptr, nullptr, maps);
 }
 
 SCDA_API int scda_conv2d_wino_wgrad_supported(int batch, int Cin, int H, int W, int Cout) {

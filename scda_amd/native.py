@@ -361,12 +361,22 @@ def wino_min_channels():
     return int(os.environ.get("SCDA_WINOGRAD_MIN_C", "32"))
 
 
+def wino_stacked(B, IH, IW, row_period):
+    """the image is a stack of 7 x 7 maps (the ResNet-50 C4 detector's channel-major RoI head): -> number of maps, else 0"""
+    if row_period == 7 and IW == 7 and B == 1 and IH % 7 == 0 and os.environ.get("SCDA_WINO_STACKED", "1") != "0":
+        return IH // 7
+    return 0
+
+
 def wino_ok(B, Cin, IH, IW, Cout, KH, KW, stride, pad, row_period=0):
     """this convolution (forward: reduced channels Cin, output rows Cout; both at least wino_min_channels()) takes the Winograd path"""
-    if not (wino_enabled() and KH == 3 and KW == 3 and stride == 1 and pad == 1 and not row_period):
+    if not (wino_enabled() and KH == 3 and KW == 3 and stride == 1 and pad == 1):
         return False
     if min(Cin, Cout) < wino_min_channels():
         return False
+    if row_period:
+        maps = wino_stacked(B, IH, IW, row_period)
+        return bool(maps and lib().scda_conv2d_wino_stacked_supported(i32(maps), i32(Cin), i32(Cout)))
     return bool(lib().scda_conv2d_wino_supported(i32(B), i32(Cin), i32(IH), i32(IW), i32(Cout)))
 
 
@@ -422,11 +432,19 @@ def conv2d_wino_pack(w, for_dgrad=False, cache=True):
     return out
 
 
-def conv2d_wino(x, u, bias, M, act=ACT_NONE, slope=0.01, mask_src=None, mask_slope=0.0, for_dgrad=False):
-    """one Winograd launch: y [B, M, H, W] from x [B, C, H, W] and packed filters u (forward, or the data gradient with x = dy)"""
+def conv2d_wino(x, u, bias, M, act=ACT_NONE, slope=0.01, mask_src=None, mask_slope=0.0, for_dgrad=False, row_period=0):
+    """one Winograd launch: y [B, M, H, W] from x [B, C, H, W] and packed filters u (forward, or the data gradient with x = dy);
+    row_period = 7 on a [1, C, R * 7, 7] tensor: a stack of R independent 7 x 7 maps"""
     B, C, H, W = x.shape
     y = torch.empty(B, M, H, W, dtype=torch.float32, device=x.device)
     ws, n = _conv_ws(B, C, H, W, M, 3, 3, 1, 1, x.device)
+    if row_period:
+        maps = wino_stacked(B, H, W, row_period)
+        if not maps:
+            raise ValueError("conv2d_wino: row_period %d on %s is not a stack of 7 x 7 maps" % (row_period, tuple(x.shape)))
+        _check(lib().scda_conv2d_wino_stacked_hip(_p(x), _p(u), _p(bias), _p(y), i32(maps), i32(C), i32(M), i32(act), f32(slope), _p(mask_src),
+                                                  f32(mask_slope), i32(int(for_dgrad)), _p(ws), _sz(n), _stream()), "scda_conv2d_wino_stacked_hip")
+        return y
     _check(lib().scda_conv2d_wino_hip(_p(x), _p(u), _p(bias), _p(y), i32(B), i32(C), i32(H), i32(W), i32(M), i32(act), f32(slope),
                                       _p(mask_src), f32(mask_slope), i32(int(for_dgrad)), _p(ws), _sz(n), _stream()), "scda_conv2d_wino_hip")
     return y
@@ -435,7 +453,7 @@ def conv2d_wino(x, u, bias, M, act=ACT_NONE, slope=0.01, mask_src=None, mask_slo
 def conv_pool_fusable(B, Cin, IH, IW, Cout, KH, KW, stride, pad, row_period=0):
     """conv3x3 + activation + 2x2 max-pool can run as one Winograd launch: an eligible layer on an even map with enough tiles to fill the
     chip without split-K (the fused epilogue needs finished values).  SCDA_CONV_POOL_FUSE=0 keeps the pool a launch of its own."""
-    if os.environ.get("SCDA_CONV_POOL_FUSE", "1") == "0" or not wino_ok(B, Cin, IH, IW, Cout, KH, KW, stride, pad, row_period):
+    if row_period or os.environ.get("SCDA_CONV_POOL_FUSE", "1") == "0" or not wino_ok(B, Cin, IH, IW, Cout, KH, KW, stride, pad, row_period):
         return False
     return ((Cout + 63) // 64) * B * ((IH + 7) // 8) * ((IW + 31) // 32) >= 200
 
@@ -505,7 +523,7 @@ def conv2d_fwd(x, w, bias, stride, pad, act=ACT_NONE, slope=0.01, row_period=0):
     if isinstance(w, torch.nn.Parameter):
         w._scda_wino_used = use_wino       # conv2d_pack_all re-packs the layouts the layer's calls actually use
     if use_wino:
-        return conv2d_wino(x, conv2d_wino_pack(w, False), bias, Cout, act, slope)
+        return conv2d_wino(x, conv2d_wino_pack(w, False), bias, Cout, act, slope, row_period=row_period)
     wp = conv2d_pack_weight(w, False)
     y = torch.empty(B, Cout, OH, OW, dtype=torch.float32, device=x.device)
     ws, n = _conv_ws(B, Cin, IH, IW, Cout, KH, KW, stride, pad, x.device)
@@ -526,7 +544,7 @@ def conv2d_dgrad(dy, w, x_shape, stride, pad, act_src=None, act_slope=0.0, row_p
         if tuple(act_src.shape) != tuple(x_shape):
             raise ValueError("act_src must have the shape of the conv input")
     if wino_ok(B, Cout, IH, IW, Cin, KH, KW, stride, pad, row_period):
-        return conv2d_wino(dy, conv2d_wino_pack(w, True), None, Cin, ACT_NONE, 0.0, act_src, act_slope, for_dgrad=True)
+        return conv2d_wino(dy, conv2d_wino_pack(w, True), None, Cin, ACT_NONE, 0.0, act_src, act_slope, for_dgrad=True, row_period=row_period)
     dx = torch.empty(B, Cin, IH, IW, dtype=torch.float32, device=dy.device)
     if act_src is None and Cin <= 4 and Cout * KH * KW * 16 <= 65536 and (KH, KW) in ((3, 3), (1, 1)):
         # image-side layer: 3 rows of a 64-row MFMA tile would be 95 % padding -- direct kernel, unpacked weights

@@ -270,3 +270,34 @@ def test_wino_persistent_form_is_bit_identical_to_one_tile_per_workgroup(cuda, c
         got[mode] = (y, dx) + tuple(yp)
     for a, c in zip(got["1"], got["0"]):
         assert torch.equal(a, c)
+
+
+@pytest.mark.parametrize("case", [(512, 64, 64), (37, 72, 40), (6, 512, 512), (130, 128, 256)])
+@pytest.mark.parametrize("masked", [False, True])
+def test_wino_on_stacked_7x7_maps(cuda, case, masked, monkeypatch):
+    """x [1, C, R * 7, 7] as a stack of R independent 7 x 7 maps (row period 7: the ResNet-50 C4 detector's channel-major RoI head,
+    models/mask_rcnn/resnet.py:131-148): four maps per pixel block as 8 x 8 each.  Forward (bias + ReLU) and data gradient (with /
+    without the activation mask) against torch's batched convolution on [R, C, 7, 7], and the Winograd path is the one taken."""
+    from scda_amd import native
+    R, Cin, Cout = case
+    g = torch.Generator().manual_seed(R + Cin + Cout)
+    xb = torch.randn(R, Cin, 7, 7, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    dyb = torch.randn(R, Cout, 7, 7, generator=g)
+    stack = lambda t: t.permute(1, 0, 2, 3).reshape(1, t.shape[1], R * 7, 7).contiguous()        # [R, C, 7, 7] -> [1, C, R * 7, 7]
+    unstack = lambda t: t.reshape(t.shape[1], R, 7, 7).permute(1, 0, 2, 3)
+    assert native.wino_ok(1, Cin, R * 7, 7, Cout, 3, 3, 1, 1, 7)
+    y = native.conv2d_fwd(stack(xb).to(cuda), w.to(cuda), b.to(cuda), 1, 1, 1, 0.0, row_period=7)
+    close(unstack(y.cpu()), F.relu(F.conv2d(xb, w, b, padding=1)))
+    xg = xb.clone().requires_grad_()
+    F.conv2d(xg, w, None, padding=1).backward(dyb)
+    want = xg.grad * ((xb > 0).float() + 0.1 * (xb <= 0).float()) if masked else xg.grad
+    dx = native.conv2d_dgrad(stack(dyb).to(cuda), w.to(cuda), (1, Cin, R * 7, 7), 1, 1, act_src=stack(xb).to(cuda) if masked else None,
+                             act_slope=0.1, row_period=7)
+    close(unstack(dx.cpu()), want)
+    # ... and against the direct kernel on the same stack
+    monkeypatch.setenv("SCDA_WINO_STACKED", "0")
+    assert not native.wino_ok(1, Cin, R * 7, 7, Cout, 3, 3, 1, 1, 7)
+    y0 = native.conv2d_fwd(stack(xb).to(cuda), w.to(cuda), b.to(cuda), 1, 1, 1, 0.0, row_period=7)
+    close(y, y0, 5e-5)

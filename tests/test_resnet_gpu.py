@@ -181,6 +181,9 @@ def test_channel_major_roi_head_equals_reference_layout(cuda, monkeypatch, plane
     O(1))."""
     if not plane_bn:
         monkeypatch.setenv("SCDA_BN_NO_PLANE", "1")
+        # ... and both layouts' 3x3 convolutions on the direct kernel (the stacked 7 x 7 maps take the Winograd kernel by default,
+        # whose sums associate differently: 3e-5 per layer, tests/test_conv_wino_gpu.py::test_wino_on_stacked_7x7_maps)
+        monkeypatch.setenv("SCDA_WINO_STACKED", "0")
     import bench
     from scda_amd.dropin.models.mask_rcnn.resnet import resnet50
     from test_oracle_golden import rand_rois
@@ -208,7 +211,7 @@ def test_channel_major_roi_head_equals_reference_layout(cuda, monkeypatch, plane
                          stats={k: v.clone() for k, v in det.state_dict().items() if 'layer4' in k and 'running' in k})
     assert any(k.startswith("layer4.0.conv2") for k in res["tall"]["grads"])
     for k in ("x_fea", "cls", "loc"):
-        close(res["tall"][k], res["nchw"][k], 2e-5)
+        close(res["tall"][k], res["nchw"][k], 2e-4 if plane_bn else 2e-5)      # (default build: Winograd against the direct kernel)
     for k, v in res["nchw"]["stats"].items():
         close(res["tall"]["stats"][k], v, 1e-5)
     if plane_bn:
