@@ -285,6 +285,11 @@ int scda_conv2d_wino_pool_hip(const float *x, const float *u, const float *bias,
 int scda_conv2d_wino_wgrad_supported(int batch, int Cin, int H, int W, int Cout);
 int scda_conv2d_wino_wgrad_hip(const float *dy, const float *x, float *dw, float *db, int batch, int Cin, int H, int W, int Cout,
                                int accumulate, int db_accumulate, void *ws, size_t ws_bytes, void *stream);
+/* ... on dy [1, Cout, maps * 7, 7] / x [1, Cin, maps * 7, 7] read as stacks of `maps` independent 7 x 7 maps (row period 7, see
+ * scda_conv2d_wino_stacked_hip): a K-slab is one tile row of a pair of maps */
+int scda_conv2d_wino_wgrad_stacked_supported(int maps, int Cin, int Cout);
+int scda_conv2d_wino_wgrad_stacked_hip(const float *dy, const float *x, float *dw, float *db, int maps, int Cin, int Cout, int accumulate,
+                                       int db_accumulate, void *ws, size_t ws_bytes, void *stream);
 
 /* C[M,N] (row stride ldc) (+)= op(A) op(B) (+ bias) -> act
  * trans_a = 0: A is [M,K] row-major (lda);  1: A is stored [K,M]

@@ -610,6 +610,11 @@ struct WinoWgradGeom {
     int splits, splits_per_xcd;
     int sp_mask, sp_shift;       // fewer than 8 splits (2 or 4): XCD x serves split x & sp_mask and m-tile group x >> sp_shift (-1: off)
     Div dNMT, dNCT, dTX, dTY, dNML;   // dNML: m-tiles per group
+    int stack;                   // > 0: dY [1, M, stack * 7, 7] / X [1, C, stack * 7, 7] are stacks of that many 7 x 7 maps (WinoGeom::stack).
+                                 // A K-slab = one tile row (of four: rows 2 t, 2 t + 1, row 7 zero) of a PAIR of maps -- 2 x 4 tiles;
+                                 // the cursor runs (pair, tile row) with TY = 4, TX = 1; patch columns as in the forward kernel: X
+                                 // columns 1 .. 7 and 9 .. 15 are the two maps, 0 / 8 / 16 the zero columns between them, dY column 7 /
+                                 // 15 (a map's column 7) zero
 };
 
 __global__ __launch_bounds__(512, 2) void conv_wino_wgrad_kernel(const float *__restrict__ dY, const float *__restrict__ X,
@@ -650,11 +655,34 @@ __global__ __launch_bounds__(512, 2) void conv_wino_wgrad_kernel(const float *__
     unsigned dma_off[G_DMA];
     unsigned long long xbits = 0;     // 4 bits per instruction: the lane's element is in patch row 0 / row 3 / column 0 / column 17
     unsigned pbits = 0;               // 1 bit per instruction: the lane's element lies beyond the image in a row's PARTIAL last slab
-    const int rem = g.W & 15;         // (W % 16 != 0: that slab holds rem / 2 real tiles; the others see zeros on both operands)
+    const int rem = g.stack ? 0 : (g.W & 15);         // (W % 16 != 0: that slab holds rem / 2 real tiles; the others see zeros on both operands)
 #pragma unroll
     for (int i = 0; i < G_DMA; ++i) {
         const int r = wave * G_DMA + i;
         unsigned off = 0x80000000u;
+        if (g.stack) {
+            // stacked maps: xbits bit 0 = the element is in a row that does not exist in tile row 0 (X row 0), bit 1 = ... in tile row 3
+            // (X rows 2 and 3 = map rows 7 and 8, dY row 1 = map row 7); pbits = the element belongs to the pair's SECOND map
+            if (r < G_YR) {
+                const int slot = r * 64 + lane, ch = slot / G_YS, e = slot - ch * G_YS;
+                const int p = e >> 4, c = e & 15;
+                if (e < 32 && m0 + ch < g.M && (c & 7) < 7) {
+                    off = (unsigned)((ch * plane + ((c >> 3) * 7 + p) * 7 + (c & 7)) * 4);
+                    xbits |= (unsigned long long)((p == 1) << 1) << (4 * i);
+                    pbits |= (unsigned)(c >> 3) << i;
+                }
+            } else if (r < G_YR + G_XR) {
+                const int slot = (r - G_YR) * 64 + lane, ch = slot / G_XS, e = slot - ch * G_XS;
+                const int row = e / 18, col = e - row * 18;
+                if (e < 72 && c0 + ch < g.C && col >= 1 && col <= 16 && ((col - 1) & 7) < 7) {
+                    off = (unsigned)((ch * plane + (((col - 1) >> 3) * 7 + row) * 7 + ((col - 1) & 7)) * 4);   // relative to row 2 t - 1: the base is moved back
+                    xbits |= (unsigned long long)((row == 0) | ((row >= 2) << 1)) << (4 * i);
+                    pbits |= (unsigned)((col - 1) >> 3) << i;
+                }
+            }
+            dma_off[i] = off;
+            continue;
+        }
         if (r < G_YR) {
             const int slot = r * 64 + lane, ch = slot / G_YS, e = slot - ch * G_YS;
             if (e < 32 && m0 + ch < g.M) {
@@ -686,6 +714,18 @@ __global__ __launch_bounds__(512, 2) void conv_wino_wgrad_kernel(const float *__
     int d_soff = 0;
     unsigned d_edge = 0, d_pm = 0;
     auto dma_prepare = [&]() {
+        if (g.stack) {      // cursor = (pair q_img, tile row q_ty)
+            d_yb = reinterpret_cast<const char *>(dY + (size_t)m0 * plane);
+            d_xb = reinterpret_cast<const char *>(X + (size_t)c0 * plane) - 7 * 4;
+            d_soff = ((2 * q_img * 7 + 2 * q_ty) * 7) * 4;
+            d_edge = (unsigned)(q_ty == 0) | ((unsigned)(q_ty == 3) << 1);
+            d_pm = (2 * q_img + 1 >= g.stack) ? pbits : 0u;
+            if (q_s + 1 < s_end) {
+                ++q_s;
+                if (++q_ty == 4) { q_ty = 0; ++q_img; }
+            }
+            return;
+        }
         d_yb = reinterpret_cast<const char *>(dY + ((size_t)q_img * g.M + m0) * plane);
         d_xb = reinterpret_cast<const char *>(X + ((size_t)q_img * g.C + c0) * plane) - (g.W + 1) * 4;
         d_soff = (2 * q_ty * g.W + 16 * q_tx) * 4;
@@ -1068,20 +1108,24 @@ SCDA_API int scda_conv2d_wino_wgrad_supported(int batch, int Cin, int H, int W, 
     return batch > 0 && Cin >= 64 && Cout >= 64 && (H % 2) == 0 && (W % 2) == 0 && 64LL * H * W * 4 < (1LL << 31);
 }
 
-// dw [Cout,Cin,3,3] (+)= weight gradient of the stride-1, pad-1 3x3 convolution; db [Cout] (+)= bias gradient (may be NULL)
-SCDA_API int scda_conv2d_wino_wgrad_hip(const float *dy, const float *x, float *dw, float *db, int batch, int Cin, int H, int W, int Cout,
-                                        int accumulate, int db_accumulate, void *ws, size_t ws_bytes, void *stream) {
+SCDA_API int scda_conv2d_wino_wgrad_stacked_supported(int maps, int Cin, int Cout) {
+    return maps > 0 && Cin >= 64 && Cout >= 64 && 64LL * maps * 49 * 4 < (1LL << 31);
+}
+
+static int wino_wgrad_launch(const float *dy, const float *x, float *dw, float *db, int batch, int Cin, int H, int W, int Cout,
+                             int accumulate, int db_accumulate, void *ws, size_t ws_bytes, void *stream, int stack) {
     if (!dy || !x || !dw || !ws) { set_error("scda_conv2d_wino_wgrad_hip: bad arguments"); return SCDA_EINVAL; }
-    if (!scda_conv2d_wino_wgrad_supported(batch, Cin, H, W, Cout)) {
-        set_error("scda_conv2d_wino_wgrad_hip: needs >= 64 channels on both sides and even H, W (Cin=%d Cout=%d H=%d W=%d)", Cin, Cout, H, W);
+    if (stack > 0 ? !(scda_conv2d_wino_wgrad_stacked_supported(stack, Cin, Cout) && batch == 1 && H == stack * 7 && W == 7)
+                  : !scda_conv2d_wino_wgrad_supported(batch, Cin, H, W, Cout)) {
+        set_error("scda_conv2d_wino_wgrad_hip: needs >= 64 channels on both sides and even H, W or a stack of 7 x 7 maps (Cin=%d Cout=%d H=%d W=%d)", Cin, Cout, H, W);
         return SCDA_EINVAL;
     }
     hipStream_t st = as_stream(stream);
     WinoWgradGeom g;
-    g.batch = batch; g.C = Cin; g.H = H; g.W = W; g.M = Cout;
+    g.batch = batch; g.C = Cin; g.H = H; g.W = W; g.M = Cout; g.stack = stack;
     const int n_mt = (Cout + 63) / 64;
-    g.n_ct = (Cin + 63) / 64; g.TY = H / 2; g.TX = (W + 15) / 16;
-    g.n_slab = batch * g.TY * g.TX;
+    g.n_ct = (Cin + 63) / 64; g.TY = stack ? 4 : H / 2; g.TX = stack ? 1 : (W + 15) / 16;
+    g.n_slab = stack ? (stack + 1) / 2 * 4 : batch * g.TY * g.TX;
     g.dNMT = Div(n_mt); g.dNCT = Div(g.n_ct); g.dTX = Div(g.TX); g.dTY = Div(g.TY);
     const long long tiles = (long long)n_mt * g.n_ct;
     const size_t slab_bytes = (size_t)Cout * Cin * 9 * sizeof(float), db_bytes = db ? (size_t)1024 * Cout * sizeof(float) : 0;
@@ -1116,6 +1160,18 @@ SCDA_API int scda_conv2d_wino_wgrad_hip(const float *dy, const float *x, float *
 }
 
 SCDA_API int scda_debug_wino_last_persistent(void) { return g_wino_last_persist; }
+
+// dw [Cout,Cin,3,3] (+)= weight gradient of the stride-1, pad-1 3x3 convolution; db [Cout] (+)= bias gradient (may be NULL)
+SCDA_API int scda_conv2d_wino_wgrad_hip(const float *dy, const float *x, float *dw, float *db, int batch, int Cin, int H, int W, int Cout,
+                                        int accumulate, int db_accumulate, void *ws, size_t ws_bytes, void *stream) {
+    return wino_wgrad_launch(dy, x, dw, db, batch, Cin, H, W, Cout, accumulate, db_accumulate, ws, ws_bytes, stream, 0);
+}
+
+// ... on dy [1, Cout, maps * 7, 7] / x [1, Cin, maps * 7, 7] read as stacks of `maps` independent 7 x 7 maps (scda_conv2d_wino_stacked_hip)
+SCDA_API int scda_conv2d_wino_wgrad_stacked_hip(const float *dy, const float *x, float *dw, float *db, int maps, int Cin, int Cout,
+                                                int accumulate, int db_accumulate, void *ws, size_t ws_bytes, void *stream) {
+    return wino_wgrad_launch(dy, x, dw, db, 1, Cin, maps * 7, 7, Cout, accumulate, db_accumulate, ws, ws_bytes, stream, maps);
+}
 
 SCDA_API void scda_debug_wino_last_order(int *out6) {
     for (int i = 0; i < 4; ++i) out6[i] = g_wino_last[i];

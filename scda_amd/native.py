@@ -382,13 +382,15 @@ def wino_ok(B, Cin, IH, IW, Cout, KH, KW, stride, pad, row_period=0):
 
 def wino_wgrad_ok(B, Cin, IH, IW, Cout, KH, KW, stride, pad, row_period=0):
     """this weight gradient takes the Winograd kernel (SCDA_WINOGRAD_WGRAD=0 keeps it on the direct one)"""
-    if not (wino_enabled() and os.environ.get("SCDA_WINOGRAD_WGRAD", "1") != "0" and KH == 3 and KW == 3 and stride == 1 and pad == 1
-            and not row_period):
+    if not (wino_enabled() and os.environ.get("SCDA_WINOGRAD_WGRAD", "1") != "0" and KH == 3 and KW == 3 and stride == 1 and pad == 1):
         return False
+    if row_period:
+        maps = wino_stacked(B, IH, IW, row_period)
+        return bool(maps and lib().scda_conv2d_wino_wgrad_stacked_supported(i32(maps), i32(Cin), i32(Cout)))
     return bool(lib().scda_conv2d_wino_wgrad_supported(i32(B), i32(Cin), i32(IH), i32(IW), i32(Cout)))
 
 
-def conv2d_wino_wgrad(dy, x, w_shape, out=None, db_out=None, want_bias=False):
+def conv2d_wino_wgrad(dy, x, w_shape, out=None, db_out=None, want_bias=False, row_period=0):
     """(dw, db) of a stride-1 pad-1 3x3 convolution on the Winograd weight-gradient kernel; accumulates into out / db_out when given"""
     _req(dy, "dy"); _req(x, "x")
     B, Cin, IH, IW = x.shape
@@ -405,6 +407,13 @@ def conv2d_wino_wgrad(dy, x, w_shape, out=None, db_out=None, want_bias=False):
         else:
             _req(db_out, "db_out"); db = db_out; dbacc = 1
     ws, n = _conv_ws(B, Cin, IH, IW, Cout, 3, 3, 1, 1, x.device)
+    if row_period:
+        maps = wino_stacked(B, IH, IW, row_period)
+        if not maps:
+            raise ValueError("conv2d_wino_wgrad: row_period %d on %s is not a stack of 7 x 7 maps" % (row_period, tuple(x.shape)))
+        _check(lib().scda_conv2d_wino_wgrad_stacked_hip(_p(dy), _p(x), _p(out), _p(db), i32(maps), i32(Cin), i32(Cout), i32(acc), i32(dbacc),
+                                                        _p(ws), _sz(n), _stream()), "scda_conv2d_wino_wgrad_stacked_hip")
+        return out, db
     _check(lib().scda_conv2d_wino_wgrad_hip(_p(dy), _p(x), _p(out), _p(db), i32(B), i32(Cin), i32(IH), i32(IW), i32(Cout), i32(acc),
                                             i32(dbacc), _p(ws), _sz(n), _stream()), "scda_conv2d_wino_wgrad_hip")
     return out, db
@@ -566,7 +575,7 @@ def conv2d_wgrad(dy, x, w_shape, stride, pad, out=None, row_period=0):
     B, Cin, IH, IW = x.shape
     Cout, _, KH, KW = w_shape
     if wino_wgrad_ok(B, Cin, IH, IW, Cout, KH, KW, stride, pad, row_period):
-        return conv2d_wino_wgrad(dy, x, w_shape, out=out)[0]
+        return conv2d_wino_wgrad(dy, x, w_shape, out=out, row_period=row_period)[0]
     acc = 0
     if out is None:
         out = torch.empty(tuple(w_shape), dtype=torch.float32, device=x.device)
@@ -587,7 +596,7 @@ def conv2d_wgrad_bias(dy, x, w_shape, stride, pad, out=None, db_out=None, row_pe
     B, Cin, IH, IW = x.shape
     Cout, _, KH, KW = w_shape
     if wino_wgrad_ok(B, Cin, IH, IW, Cout, KH, KW, stride, pad, row_period):
-        return conv2d_wino_wgrad(dy, x, w_shape, out=out, db_out=db_out, want_bias=True)
+        return conv2d_wino_wgrad(dy, x, w_shape, out=out, db_out=db_out, want_bias=True, row_period=row_period)
     L = lib()
     if not L.scda_conv2d_wgrad_bias_fusable(i32(B), i32(Cout), i32(dy.shape[2]), i32(dy.shape[3]), _p(dy)):
         return conv2d_wgrad(dy, x, w_shape, stride, pad, out=out, row_period=row_period), bias_grad_nchw(dy, out=db_out)

@@ -301,3 +301,26 @@ def test_wino_on_stacked_7x7_maps(cuda, case, masked, monkeypatch):
     assert not native.wino_ok(1, Cin, R * 7, 7, Cout, 3, 3, 1, 1, 7)
     y0 = native.conv2d_fwd(stack(xb).to(cuda), w.to(cuda), b.to(cuda), 1, 1, 1, 0.0, row_period=7)
     close(y, y0, 5e-5)
+
+
+@pytest.mark.parametrize("case", [(512, 64, 64), (37, 72, 80), (7, 128, 256)])
+def test_wino_wgrad_on_stacked_7x7_maps(cuda, case, monkeypatch):
+    """the weight (+ bias) gradient on stacks of 7 x 7 maps: a K-slab = one tile row of a pair of maps (odd map counts: the last
+    pair's second map is masked), against torch's batched convolution on [R, C, 7, 7] and the direct kernel on the same stack"""
+    from scda_amd import native
+    R, Cin, Cout = case
+    g = torch.Generator().manual_seed(R + Cin + Cout + 3)
+    xb = torch.randn(R, Cin, 7, 7, generator=g)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).requires_grad_()
+    b = torch.zeros(Cout, requires_grad=True)
+    dyb = torch.randn(R, Cout, 7, 7, generator=g)
+    F.conv2d(xb, w, b, padding=1).backward(dyb)
+    stack = lambda t: t.permute(1, 0, 2, 3).reshape(1, t.shape[1], R * 7, 7).contiguous().to(cuda)
+    assert native.wino_wgrad_ok(1, Cin, R * 7, 7, Cout, 3, 3, 1, 1, 7)
+    dw, db = native.conv2d_wgrad_bias(stack(dyb), stack(xb), w.shape, 1, 1, row_period=7)
+    close(dw, w.grad); close(db, b.grad, 2e-5)
+    dw2, db2 = native.conv2d_wgrad_bias(stack(dyb), stack(xb), w.shape, 1, 1, out=dw.clone(), db_out=db.clone(), row_period=7)
+    close(dw2, 2 * w.grad); close(db2, 2 * b.grad, 2e-5)
+    monkeypatch.setenv("SCDA_WINO_STACKED", "0")
+    assert not native.wino_wgrad_ok(1, Cin, R * 7, 7, Cout, 3, 3, 1, 1, 7)
+    close(dw, native.conv2d_wgrad_bias(stack(dyb), stack(xb), w.shape, 1, 1, row_period=7)[0], 5e-5)
