@@ -128,9 +128,9 @@ def synth_batch(rank, H=H, W=W):
 
 
 def pmc_traffic(kernel, prefix=""):
-    """-> (bytes per launch, source file, launches averaged, algorithmic bytes per launch of the SAME launches or None)"""
+    """-> (bytes per launch, source file, launches averaged, algorithmic bytes per launch of the SAME launches or None, traffic / 8-L2 floor or None)"""
     t = _pmc_traffic(kernel, prefix)
-    return t if t[0] is not None else (None, None, None, None)
+    return t if t[0] is not None else (None, None, None, None, None)
 
 
 def _pmc_traffic(kernel, prefix=""):
@@ -147,11 +147,12 @@ def _pmc_traffic(kernel, prefix=""):
                 continue              # a counter pass of another kernel (or another class of it) says nothing about this one
             like = d.get("dominant_detector_launches")
             if like:                  # joined per dispatch: exactly the launches the in-library profiler times (detector forward + data gradient)
-                return int(like["traffic_bytes_per_launch"]), "profiles/" + name, int(like["launches"]), int(like["algorithmic_bytes_per_launch"])
-            return int(d["dominant"]["traffic_bytes_per_launch"]), "profiles/" + name, int(d["dominant"].get("launches", 0)), None
+                return (int(like["traffic_bytes_per_launch"]), "profiles/" + name, int(like["launches"]), int(like["algorithmic_bytes_per_launch"]),
+                        like.get("traffic_over_xcd_floor"))
+            return int(d["dominant"]["traffic_bytes_per_launch"]), "profiles/" + name, int(d["dominant"].get("launches", 0)), None, None
         except Exception:
             continue
-    return None, None, None, None
+    return None, None, None, None, None
 
 
 def cpu_baseline():
@@ -373,7 +374,7 @@ def main():
             n, tms, fl, by = prof[dominant]
             ach = fl / (tms * 1e-3) / 1e12
             # the committed counter passes of THIS configuration (none exist for the mask configuration: traffic stays null there)
-            traffic, src, t_n, t_alg = pmc_traffic(dominant, {"vgg16": "", "resnet50": "resnet50_", "maskrcnn": "maskrcnn_"}[a.config])
+            traffic, src, t_n, t_alg, t_floor = pmc_traffic(dominant, {"vgg16": "", "resnet50": "resnet50_", "maskrcnn": "maskrcnn_"}[a.config])
             it_ach = f_iter * world * a.steps / dt
             f_exec = f_iter - sum(WINO_ELIGIBLE_TFLOP.values()) * (1.0 - 1.0 / WINO_RATIO) if (wino and a.config == "vgg16") else None
             roof = {"bound": "mfma", "kernel": dominant, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
@@ -384,6 +385,9 @@ def main():
                     # each ran), against THAT population's algorithmic bytes
                     "traffic_launches": t_n, "traffic_algorithmic_bytes_per_launch": t_alg,
                     "traffic_over_algorithmic": round(traffic / t_alg, 3) if traffic and t_alg else None,
+                    # ... and against what eight non-coherent per-XCD L2s must fetch at least for the same launches (scripts/pmc_summary.py
+                    # xcd_floor: (8 / gm) x transformed filters + gm x input): the counter sits at the L2s' memory side
+                    "traffic_over_xcd_floor": t_floor,
                     "gflop_per_launch": round(fl / n / 1e9, 2),
                     **({"flop_definition": "MFMA work the Winograd F(2x2,3x3) kernel executes (16 products per 2x2 output tile and channel "
                                            "pair) = the direct convolution's / 2.25",

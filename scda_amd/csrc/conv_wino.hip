@@ -1055,7 +1055,7 @@ static int wino_launch(const float *x, const float *u, const float *bias, float 
     // flops = the MFMA work the kernel EXECUTES (16 products per 2x2 tile and channel pair: the direct form's 36 / 2.25)
     // algorithmic bytes: input once, filters once, result once (fused pool: the pooled map and its winners instead of the full map)
     const double out_bytes = pool_y ? 1.25 * batch * M * H * W : 4.0 * batch * M * H * W;
-    const double alg_bytes = 4.0 * ((double)batch * C * H * W + 9.0 * M * C) + out_bytes;
+    const double alg_bytes = 4.0 * ((double)batch * C * H * W + 9.0 * M * C) + out_bytes + (mask_src ? 4.0 * batch * M * H * W : 0.0);   // (+ the activation mask)
     prof_begin(for_dgrad ? PK_WINO_DGRAD : PK_WINO_FWD, 2.0 * M * (double)batch * H * W * C * 4, st, alg_bytes);
     long long wgs = tiles * splits;
     if (g.pixel_major) {      // 8 / gm runs of per_xcd (split, pixel block) items x n_mt m-tiles; the last run may hold idle workgroups
@@ -1064,7 +1064,7 @@ static int wino_launch(const float *x, const float *u, const float *bias, float 
         wgs = 8LL * g.per_xcd * (g.n_mt / gm);
     }
     g_wino_last[0] = MBv; g_wino_last[1] = g.pixel_major; g_wino_last[2] = gm; g_wino_last[3] = splits;
-    wino_log(pool_y ? "fwd_pool" : for_dgrad ? "dgrad" : "fwd", MBv, wgs, batch, C, H, W, M, splits, alg_bytes, 2.0 * M * (double)batch * H * W * C * 4);
+    wino_log(pool_y ? "fwd_pool" : for_dgrad ? (mask_src ? "dgrad_mask" : "dgrad") : "fwd", MBv, wgs, batch, C, H, W, M, splits, alg_bytes, 2.0 * M * (double)batch * H * W * C * 4);
     // more 64-row tiles than CUs: one persistent workgroup per CU walks them (see the kernel); SCDA_WINO_PERSIST=0 turns it off
     static const int n_cu = [] { int d = 0, n = 0; if (hipGetDevice(&d) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || n < 8) n = 256; return n / 8 * 8; }();
     const char *pe = getenv("SCDA_WINO_PERSIST");

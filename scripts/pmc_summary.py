@@ -46,7 +46,7 @@ def load_wino(d, counter):
 
 
 def wino_layers(d):
-    """per (kind, shape): launches, algorithmic bytes, read bytes, write bytes per launch"""
+    """per (kind, shape): launches, algorithmic bytes, read bytes, write bytes per launch, executed flop"""
     F, W = load_wino(d, "FETCH_SIZE"), load_wino(d, "WRITE_SIZE")
     if not F or not W or len(F) != len(W):
         return None
@@ -59,6 +59,21 @@ def wino_layers(d):
         a = agg.setdefault(key, [0, float(l[9]), 0.0, 0.0, float(l[10])])
         a[0] += 1; a[2] += 2.0 * 1024 * f; a[3] += 1024 * w
     return agg
+
+
+def xcd_floor(kind, batch, C, H, W, M, alg_bytes):
+    """What the eight NON-COHERENT per-XCD L2s must fetch at least for a forward / data-gradient launch: every XCD needs the transformed
+    filters of the m-tiles it serves and the input of the pixel blocks it serves; splitting the XCDs gm x (8 / gm) over m-tile groups x
+    pixel-block runs costs (8 / gm) * U + gm * X at the L2s' memory side (Infinity-Cache hits are counted there), U = 16 * M_pad * C * 4
+    bytes of transformed filters (16 / 9 of the raw 3x3 weights the algorithmic figure counts), X the input.  The counter can only be
+    compared with THIS floor, not with the algorithmic bytes, once U or X exceeds what one 4 MB L2 keeps."""
+    if kind == "wgrad":
+        return None
+    U = 16.0 * ((M + 63) // 64 * 64) * C * 4
+    X = 4.0 * batch * C * H * W
+    out = alg_bytes - X - 4.0 * 9 * M * C      # (the result, and for a masked data gradient the activation mask it reads)
+    # (an operand that fits beside the other in one L2 is fetched once per XCD that uses it, not once per workgroup: the same formula)
+    return min((8 / gm) * U + gm * X for gm in (1, 2, 4, 8) if gm <= max(1, (M + 63) // 64) or gm == 1) + out
 
 
 def short(name):
@@ -115,10 +130,23 @@ def main(d, out_md, out_json, which=None):
                     "`SCDA_GAN_GRAPH=0 SCDA_WINO_LOG=...` so that every dispatch is joined with its layer): traffic %.1f MB per launch against\n"
                     "%.1f MB algorithmic = **%.2fx**.\n\n" % (like["launches"], like["traffic_bytes_per_launch"] / 1e6,
                                                               like["algorithmic_bytes_per_launch"] / 1e6, like["traffic_over_algorithmic"]))
-            f.write("| Winograd launch (kind, batch, C, H, W, M) | launches | algorithmic MB | read MB | write MB | traffic / algorithmic |\n|---|---:|---:|---:|---:|---:|\n")
+            f.write("`8-L2 floor` = what eight non-coherent 4 MB L2s must fetch at least: min over gm of (8 / gm) x transformed filters + gm x input\n"
+                    "(+ the result once); these counters sit at the L2s' memory side and count Infinity-Cache hits, so from conv3_x on (filters or\n"
+                    "input beyond one L2) the floor, not the algorithmic figure, is what the launch order can reach.\n\n")
+            f.write("| Winograd launch (kind, batch, C, H, W, M) | launches | algorithmic MB | read MB | write MB | traffic / algorithmic | 8-L2 floor MB | traffic / floor |\n|---|---:|---:|---:|---:|---:|---:|---:|\n")
+            fl_sum = tr_sum = 0.0
             for k, a in layers.items():
-                f.write("| %s b%d %d x %d x %d -> %d | %d | %.1f | %.1f | %.1f | %.2f |\n"
-                        % (k[0], k[1], k[2], k[3], k[4], k[5], a[0], a[1] / 1e6, a[2] / a[0] / 1e6, a[3] / a[0] / 1e6, (a[2] + a[3]) / a[0] / a[1]))
+                fl = xcd_floor(k[0], k[1], k[2], k[3], k[4], k[5], a[1])
+                tr = (a[2] + a[3]) / a[0]
+                if fl and k[1] == 1:
+                    fl_sum += fl * a[0]; tr_sum += tr * a[0]
+                f.write("| %s b%d %d x %d x %d -> %d | %d | %.1f | %.1f | %.1f | %.2f | %s | %s |\n"
+                        % (k[0], k[1], k[2], k[3], k[4], k[5], a[0], a[1] / 1e6, a[2] / a[0] / 1e6, a[3] / a[0] / 1e6, tr / a[1],
+                           "%.1f" % (fl / 1e6) if fl else "-", "%.2f" % (tr / fl) if fl else "-"))
+            if fl_sum:
+                like["xcd_floor_bytes_per_launch"] = round(fl_sum / like["launches"])
+                like["traffic_over_xcd_floor"] = round(tr_sum / fl_sum, 3)
+                f.write("\nOver the same %d launches: traffic / 8-L2 floor = **%.2fx**.\n" % (like["launches"], tr_sum / fl_sum))
             f.write("\n")
         f.write("| kernel | launches | read MB/launch | write MB/launch |\n|---|---:|---:|---:|\n")
         for r in rows[:45]:
