@@ -130,6 +130,17 @@ def resize_to_tensor(img, new_w, new_h, device, normalize=True, mean=0.5, std=0.
     """`img`: a PIL image (mode L or RGB) or a uint8 array [H, W] / [H, W, 1] / [H, W, 3]  ->  float32 [C, new_h, new_w] on `device`:
     normalize(to_tensor(img.resize((new_w, new_h)) [.transpose(FLIP_LEFT_RIGHT)])) of the CPU data path (scda_amd/data.py), bit for bit.
     Only the decoded bytes cross PCIe (a quarter of the float tensor, and before the down-scale or after it, whichever the caller holds)."""
+    mode = getattr(img, "mode", None)
+    if mode is not None:
+        # PIL's Image.resize() default (what the CPU path calls) depends on the image and on Pillow: NEAREST for modes 'P' and '1' always
+        # and for every mode before Pillow 7, BICUBIC otherwise; np.asarray of a 'P' image are palette indices.  This path restates the
+        # BICUBIC / BILINEAR / ... convolution filters on L and RGB bytes only -- anything else must take the CPU path, loudly.
+        if mode not in ("L", "RGB"):
+            raise ValueError("device image path: PIL mode %r is not supported (L and RGB are); load with device=None or convert('RGB')" % mode)
+        import PIL
+        if int(PIL.__version__.split(".")[0]) < 7 and filter == "bicubic":
+            raise ValueError("device image path: Pillow %s resizes with NEAREST by default; the device path restates Pillow >= 7's BICUBIC "
+                             "default -- pass device=None" % PIL.__version__)
     a = np.asarray(img, dtype=np.uint8)
     if a.ndim == 2:
         a = a[:, :, None]

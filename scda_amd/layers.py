@@ -6,6 +6,8 @@ torchvision's vgg16-397923af.pth load unchanged), but none of them calls a
 torch compute kernel: forward dispatches to scda_amd.autograd_ops.
 """
 
+import weakref
+
 import torch
 import torch.nn as nn
 
@@ -30,8 +32,12 @@ class Conv2d(nn.Conv2d):
         # > 0: the input is a vertical stack of independent maps of that many rows (the channel-major RoI-head layout
         # [1, C, R*7, 7] of the ResNet-C4 detector); set per call by the owner (dropin/models/mask_rcnn/resnet.py)
         self.row_period = 0
-        # fusion plan: a MaxPool2x2 consumes this conv's ReLU output (plan_act_fusion): the pool can run in this conv's epilogue
+        # fusion plan: a MaxPool2x2 consumes this conv's ReLU output (plan_act_fusion): the pool can run in this conv's epilogue.
+        # The hand-over is structural: the conv tells ITS pool module (a weak reference set by the plan) that the tensor it is about
+        # to receive is already pooled, with the shape to expect -- not an attribute on the tensor, which a hook or wrapper that
+        # returns a new tensor (detach, clone, checkpointing) would drop, pooling a second time without a word.
         self.pool_next = False
+        self._pool_ref = None
 
     def forward(self, x):
         if self.pool_next and A.replay is None and self.fused_act == A.ACT_RELU and self.defer_act_bwd:
@@ -39,9 +45,11 @@ class Conv2d(nn.Conv2d):
             if x.is_cuda and N.conv_pool_fusable(B, Cin, IH, IW, self.out_channels, self.kernel_size[0], self.kernel_size[1],
                                                  self.stride[0], self.padding[0], self.row_period):
                 # conv + ReLU + the 2x2 max-pool behind it in one launch; the pool module recognises the pooled tensor and passes it on
-                y = A.ConvPoolFn.apply(x, self.weight, self.bias, self.slope, self.input_act)
-                y._scda_pooled = True
-                return y
+                pool = self._pool_ref() if self._pool_ref is not None else None
+                if pool is not None:
+                    y = A.ConvPoolFn.apply(x, self.weight, self.bias, self.slope, self.input_act)
+                    pool.expect_pooled(tuple(y.shape))
+                    return y
         return A.conv2d(x, self.weight, self.bias, self.stride[0], self.padding[0], self.fused_act, self.slope,
                         (self.input_act, self.defer_act_bwd), self.row_period)
 
@@ -107,9 +115,17 @@ class Linear(nn.Linear):
 
 class MaxPool2x2(nn.Module):
     relu_input = False             # fusion plan: this pool's backward also applies the ReLU gradient of the conv in front of it
+    _pooled_shape = None           # set by the conv in front (Conv2d.forward) when IT pooled: the shape of the tensor to pass through
+
+    def expect_pooled(self, shape):
+        self._pooled_shape = shape
 
     def forward(self, x):
-        if getattr(x, "_scda_pooled", False):     # the producing conv already pooled (layers.Conv2d.forward / A.ConvPoolFn)
+        if self._pooled_shape is not None:     # the producing conv already pooled (layers.Conv2d.forward / A.ConvPoolFn)
+            want, self._pooled_shape = self._pooled_shape, None
+            if tuple(x.shape) != want:
+                raise RuntimeError("MaxPool2x2: the convolution in front pooled in its epilogue and announced %s, but a tensor of shape %s "
+                                   "arrived (a hook between the two modules?)" % (want, tuple(x.shape)))
             return x
         return A.MaxPool2x2Fn.apply(x, self.relu_input)
 
@@ -192,6 +208,7 @@ def plan_act_fusion(*sequentials):
             elif isinstance(a, Conv2d) and a.fused_act == A.ACT_RELU and isinstance(b, MaxPool2x2):
                 a.defer_act_bwd, b.relu_input = True, True
                 a.pool_next = True
+                a._pool_ref = weakref.ref(b)
             elif isinstance(a, Linear) and a.fused_act == A.ACT_RELU and isinstance(b, Dropout):
                 a.defer_act_bwd, b.relu_input = True, True
             else:

@@ -487,9 +487,10 @@ def conv2d_pack_all(flat):
     # which weights ran on the Winograd kernel in their last forward call (native.conv2d_fwd notes it): those get its transformed
     # filters (modes 2, 3) instead of the implicit-GEMM layouts (0, 1); a call that needs the other kind packs lazily
     wino = tuple(bool(getattr(w, "_scda_wino_used", False)) for w in ws) if wino_enabled() else None
-    plan = getattr(flat, "_scda_pack_plan", None)
-    if plan is not None and plan[4] != wino:
-        plan = None
+    # one plan (descriptor table + output buffer) PER flag tuple, kept: with variable-size inputs a layer's eligibility flips with the
+    # parity of the map size, and rebuilding the plan on every flip meant a descriptor upload and fresh buffers for every layout
+    plans = flat.__dict__.setdefault("_scda_pack_plans", {})
+    plan = plans.get(wino)
     L = lib()
     if plan is None:
         L.scda_conv2d_packed_elems.restype = ctypes.c_size_t
@@ -508,7 +509,9 @@ def conv2d_pack_all(flat):
                 tiles += int(L.scda_conv2d_pack_tiles(i32(Cout), i32(Cin), i32(KH), i32(KW), i32(d)))
         desc = upload(torch.tensor(rows, dtype=torch.int64), flat.data.device)
         out = torch.empty(off, dtype=torch.float32, device=flat.data.device)
-        plan = flat._scda_pack_plan = (desc, out, entries, tiles, wino)
+        if len(plans) >= 8:          # (bounded: eligibility patterns of a real data set are few)
+            plans.clear()
+        plan = plans[wino] = (desc, out, entries, tiles, wino)
     desc, out, entries, tiles, _ = plan
     _check(L.scda_conv2d_pack_weights_batched_hip(_p(flat.data), _p(out), _p(desc), i32(len(entries)),
                                                   ctypes.c_longlong(tiles), _stream()), "scda_conv2d_pack_weights_batched_hip")

@@ -519,6 +519,7 @@ class ScdaTrainer:
         if gt_masks is not None:
             x['ground_truth_masks'] = gt_masks
         pending = {}
+        self._in_graph = False
         for sch in self._warmup or ():     # :510-514 -- the warm-up schedulers step at the top of the iteration
             sch.step()
 
@@ -575,14 +576,16 @@ class ScdaTrainer:
         pro_shape = (src_patch.shape[0], self._dis_patch_out_len())
         t['score1'], t['score0'], t['score0p'], t['score1p'] = _labels(
             [('s', 1, row), ('s', 0, row), ('s', 0, pro_shape), ('s', 1, pro_shape)], dev)
-        self._in_graph = in_graph
-        if graphs is not None and graphs.ready('a'):
-            src_recon, tgt_recon, adloss, dis_patch_loss = graphs.run('a', t)
-            w1 = w2 = None
-        else:
-            with _recording(graphs, 'a', t) as rec:
-                src_recon, tgt_recon, adloss, dis_patch_loss, w1, w2 = rec(lambda tt: self._region_a(tt))
-        self._in_graph = False
+        self._in_graph = in_graph      # (reset in a finally: an exception inside a region -- an OOM while recording, a shape error -- must
+        try:                           # not leave the flag set, or the next eager step would skip every phase's all-reduce)
+            if graphs is not None and graphs.ready('a'):
+                src_recon, tgt_recon, adloss, dis_patch_loss = graphs.run('a', t)
+                w1 = w2 = None
+            else:
+                with _recording(graphs, 'a', t) as rec:
+                    src_recon, tgt_recon, adloss, dis_patch_loss, w1, w2 = rec(lambda tt: self._region_a(tt))
+        finally:
+            self._in_graph = False
         if in_graph:                   # the region's collectives, behind the replay
             w1 = self._all_reduce(self.dis, async_op=True)
             w2 = self._all_reduce(self.dis_patch, async_op=True)
@@ -599,13 +602,15 @@ class ScdaTrainer:
         # ---------------- (3) decoders ----------------
         t['one_t'], t['zero_t'], t['one_s'], t['zero_s'] = _labels([('h', 1, row), ('h', 0, row), ('h', 1, row), ('h', 0, row)], dev)
         self._in_graph = in_graph
-        if graphs is not None and graphs.ready('b'):
-            recon_loss, fake1_src, w_tgt2 = graphs.run('b', t)
-            w3 = None
-        else:
-            with _recording(graphs, 'b', t) as rec:
-                recon_loss, fake1_src, w_tgt2, w3 = rec(lambda tt: self._region_b(src_recon, tgt_recon, tt))
-        self._in_graph = False
+        try:
+            if graphs is not None and graphs.ready('b'):
+                recon_loss, fake1_src, w_tgt2 = graphs.run('b', t)
+                w3 = None
+            else:
+                with _recording(graphs, 'b', t) as rec:
+                    recon_loss, fake1_src, w_tgt2, w3 = rec(lambda tt: self._region_b(src_recon, tgt_recon, tt))
+        finally:
+            self._in_graph = False
         if in_graph:
             w3 = self._all_reduce(self.dec, async_op=True)
         mark('phase3')
