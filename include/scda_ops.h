@@ -281,7 +281,7 @@ int scda_conv2d_wino_pool_hip(const float *x, const float *u, const float *bias,
                               int H, int W, int M, int act, float slope, void *stream);
 /* ... and the weight gradient in the same (transposed) algorithm: dw [Cout,Cin,3,3] (+)= G^T [ sum over 2x2 tiles (A dy A^T) .*
  * (B^T x B) ] G, db [Cout] (+)= sum of dy (fused, may be NULL); deterministic split-K like scda_conv2d_wgrad_hip.
- * scda_conv2d_wino_wgrad_supported: >= 64 channels on both sides, H and W even (K-slabs of 2 x 16 pixels, partial at the right edge). */
+ * scda_conv2d_wino_wgrad_supported: >= 32 channels on both sides, H and W even (K-slabs of 2 x 16 pixels, partial at the right edge). */
 int scda_conv2d_wino_wgrad_supported(int batch, int Cin, int H, int W, int Cout);
 int scda_conv2d_wino_wgrad_hip(const float *dy, const float *x, float *dw, float *db, int batch, int Cin, int H, int W, int Cout,
                                int accumulate, int db_accumulate, void *ws, size_t ws_bytes, void *stream);

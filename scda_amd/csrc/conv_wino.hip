@@ -1105,7 +1105,7 @@ SCDA_API int scda_conv2d_wino_stacked_hip(const float *x, const float *u, const 
 }
 
 SCDA_API int scda_conv2d_wino_wgrad_supported(int batch, int Cin, int H, int W, int Cout) {
-    return batch > 0 && Cin >= 64 && Cout >= 64 && (H % 2) == 0 && (W % 2) == 0 && 64LL * H * W * 4 < (1LL << 31);
+    return batch > 0 && Cin >= 32 && Cout >= 32 && (H % 2) == 0 && (W % 2) == 0 && 64LL * H * W * 4 < (1LL << 31);
 }
 
 SCDA_API int scda_conv2d_wino_wgrad_stacked_supported(int maps, int Cin, int Cout) {
@@ -1117,7 +1117,7 @@ static int wino_wgrad_launch(const float *dy, const float *x, float *dw, float *
     if (!dy || !x || !dw || !ws) { set_error("scda_conv2d_wino_wgrad_hip: bad arguments"); return SCDA_EINVAL; }
     if (stack > 0 ? !(scda_conv2d_wino_wgrad_stacked_supported(stack, Cin, Cout) && batch == 1 && H == stack * 7 && W == 7)
                   : !scda_conv2d_wino_wgrad_supported(batch, Cin, H, W, Cout)) {
-        set_error("scda_conv2d_wino_wgrad_hip: needs >= 64 channels on both sides and even H, W or a stack of 7 x 7 maps (Cin=%d Cout=%d H=%d W=%d)", Cin, Cout, H, W);
+        set_error("scda_conv2d_wino_wgrad_hip: needs >= 32 channels on both sides (>= 64 on stacked maps) and even H, W or a stack of 7 x 7 maps (Cin=%d Cout=%d H=%d W=%d)", Cin, Cout, H, W);
         return SCDA_EINVAL;
     }
     hipStream_t st = as_stream(stream);

@@ -109,6 +109,8 @@ WGRAD_CASES = [
     (1, 64, 4, 6, 64),         # a single PARTIAL slab: 3 real tiles of 8
     (2, 128, 50, 84, 128),     # ResNet layer3's 50 x 84: 5 slabs + a partial one (4 pixels) per tile row
     (1, 64, 100, 168, 128),    # layer2's 100 x 168: partial slab of 8 pixels
+    (4, 64, 64, 64, 32),       # 32 output channels (the decoders' 64 -> 32 stage): half of the 64-row tile is zero rows
+    (1, 40, 32, 32, 48),       # fewer than 64 channels on both sides, ragged
 ]
 
 
