@@ -31,6 +31,25 @@ import time
 # across processes) fails with hipIpcGetMemHandle: invalid argument.  Must be in the environment before HIP initialises.
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
+
+def _early_world():
+    """ranks of this run as far as the command line / environment say, BEFORE torch is imported: the data-parallel process
+    environment (scda_amd.hostenv.data_parallel_env: eight hardware queues ...) must be in place when HIP initialises, and
+    launch_ranks' children inherit it"""
+    n = int(os.environ.get("WORLD_SIZE", "1") or 1)
+    for i, tok in enumerate(sys.argv):
+        if tok == "--gpus" and i + 1 < len(sys.argv) and sys.argv[i + 1].isdigit():
+            n = max(n, int(sys.argv[i + 1]))
+        elif tok.startswith("--gpus=") and tok[7:].isdigit():
+            n = max(n, int(tok[7:]))
+    return n
+
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from scda_amd import hostenv as _hostenv                       # (imports nothing of torch)
+_BLOCKING = _hostenv.wants_blocking_sync(_early_world())
+_DP_ENV = _hostenv.data_parallel_env(_early_world())
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -251,9 +270,9 @@ def main():
                          "`python -m torch.distributed.run --nproc-per-node %d`" % (a.gpus, world, a.gpus, a.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    if world > 1 or os.environ.get("SCDA_BLOCKING_SYNC"):
+    if _BLOCKING:
         from scda_amd.hostenv import prefer_blocking_sync
-        prefer_blocking_sync(local)  # ranks share the host cores: sleep, do not spin, while waiting for the device
+        prefer_blocking_sync(local)  # ranks share few host cores (CPU quota < 2.25 x ranks): sleep, do not spin, while waiting for the device
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -415,7 +434,10 @@ def main():
             "collective": {"backend": ("rccl (torch.distributed 'nccl')" if backend == "nccl" else backend) if world > 1 else None,
                            "ranks": dist.get_world_size() if world > 1 else 1,
                            # dis, dis_patch, dec + the detector's bucket in two pieces (classifier + heads from inside the backward)
-                           "all_reduces_per_step": (5 if getattr(tr, "_det_early_span", lambda: None)() else 4) if world > 1 else 0},
+                           "all_reduces_per_step": (5 if getattr(tr, "_det_early_span", lambda: None)() else 4) if world > 1 else 0,
+                           # process environment of a rank (scda_amd.hostenv.data_parallel_env) and how its host thread waits
+                           "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                           "host_wait": "blocking" if _BLOCKING else "spin", "env_set": _DP_ENV},
             "config": {"workload": ("vgg16_FasterRCNN + 4-cluster SCDA, synthetic Cityscapes->Foggy 512x1024, batch=1/GPU "
                                     "(BASELINE.json configs[1]); 1 step = 1 source + 1 target image, 4 optimiser phases")
                        if a.config == "vgg16" else

@@ -107,6 +107,15 @@ def _first_slurm_host(nodelist):
 def dist_init(port, backend='nccl'):
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC (the only form the MI355X hosts' driver supports); harmless
     # when HIP is already initialised with it exported, as the launch environment does
+    _world = int(os.environ.get('SLURM_NTASKS', os.environ.get('WORLD_SIZE', 1)))
+    if backend == 'nccl' and _world > 1:
+        # eight hardware queues for a rank's five streams (scda_amd.hostenv.data_parallel_env: 26.0 -> 18.3 ms per iteration).  The
+        # reference's driver calls dist_init first thing in main() (tools/faster_rcnn_train_val.py:129), before anything touches the GPU
+        from scda_amd.hostenv import data_parallel_env
+        if torch.cuda.is_initialized() and 'GPU_MAX_HW_QUEUES' not in os.environ:
+            logger.warning('dist_init: HIP is already initialised, GPU_MAX_HW_QUEUES=8 comes too late for this process '
+                           '(export it, or call dist_init before the first torch.cuda call)')
+        data_parallel_env(_world)
     if 'SLURM_PROCID' in os.environ:
         rank = int(os.environ['SLURM_PROCID'])
         world = int(os.environ['SLURM_NTASKS'])

@@ -68,6 +68,38 @@ def prefer_blocking_sync(device_index=0):
 _blocking_sync = [False]
 
 
+def data_parallel_env(world_size):
+    """Process environment of a rank of a data-parallel run; call BEFORE the process touches the GPU (the HIP runtime reads it when it
+    initialises).  GPU_MAX_HW_QUEUES=8: the runtime's default is four hardware queues per process; a rank drives five streams
+    (compute, box logic, target branch, the nets' B halves, RCCL's), two of them then share a queue, and a stream that waits for an
+    event deep in the backlog of another -- the all-reduce launched from inside the detector backward -- holds up its queue-mate.
+    Measured with the whole RCCL choreography of a step on a one-rank group (scripts/onerank_matrix.sh,
+    profiles/r05_onerank_rccl.txt; the plain step is 18.1 - 18.8 ms on the same boxes): 26.0 - 26.8 ms per iteration with four
+    queues, 18.3 - 19.3 with eight, 18.6 - 19.6 with six.  With eight queues the EAGER iteration is also as fast as the hipGraph
+    replays are with four (18.1 / 18.6 vs 18.15 / 18.75 ms) -- data-parallel runs lose nothing by doing without the graphs, which
+    do NOT work with eight queues (25.7 ms).
+    Only a default is set: what the caller exported wins.  -> dict of the variables this call set."""
+    done = {}
+    if world_size > 1 and "GPU_MAX_HW_QUEUES" not in os.environ:
+        os.environ["GPU_MAX_HW_QUEUES"] = done["GPU_MAX_HW_QUEUES"] = "8"
+    return done
+
+
+def wants_blocking_sync(world_size):
+    """several ranks on one host: sleep instead of spinning while waiting for the device only when the container's CPU quota is tight
+    -- a spinning rank keeps 1.9 cores busy, a sleeping one 1.45 (scripts/host_budget_8ranks.py: 8 ranks = 15.1 / 11.7 cores of a
+    16-CPU quota), and a throttled CFS period stalls every rank; with the collectives' stream in the process the blocking flag
+    costs 0 - 2.5 ms per iteration from run to run (18.4 - 20.9 ms, profiles/r05_onerank_rccl.txt), which is why it is no longer
+    taken whenever there is more than one rank.  SCDA_BLOCKING_SYNC=0 / 1 overrides."""
+    v = os.environ.get("SCDA_BLOCKING_SYNC")
+    if v is not None:
+        return v not in ("", "0")
+    if world_size <= 1:
+        return False
+    q = cpu_quota()
+    return q is not None and q < 2.25 * world_size
+
+
 def blocking_sync_selected():
     """prefer_blocking_sync() took effect in this process.  The trainer then keeps the GAN phases eager: under any non-default
     scheduling flag each hipGraph launch costs the device ~1.3 ms inside the runtime (profiles/r03_hipgraph.txt; round 4, same

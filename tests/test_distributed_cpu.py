@@ -167,3 +167,28 @@ def test_slurm_master_address_is_not_loopback_on_several_nodes(monkeypatch):
     monkeypatch.setenv("SLURM_NODELIST", "")
     with pytest.raises(RuntimeError):
         D.dist_init("23456", backend="gloo")
+
+
+def test_data_parallel_env_sets_only_defaults(monkeypatch):
+    """scda_amd.hostenv.data_parallel_env: eight hardware queues for a rank of a multi-rank run; nothing for one rank; what the
+    caller exported wins.  wants_blocking_sync: blocking waits only under a tight CPU quota, or when forced"""
+    from scda_amd import hostenv
+    for k in ("GPU_MAX_HW_QUEUES", "SCDA_BLOCKING_SYNC"):
+        monkeypatch.delenv(k, raising=False)
+    assert hostenv.data_parallel_env(1) == {} and "GPU_MAX_HW_QUEUES" not in os.environ
+    try:
+        assert hostenv.data_parallel_env(8) == {"GPU_MAX_HW_QUEUES": "8"}
+        assert os.environ["GPU_MAX_HW_QUEUES"] == "8"
+    finally:
+        os.environ.pop("GPU_MAX_HW_QUEUES", None)        # (set directly in os.environ by the call: monkeypatch does not know it)
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "16")
+    assert hostenv.data_parallel_env(8) == {} and os.environ["GPU_MAX_HW_QUEUES"] == "16"
+    monkeypatch.setattr(hostenv, "cpu_quota", lambda: 16)
+    assert hostenv.wants_blocking_sync(8) and not hostenv.wants_blocking_sync(4) and not hostenv.wants_blocking_sync(1)
+    monkeypatch.setattr(hostenv, "cpu_quota", lambda: None)
+    assert not hostenv.wants_blocking_sync(8)
+    monkeypatch.setenv("SCDA_BLOCKING_SYNC", "1")
+    assert hostenv.wants_blocking_sync(1)
+    monkeypatch.setenv("SCDA_BLOCKING_SYNC", "0")
+    monkeypatch.setattr(hostenv, "cpu_quota", lambda: 2)
+    assert not hostenv.wants_blocking_sync(8)
