@@ -147,7 +147,8 @@ def test_wino_wgrad_routes_through_conv2d_entry_points(cuda):
     native.prof_enable(False)
     assert native.prof_collect()["conv_wino_wgrad_kernel"][0] == 2
     assert torch.equal(dw, dw1)
-    assert not native.wino_wgrad_ok(1, 32, 32, 64, 64, 3, 3, 1, 1) and not native.wino_wgrad_ok(1, 64, 32, 64, 64, 3, 3, 2, 1)
+    assert not native.wino_wgrad_ok(1, 16, 32, 64, 64, 3, 3, 1, 1) and not native.wino_wgrad_ok(1, 64, 32, 64, 64, 3, 3, 2, 1)
+    assert native.wino_wgrad_ok(1, 32, 32, 64, 64, 3, 3, 1, 1) and native.wino_wgrad_ok(1, 64, 32, 64, 32, 3, 3, 1, 1)     # from 32 channels a side
     assert native.wino_wgrad_ok(1, 64, 32, 72, 64, 3, 3, 1, 1) and not native.wino_wgrad_ok(1, 64, 32, 71, 64, 3, 3, 1, 1)
 
 
