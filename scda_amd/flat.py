@@ -215,36 +215,3 @@ class FlatAdam(torch.optim.Optimizer):
         self.flat.epoch += 1   # the kernel wrote through raw pointers: packed-weight caches of this bucket are stale
         N.conv2d_pack_all(self.flat)   # ... and are rebuilt right here, all layers and both directions in one launch
         return loss
-
-    @torch.no_grad()
-    def step_split(self, span, stream):
-        """step() as two launches: the elements [lo, hi) of the bucket on `stream` (ordered behind the current stream's work), the
-        rest -- and the weight re-pack, which must not cover a convolution inside [lo, hi) -- on the current stream.  Element-wise
-        the same update.  -> event recorded on `stream` behind its launch: whoever reads or writes parameters / gradients /
-        moments inside [lo, hi) next must wait for it."""
-        self.flat.check_aliases()
-        self.flat.finalize_grads()
-        lo, hi = span
-        base = self.flat.data.data_ptr()
-        if any(lo <= (w.data_ptr() - base) // 4 < hi for w in (getattr(self.flat, "conv_weights", None) or ())):
-            raise ValueError("FlatAdam.step_split: a convolution weight lies inside the slice stepped on the other stream")
-        g = self.param_groups[0]
-        st = self.state[self.bucket]
-        n = int(st["step"]) + 1
-        st["step"] = torch.tensor(float(n), dtype=torch.float32)
-
-        def launch(a, b):
-            if b > a:
-                N.adam_step(self.flat.data[a:b], self.flat.grad[a:b], st["exp_avg"][a:b], st["exp_avg_sq"][a:b], float(g["lr"]),
-                            g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], n, max_blocks=self.max_blocks)
-        cur = torch.cuda.current_stream(self.flat.data.device)
-        stream.wait_stream(cur)
-        with torch.cuda.stream(stream):
-            launch(lo, hi)
-            ev = torch.cuda.Event()
-            ev.record(stream)
-        launch(0, lo)
-        launch(hi, self.flat.numel)
-        self.flat.epoch += 1
-        N.conv2d_pack_all(self.flat)
-        return ev

@@ -317,18 +317,6 @@ class ScdaTrainer:
             self.dis.branch_stream = self.branch
         else:
             self.branch = None
-        # EXPERIMENT (SCDA_ADAM_OVERLAP=1): the classifier + heads' share of the detector's Adam step (87 % of the bucket) on a stream
-        # of its own, underneath the next iteration's backbones; the head modules wait for it in a forward pre-hook
-        self.adam_stream, self._head_ev = None, None
-        if (device.type == "cuda" and os.environ.get("SCDA_ADAM_OVERLAP") == "1" and not reference_style
-                and getattr(self.model, 'EARLY_REDUCE_PREFIXES', None)):
-            self.adam_stream = torch.cuda.Stream(device=device, priority=int(os.environ.get("SCDA_ADAM_PRIO", "0")))
-
-            def wait_head(mod, inp):
-                if self._head_ev is not None:
-                    torch.cuda.current_stream(device).wait_event(self._head_ev)
-            for name in {p.split('.')[0] for p in self.model.EARLY_REDUCE_PREFIXES}:
-                getattr(self.model, name).register_forward_pre_hook(wait_head)
 
     # ---- learning-rate schedule (tools/faster_rcnn_train_val.py:346-388) ------------------------------------------
     def begin_warmup(self, warmup_iters, batch_size=1, world_size=None):
@@ -402,14 +390,6 @@ class ScdaTrainer:
             if pre and flat is not None and os.environ.get("SCDA_SEGMENTED_REDUCE", "1") != "0":
                 self._early_span = flat.span_of([p for n, p in self.model.named_parameters() if n.startswith(tuple(pre)) and p.requires_grad])
         return self._early_span
-
-    def _head_span(self):
-        if not hasattr(self, '_head_span_v'):
-            flat = getattr(self.model, '_scda_flat', None)
-            pre = tuple(self.model.EARLY_REDUCE_PREFIXES)
-            self._head_span_v = None if flat is None else flat.span_of([p for n, p in self.model.named_parameters()
-                                                                       if n.startswith(pre) and p.requires_grad])
-        return self._head_span_v
 
     def _reduce(self, module, async_op):
         self._finish_grads(module)
@@ -666,11 +646,7 @@ class ScdaTrainer:
         if w4 is not None:
             w4.wait()
             self._grab_reduced('det', self.model)
-        head = self._head_span() if self.adam_stream is not None else None
-        if head is not None:
-            self._head_ev = self.opt['det'].step_split(head, self.adam_stream)
-        else:
-            self.opt['det'].step()
+        self.opt['det'].step()
         mark('phase4+det_step')
 
         self.last_num_proposals = outputs.get('num_proposals')     # post-NMS proposal counts (source, target) of this iteration
