@@ -68,8 +68,11 @@ python scripts/pmc_mfma_summary.py $OUT/resnet50/pmc_mfma/pmc_counter_collection
 python scripts/host_budget_8ranks.py spin > $OUT/host_budget.txt 2>/dev/null
 python scripts/host_budget_8ranks.py block >> $OUT/host_budget.txt 2>/dev/null
 SCDA_GAN_GRAPH=1 python scripts/host_budget_8ranks.py block >> $OUT/host_budget.txt 2>/dev/null
-( python scripts/onerank_rccl_cost.py 0; python scripts/onerank_rccl_cost.py 1; SCDA_GAN_GRAPH=1 python scripts/onerank_rccl_cost.py 1 ) 2>/dev/null | grep collectives > $OUT/onerank_rccl.txt
-python scripts/allreduce_contention.py 32 4 2>/dev/null > $OUT/allreduce_contention.txt
+# the process environment of a data-parallel rank (hostenv.data_parallel_env): eight hardware queues, eager GAN phases
+GPU_MAX_HW_QUEUES=8 SCDA_GAN_GRAPH=0 python scripts/host_budget_8ranks.py spin >> $OUT/host_budget.txt 2>/dev/null
+GPU_MAX_HW_QUEUES=8 SCDA_GAN_GRAPH=0 python scripts/host_budget_8ranks.py block >> $OUT/host_budget.txt 2>/dev/null
+bash scripts/onerank_matrix.sh $TAG/onerank > /dev/null 2>&1; cp $OUT/onerank/onerank_rccl.txt $OUT/onerank_rccl.txt
+( python scripts/allreduce_contention.py 32 4; echo; echo "GPU_MAX_HW_QUEUES=8:"; GPU_MAX_HW_QUEUES=8 python scripts/allreduce_contention.py 32 4 ) 2>/dev/null > $OUT/allreduce_contention.txt
 python scripts/bench_wino.py > $OUT/wino_layers.txt 2>/dev/null
 python scripts/time_eval.py 2>/dev/null > $OUT/eval.txt
 if [ "${2:-}" = "full" ]; then

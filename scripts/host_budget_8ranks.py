@@ -53,6 +53,6 @@ if __name__ == "__main__":
     torch.cuda.synchronize()
     w = time.perf_counter() - w0; u1, n1, t1 = stat()
     stop.set()
-    print("%-5s graphs=%s  7 stand-ins x %.2f cores | iteration median %.2f ms  mean %.2f  max %.1f | cgroup %.1f cores busy of a %s-CPU quota, "
-          "%d throttled periods (%.0f ms)" % (mode, os.environ.get("SCDA_GAN_GRAPH", "0 (auto)" if mode == "block" else "1 (auto)"), burn, np.median(ts), np.mean(ts), max(ts),
+    print("%-5s graphs=%s queues=%s  7 stand-ins x %.2f cores | iteration median %.2f ms  mean %.2f  max %.1f | cgroup %.1f cores busy of a %s-CPU quota, "
+          "%d throttled periods (%.0f ms)" % (mode, os.environ.get("SCDA_GAN_GRAPH", "0 (auto)" if mode == "block" else "1 (auto)"), os.environ.get("GPU_MAX_HW_QUEUES", "4 (default)"), burn, np.median(ts), np.mean(ts), max(ts),
                                            (u1 - u0) / 1e6 / w, cpu_quota(), n1 - n0, (t1 - t0) / 1e3), flush=True)
