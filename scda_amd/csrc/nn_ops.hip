@@ -1002,6 +1002,58 @@ __global__ __launch_bounds__(256) void upsample2_bwd_kernel(const float *__restr
     }
 }
 
+// The same gather with ROWS input rows of a plane in flight at once (IH % ROWS == 0, OW % 4 == 0, OW <= kUpRowsOW): pass A fills an
+// LDS block [ROWS][OW] -- a thread owns four consecutive columns of one row and reads the 4 - 5 output rows that touch it with 16-byte
+// loads -- ONE barrier, pass B gives every (row, column) of the ROWS x IW results its 4 - 5 weighted entries.  The row-at-a-time kernel
+// above is two barriers and two half-empty passes (OW and IW of 256 threads busy) per input row, four rows one after the other per
+// workgroup: 52 - 70 us for the decoders' [4, 128, 128, 128] / [4, 64, 256, 256] gradients (0.8 - 1.2 TB/s), a latency chain.  Per
+// element the same weights added in the same order (output rows, then output columns, ascending): bit-identical results.
+constexpr int kUpRowsOW = 1024;
+
+template <int ROWS>
+__global__ __launch_bounds__(256) void upsample2_bwd_rows_kernel(const float *__restrict__ dy, float *__restrict__ dx,
+                                                                 const int IH, const int IW, const int OH, const int OW,
+                                                                 const float sh, const float sw) {
+    __shared__ __attribute__((aligned(16))) float rowbuf[ROWS * kUpRowsOW];
+    const int row0 = blockIdx.x * ROWS, pc = row0 / IH, iy0 = row0 - pc * IH;       // workgroup-uniform: the ROWS rows share a plane
+    const float *g = dy + (size_t)pc * OH * OW;
+    const int q_per_row = OW >> 2;
+    for (int i = threadIdx.x; i < ROWS * q_per_row; i += 256) {
+        const int rr = i / q_per_row, q = i - rr * q_per_row;
+        const int iy = iy0 + rr;
+        int ylo, yhi;
+        up2_candidates(iy, IH, OH, sh, ylo, yhi);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int oy = ylo; oy <= yhi; ++oy) {
+            const float fy = sh * (float)oy;
+            const int y0 = (int)fy, y1 = y0 + (y0 < IH - 1 ? 1 : 0);
+            const float ly1 = fminf(fmaxf(fy - (float)y0, 0.f), 1.f), ly0 = 1.f - ly1;
+            const float wy = (y0 == iy ? ly0 : 0.f) + (y1 == iy ? ly1 : 0.f);
+            if (wy != 0.f) {
+                const float4 v = *reinterpret_cast<const float4 *>(g + (size_t)oy * OW + q * 4);
+                acc.x += wy * v.x; acc.y += wy * v.y; acc.z += wy * v.z; acc.w += wy * v.w;
+            }
+        }
+        *reinterpret_cast<float4 *>(rowbuf + rr * OW + q * 4) = acc;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < ROWS * IW; i += 256) {
+        const int rr = i / IW, ix = i - rr * IW;
+        int xlo, xhi;
+        up2_candidates(ix, IW, OW, sw, xlo, xhi);
+        const float *rb = rowbuf + rr * OW;
+        float acc = 0.f;
+        for (int ox = xlo; ox <= xhi; ++ox) {
+            const float fx = sw * (float)ox;
+            const int x0 = (int)fx, x1 = x0 + (x0 < IW - 1 ? 1 : 0);
+            const float lx1 = fminf(fmaxf(fx - (float)x0, 0.f), 1.f), lx0 = 1.f - lx1;
+            const float wx = (x0 == ix ? lx0 : 0.f) + (x1 == ix ? lx1 : 0.f);
+            if (wx != 0.f) acc += wx * rb[ox];
+        }
+        dx[(size_t)(row0 + rr) * IW + ix] = acc;
+    }
+}
+
 // ------------------------------------------------------------- BCE ----------
 // F.binary_cross_entropy(p, t) mean with the log clamp at -100 (torch semantics);
 // faster_rcnn_train_val.py:584-600,627-628,675-687,723-732.  single workgroup (n <= ~1e5).
@@ -1481,7 +1533,11 @@ SCDA_API int scda_upsample2x_bwd_hip(const float *dy, float *dx, int planes, int
     NN_CHECK(dy && dx && planes > 0 && IH > 1 && IW > 1, "scda_upsample2x_bwd_hip")
     const int OH = IH * 2, OW = IW * 2;
     if (OW > kUpMaxOW) { set_error("scda_upsample2x_bwd_hip: rows wider than %d are not supported", kUpMaxOW); return SCDA_EINVAL; }
-    if ((IH % 4) == 0)
+    const bool row_at_a_time = getenv("SCDA_UPSAMPLE_BWD_ROWWISE") != nullptr;   // A/B knob (read per launch: the test compares both kernels)
+    if (!row_at_a_time && (IH % 8) == 0 && (OW % 4) == 0 && OW <= kUpRowsOW && ((((uintptr_t)dy) & 15) == 0))
+        hipLaunchKernelGGL(upsample2_bwd_rows_kernel<8>, dim3(planes * IH / 8), dim3(256), 0, as_stream(stream), dy, dx, IH, IW, OH, OW,
+                           up_scale(IH, OH), up_scale(IW, OW));
+    else if ((IH % 4) == 0)
         hipLaunchKernelGGL(upsample2_bwd_kernel<4>, dim3(planes * IH / 4), dim3(256), 0, as_stream(stream), dy, dx, IH, IW, OH, OW,
                            up_scale(IH, OH), up_scale(IW, OW));
     else

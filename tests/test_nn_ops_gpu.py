@@ -214,6 +214,23 @@ def test_upsample2x(cuda, shape):
     close(yg, y, 1e-5); close(xg.grad, xr.grad, 1e-5)
 
 
+@pytest.mark.parametrize("shape", [(4, 128, 128, 128), (4, 64, 256, 256), (2, 3, 16, 24), (1, 2, 256, 8)])
+def test_upsample2x_backward_rows_form_is_bit_identical(cuda, shape, monkeypatch):
+    """the gradient of the bilinear x2 with eight input rows in flight per workgroup (upsample2_bwd_rows_kernel: the decoders'
+    [4, 128, 128, 128] and [4, 64, 256, 256] output gradients) against the row-at-a-time kernel it replaces
+    (SCDA_UPSAMPLE_BWD_ROWWISE=1): the same weights in the same order, bit for bit; both against torch"""
+    from scda_amd import native as N
+    dy = torch.randn(*shape, generator=gen(31))
+    x = torch.zeros(shape[0], shape[1], shape[2] // 2, shape[3] // 2, requires_grad=True)
+    F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=True).backward(dy)
+    d = dy.to(cuda)
+    new = N.upsample2x_bwd(d)
+    monkeypatch.setenv("SCDA_UPSAMPLE_BWD_ROWWISE", "1")
+    old = N.upsample2x_bwd(d)
+    assert torch.equal(new, old)
+    close(new, x.grad, 1e-5)
+
+
 def test_bce_gap_rowmean_add(cuda):
     from scda_amd import autograd_ops as A, native as N
     p = torch.rand(1, 1024, generator=gen(23)).clamp(1e-6, 1 - 1e-6); p[0, 0] = 0.0; p[0, 1] = 1.0
