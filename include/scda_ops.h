@@ -378,6 +378,17 @@ int scda_batchnorm_fwd_hip(const float *x, float *y, const float *gamma, const f
 int scda_batchnorm_bwd_hip(const float *dy, const float *x, const float *gamma, const float *beta, const float *save_mean,
                            const float *save_rstd, float *dx, float *dgamma, float *dbeta, int B, int C, int HW, int act,
                            float slope, int accumulate, float *ws, void *stream);
+/* bn3 -> "out += residual" -> ReLU of a bottleneck (models/mask_rcnn/resnet.py:95-104) inside the batch norm's pass:
+ * y = relu(bn_train(x) + residual), statistics and running-stat update as scda_batchnorm_fwd_hip; the backward gates dy by y > 0,
+ * writes the gated gradient (what the residual branch receives) to d_residual and differentiates the batch norm on it.  Served for the
+ * shapes scda_batchnorm_add_relu_ok() accepts (batch 1, HW % 4 == 0, HW <= 40960, 16-byte aligned tensors); SCDA_EINVAL otherwise. */
+int scda_batchnorm_add_relu_ok(int B, int HW);
+int scda_batchnorm_add_relu_fwd_hip(const float *x, const float *residual, float *y, const float *gamma, const float *beta,
+                                    float *running_mean, float *running_var, float *save_mean, float *save_rstd, int B, int C,
+                                    int HW, float eps, float momentum, void *stream);
+int scda_batchnorm_add_relu_bwd_hip(const float *dy, const float *x, const float *y, const float *gamma, const float *beta,
+                                    const float *save_mean, const float *save_rstd, float *dx_or_null, float *d_residual,
+                                    float *dgamma, float *dbeta, int B, int C, int HW, int accumulate, void *stream);
 /* nn.BatchNorm2d in eval mode (running statistics): out = act((x - mean) * rsqrt(var + eps) * gamma + beta); with dy given,
  * out = the gradient w.r.t. x instead (dy * act'(y) * gamma * rsqrt(var + eps); statistics and affine parameters are constants) */
 int scda_batchnorm_eval_hip(const float *x, const float *dy_or_null, float *out, const float *gamma, const float *beta,

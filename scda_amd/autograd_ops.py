@@ -462,6 +462,31 @@ class BatchNormTrainFn(Function):
         return dx, dg, db, None, None, None, None, None, None
 
 
+class BatchNormAddReluFn(Function):
+    """relu(bn_train(x) + residual): bn3 and the residual join of a bottleneck (models/mask_rcnn/resnet.py:95-104) as one kernel each
+    way.  Same arithmetic as BatchNormTrainFn followed by AddReluFn, without the normalised map's round trip through memory (forward)
+    and without the separate gating pass (backward: the gated gradient is written once, for the residual branch)."""
+
+    @staticmethod
+    def forward(ctx, x, residual, gamma, beta, run_mean, run_var, eps, momentum):
+        x = _c(x)
+        y, mean, rstd = N.batchnorm_add_relu_fwd(x, _c(residual), gamma, beta, run_mean, run_var, eps, momentum)
+        ctx.g_ref, ctx.b_ref = gamma, beta
+        ctx.save_for_backward(x, y, gamma, beta, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, gamma, beta, mean, rstd = ctx.saved_tensors
+        sg, sb = _sink(ctx.g_ref), _sink(ctx.b_ref)
+        both = sg is not None and sb is not None
+        dx, dres, dg, db = N.batchnorm_add_relu_bwd(_c(dy), x, y, gamma, beta, mean, rstd, need_dx=ctx.needs_input_grad[0],
+                                                    out=(sg, sb) if both else None)
+        if both:
+            dg = db = None
+        return dx, (dres if ctx.needs_input_grad[1] else None), dg, db, None, None, None, None
+
+
 class BatchNormEvalFn(Function):
     """eval-mode nn.BatchNorm2d (+ fused activation): running statistics and affine parameters are constants"""
 

@@ -646,7 +646,10 @@ __global__ __launch_bounds__(1024) void bn_plane_fwd_kernel(const float *__restr
                                                             float *__restrict__ run_mean, float *__restrict__ run_var,
                                                             float *__restrict__ mean_out, float *__restrict__ rstd_out,
                                                             const int HW, const float eps, const float momentum,
-                                                            const int act, const float slope) {
+                                                            const int act, const float slope,
+                                                            const float *__restrict__ res = nullptr) {
+    // res (may be null): the residual join of a ResNet block in the same pass, y = relu(bn(x) + res) -- the same roundings as the
+    // normalise kernel followed by add_relu_kernel, without writing and re-reading the normalised map
     __shared__ float red[16];
     const int c = blockIdx.x, n4 = HW >> 2;
     const float n = (float)HW;
@@ -681,6 +684,10 @@ __global__ __launch_bounds__(1024) void bn_plane_fwd_kernel(const float *__restr
             o.y = inorm_act((v[j].y - mean) * rstd * ga + be, act, slope);
             o.z = inorm_act((v[j].z - mean) * rstd * ga + be, act, slope);
             o.w = inorm_act((v[j].w - mean) * rstd * ga + be, act, slope);
+            if (res) {
+                const float4 r = reinterpret_cast<const float4 *>(res + (size_t)c * HW)[i];
+                o.x = fmaxf(o.x + r.x, 0.f); o.y = fmaxf(o.y + r.y, 0.f); o.z = fmaxf(o.z + r.z, 0.f); o.w = fmaxf(o.w + r.w, 0.f);
+            }
             y4[i] = o;
         }
     }
@@ -699,7 +706,12 @@ __global__ __launch_bounds__(1024) void bn_plane_bwd_kernel(const float *__restr
                                                             const float *__restrict__ mean_in, const float *__restrict__ rstd_in,
                                                             float *__restrict__ dx, float *__restrict__ dgamma,
                                                             float *__restrict__ dbeta, const int HW, const int act,
-                                                            const float slope, const int accumulate) {
+                                                            const float slope, const int accumulate,
+                                                            const float *__restrict__ join_y = nullptr,
+                                                            float *__restrict__ join_g = nullptr) {
+    // join_y / join_g (may be null): backward of y = relu(bn(x) + res) in the same pass -- the incoming gradient is gated by
+    // join_y > 0 first (act_bwd_kernel's test), the gated gradient is what the residual branch receives (written to join_g) and what
+    // the batch norm differentiates
     __shared__ float red[16];
     const int c = blockIdx.x, n4 = HW >> 2;
     const float n = (float)HW;
@@ -717,7 +729,13 @@ __global__ __launch_bounds__(1024) void bn_plane_bwd_kernel(const float *__restr
     for (int j = 0; j < VPT; ++j) {
         const int i = j * 1024 + threadIdx.x;
         const bool ok = i < n4;
-        const float4 xv = ok ? x4[i] : make_float4(mean, mean, mean, mean), gv = ok ? g4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 xv = ok ? x4[i] : make_float4(mean, mean, mean, mean);
+        float4 gv = ok ? g4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (join_y && ok) {
+            const float4 yv = reinterpret_cast<const float4 *>(join_y + (size_t)c * HW)[i];
+            gv.x = yv.x > 0.f ? gv.x : 0.f; gv.y = yv.y > 0.f ? gv.y : 0.f; gv.z = yv.z > 0.f ? gv.z : 0.f; gv.w = yv.w > 0.f ? gv.w : 0.f;
+            reinterpret_cast<float4 *>(join_g + (size_t)c * HW)[i] = gv;
+        }
         xh[j].x = (xv.x - mean) * rstd; xh[j].y = (xv.y - mean) * rstd; xh[j].z = (xv.z - mean) * rstd; xh[j].w = (xv.w - mean) * rstd;
         g[j].x = gate(gv.x, xh[j].x); g[j].y = gate(gv.y, xh[j].y); g[j].z = gate(gv.z, xh[j].z); g[j].w = gate(gv.w, xh[j].w);
         s1 += (g[j].x + g[j].y) + (g[j].z + g[j].w);
@@ -1476,6 +1494,40 @@ SCDA_API int scda_batchnorm_fwd_hip(const float *x, float *y, const float *gamma
     hipLaunchKernelGGL(batchnorm_fwd_kernel, dim3(C), dim3(256), 0, as_stream(stream), x, y, gamma, beta, running_mean, running_var,
                        save_mean, save_rstd, B, C, HW, eps, momentum, act, slope);
     return launch_status("batchnorm_fwd_kernel");
+}
+
+// relu(bn(x) + residual) of a ResNet block (models/mask_rcnn/resnet.py:95-104) in the batch norm's own pass, and its backward.
+// Plane form only (batch 1: every layer of a batch-1 detector and the channel-major RoI head): scda_batchnorm_add_relu_ok() says
+// whether a shape is served; callers run the two separate kernels otherwise.
+SCDA_API int scda_batchnorm_add_relu_ok(int B, int HW) {
+    static const float *aligned = nullptr;
+    return bn_plane_vpt(B, HW, aligned, aligned, aligned, 10) != 0;
+}
+
+SCDA_API int scda_batchnorm_add_relu_fwd_hip(const float *x, const float *residual, float *y, const float *gamma, const float *beta,
+                                             float *running_mean, float *running_var, float *save_mean, float *save_rstd, int B, int C,
+                                             int HW, float eps, float momentum, void *stream) {
+    NN_CHECK(x && residual && y && gamma && beta && save_mean && save_rstd && B > 0 && C > 0 && HW > 0, "scda_batchnorm_add_relu_fwd_hip")
+    const int vpt = bn_plane_vpt(B, HW, x, y, residual, 10);
+    NN_CHECK(vpt, "scda_batchnorm_add_relu_fwd_hip (shape / alignment not served: see scda_batchnorm_add_relu_ok)")
+#define BN_PLANE_FWD(V) hipLaunchKernelGGL(bn_plane_fwd_kernel<V>, dim3(C), dim3(1024), 0, as_stream(stream), x, y, gamma, beta, running_mean, running_var, save_mean, save_rstd, HW, eps, momentum, 0, 0.f, residual)
+    if (vpt == 2) BN_PLANE_FWD(2); else if (vpt == 5) BN_PLANE_FWD(5); else if (vpt == 7) BN_PLANE_FWD(7); else BN_PLANE_FWD(10);
+#undef BN_PLANE_FWD
+    return launch_status("bn_plane_fwd_kernel (residual join)");
+}
+
+SCDA_API int scda_batchnorm_add_relu_bwd_hip(const float *dy, const float *x, const float *y, const float *gamma, const float *beta,
+                                             const float *save_mean, const float *save_rstd, float *dx, float *d_residual,
+                                             float *dgamma, float *dbeta, int B, int C, int HW, int accumulate, void *stream) {
+    NN_CHECK(dy && x && y && gamma && beta && save_mean && save_rstd && d_residual && dgamma && dbeta && B > 0 && C > 0 && HW > 0,
+             "scda_batchnorm_add_relu_bwd_hip")
+    const int vpt = bn_plane_vpt(B, HW, x, dy, dx, 10);
+    NN_CHECK(vpt && !(((uintptr_t)y | (uintptr_t)d_residual) & 15),
+             "scda_batchnorm_add_relu_bwd_hip (shape / alignment not served: see scda_batchnorm_add_relu_ok)")
+#define BN_PLANE_BWD(V) hipLaunchKernelGGL(bn_plane_bwd_kernel<V>, dim3(C), dim3(1024), 0, as_stream(stream), dy, x, gamma, beta, save_mean, save_rstd, dx, dgamma, dbeta, HW, 0, 0.f, accumulate, y, d_residual)
+    if (vpt == 2) BN_PLANE_BWD(2); else if (vpt == 5) BN_PLANE_BWD(5); else if (vpt == 7) BN_PLANE_BWD(7); else BN_PLANE_BWD(10);
+#undef BN_PLANE_BWD
+    return launch_status("bn_plane_bwd_kernel (residual join)");
 }
 
 SCDA_API int scda_batchnorm_bwd_hip(const float *dy, const float *x, const float *gamma, const float *beta,

@@ -72,9 +72,8 @@ class Bottleneck(nn.Module):
             return A.AddReluFn.apply(out, residual)
         out = self.bn1(self.conv1(x))
         out = self.bn2(self.conv2(out))
-        out = self.bn3(self.conv3(out))
         residual = x if self.downsample is None else self.downsample(x)
-        return A.AddReluFn.apply(out, residual)
+        return self.bn3.forward_add_relu(self.conv3(out), residual)      # bn3 + "out += residual" + ReLU (:95-104): one kernel
 
 
 class ResNet(FasterRCNN_AdEx):

@@ -6,6 +6,7 @@ torchvision's vgg16-397923af.pth load unchanged), but none of them calls a
 torch compute kernel: forward dispatches to scda_amd.autograd_ops.
 """
 
+import os
 import weakref
 
 import torch
@@ -258,6 +259,19 @@ class BatchNorm2d(nn.BatchNorm2d):
             return A.ActFn.apply(y, 0 if self.fused_act == A.ACT_RELU else 1, self.slope)
         return A.BatchNormTrainFn.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
                                         self.momentum, self.fused_act, self.slope)
+
+
+    def forward_add_relu(self, x, residual):
+        """relu(self(x) + residual) -- the residual join of a ResNet block.  One kernel in training mode on the maps the plane form
+        serves (batch 1); the batch norm followed by the join kernel otherwise (eval mode, other shapes, a fused activation of its
+        own, the parity tests' replay hook: they replay the join's mask)."""
+        if (self.training and self.fused_act == A.ACT_NONE and A.replay is None and self.momentum is not None and x.dim() == 4
+                and x.shape == residual.shape and N.batchnorm_add_relu_ok(x) and not os.environ.get("SCDA_BN_NO_JOIN")):
+            if self.num_batches_tracked is not None:
+                self._nbt_pending = getattr(self, "_nbt_pending", 0) + 1
+            return A.BatchNormAddReluFn.apply(x, residual, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
+                                              self.momentum)
+        return A.AddReluFn.apply(self(x), residual)
 
 
 def _flush_nbt(module):

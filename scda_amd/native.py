@@ -943,6 +943,40 @@ def batchnorm_bwd(dy, x, gamma, beta, mean, rstd, act, slope, need_dx=True, out=
     return dx, dg, db
 
 
+def batchnorm_add_relu_ok(x):
+    """is relu(bn(x) + residual) served as one kernel for this map?  (batch 1, plane of a multiple of 4 up to 40960 elements)"""
+    B, C, H, W = x.shape
+    return bool(lib().scda_batchnorm_add_relu_ok(i32(B), i32(H * W)))
+
+
+def batchnorm_add_relu_fwd(x, residual, gamma, beta, run_mean, run_var, eps, momentum):
+    _req(x, "x"); _req(residual, "residual"); _req(gamma, "gamma"); _req(beta, "beta")
+    if residual.shape != x.shape:
+        raise ValueError("batchnorm_add_relu_fwd: shape mismatch")
+    B, C, H, W = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(C, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(C, dtype=torch.float32, device=x.device)
+    _check(lib().scda_batchnorm_add_relu_fwd_hip(_p(x), _p(residual), _p(y), _p(gamma), _p(beta), _p(run_mean), _p(run_var), _p(mean),
+                                                 _p(rstd), i32(B), i32(C), i32(H * W), f32(eps), f32(momentum), _stream()),
+           "scda_batchnorm_add_relu_fwd_hip")
+    return y, mean, rstd
+
+
+def batchnorm_add_relu_bwd(dy, x, y, gamma, beta, mean, rstd, need_dx=True, out=None):
+    """-> (dx, d_residual, dgamma, dbeta); out = (dgamma, dbeta) buffers to accumulate into, or None to allocate"""
+    _req(dy, "dy"); _req(x, "x"); _req(y, "y")
+    B, C, H, W = x.shape
+    dx = torch.empty_like(x) if need_dx else None
+    dres = torch.empty_like(x)
+    dg, db = out if out is not None else (torch.empty(C, dtype=torch.float32, device=x.device),
+                                          torch.empty(C, dtype=torch.float32, device=x.device))
+    _check(lib().scda_batchnorm_add_relu_bwd_hip(_p(dy), _p(x), _p(y), _p(gamma), _p(beta), _p(mean), _p(rstd), _p(dx), _p(dres), _p(dg),
+                                                 _p(db), i32(B), i32(C), i32(H * W), i32(0 if out is None else 1), _stream()),
+           "scda_batchnorm_add_relu_bwd_hip")
+    return dx, dres, dg, db
+
+
 def batchnorm_eval(x, gamma, beta, run_mean, run_var, eps, act, slope, dy=None):
     """eval-mode batch norm (+act); with dy: the gradient w.r.t. x"""
     _req(x, "x"); _req(gamma, "gamma"); _req(beta, "beta"); _req(run_mean, "running_mean"); _req(run_var, "running_var")

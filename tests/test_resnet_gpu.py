@@ -47,6 +47,57 @@ def test_batch_norm_train_on_roi_shaped_input(cuda, shape):
     close(rmg, rm, 1e-5); close(rvg, rv, 1e-5)
 
 
+@pytest.mark.parametrize("shape", [(1, 16, 50, 84), (1, 8, 100, 168), (1, 8, 3584, 7), (1, 4, 160, 256), (1, 8, 7, 8)])
+def test_batch_norm_residual_join_one_kernel(cuda, shape, monkeypatch):
+    """bn3 + "out += residual" + ReLU of a bottleneck (models/mask_rcnn/resnet.py:95-104) in the batch norm's own pass, both ways:
+    against plain torch, and bit-identical to the batch norm kernel followed by the join kernel (SCDA_BN_NO_JOIN=1) -- output,
+    running statistics, all four gradients"""
+    from scda_amd import layers as L
+    from scda_amd import native
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(*shape, generator=g) * 1.3 + 0.2
+    r = torch.randn(*shape, generator=g)
+    dy = torch.randn(*shape, generator=g)
+    C = shape[1]
+    ga, be = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    xr, rr, gr, br = x.clone().requires_grad_(), r.clone().requires_grad_(), ga.clone().requires_grad_(), be.clone().requires_grad_()
+    rm, rv = torch.zeros(C), torch.ones(C)
+    y = F.relu(F.batch_norm(xr, rm, rv, gr, br, True, 0.1, 1e-5) + rr); y.backward(dy)
+    assert native.batchnorm_add_relu_ok(x.to(cuda))
+
+    def run(joined):
+        if joined:
+            monkeypatch.delenv("SCDA_BN_NO_JOIN", raising=False)
+        else:
+            monkeypatch.setenv("SCDA_BN_NO_JOIN", "1")
+        bn = L.BatchNorm2d(C).to(cuda).train()
+        bn.weight.data.copy_(ga); bn.bias.data.copy_(be)
+        xg, rg = x.to(cuda).requires_grad_(), r.to(cuda).requires_grad_()
+        yg = bn.forward_add_relu(xg, rg)
+        assert (type(yg.grad_fn).__name__ == "BatchNormAddReluFnBackward") == joined
+        yg.backward(dy.to(cuda))
+        return yg.detach(), xg.grad, rg.grad, bn.weight.grad, bn.bias.grad, bn.running_mean.clone(), bn.running_var.clone()
+
+    one, two = run(True), run(False)
+    for a, b in zip(one, two):
+        assert torch.equal(a, b)
+    close(one[0], y, 1e-5); close(one[1], xr.grad, 1e-4); close(one[2], rr.grad, 1e-5); close(one[3], gr.grad, 1e-4)
+    close(one[4], br.grad, 1e-4); close(one[5], rm, 1e-5); close(one[6], rv, 1e-5)
+
+
+def test_batch_norm_residual_join_falls_back(cuda):
+    """batch > 1, eval mode and planes that are no multiple of 4 floats run the two kernels (same results as plain torch)"""
+    from scda_amd import layers as L
+    g = torch.Generator().manual_seed(8)
+    for shape, train in (((3, 4, 6, 10), True), ((1, 4, 5, 7), True), ((1, 4, 8, 8), False)):
+        x, r = torch.randn(*shape, generator=g), torch.randn(*shape, generator=g)
+        ref = nn.BatchNorm2d(shape[1]).train(train)
+        bn = L.BatchNorm2d(shape[1]).to(cuda).train(train)
+        yg = bn.forward_add_relu(x.to(cuda).requires_grad_(), r.to(cuda))
+        assert type(yg.grad_fn).__name__ == "AddReluFnBackward"
+        close(yg, F.relu(ref(x) + r), 1e-5)
+
+
 class TorchBottleneck(nn.Module):
     """models/mask_rcnn/resnet.py:69-106 in plain torch"""
 
@@ -64,7 +115,8 @@ class TorchBottleneck(nn.Module):
         return F.relu(out + (x if self.downsample is None else self.downsample(x)))
 
 
-@pytest.mark.parametrize("inplanes,planes,stride,down,shape", [(64, 32, 2, True, (2, 64, 14, 18)), (128, 32, 1, False, (40, 128, 7, 7))])
+@pytest.mark.parametrize("inplanes,planes,stride,down,shape", [(64, 32, 2, True, (2, 64, 14, 18)), (128, 32, 1, False, (40, 128, 7, 7)),
+                                                               (128, 32, 1, False, (1, 128, 28, 36)), (64, 32, 2, True, (1, 64, 28, 40))])
 def test_bottleneck_forward_backward(cuda, inplanes, planes, stride, down, shape):
     from scda_amd import layers as L
     from scda_amd.dropin.models.mask_rcnn.resnet import Bottleneck
