@@ -331,16 +331,29 @@ def main():
     # separate pass after the timed region (3 more iterations) and the throughput number stays unperturbed.
     in_region = a.config == "vgg16"
     dom_list = list(dominant) if isinstance(dominant, tuple) else [dominant]
-    native.prof_enable(dom_list if in_region else False)
+    # An event pair is two queue markers, and a launch behind a marker starts ~6 us after the kernel in front of it has ended where
+    # an unmarked one follows back to back: with the pairs around all 39 Winograd launches of EVERY timed iteration the iteration is
+    # 0.31 ms (1.7 %) longer than without them (scripts/event_pair_cost.py: alternating blocks in one process, 18.44 vs 18.13 ms).
+    # They are therefore recorded in every PROF_EVERY-th timed iteration -- still inside the timed region, 39 x steps / PROF_EVERY
+    # samples; SCDA_BENCH_PROF_EVERY=1 marks every iteration, as rounds 1 - 4 did.
+    prof_every = max(1, int(os.environ.get("SCDA_BENCH_PROF_EVERY", "5")))
+    prof_iters = 0
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for i in range(a.steps):
+        marked = in_region and i % prof_every == 0
+        if marked:
+            native.prof_enable(dom_list)
+            prof_iters += 1
         out = tr.step(src, gts, info, tgt, **step_kw)
+        if marked:
+            native.prof_enable(False)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    in_region_timed = in_region
     mask_rois = getattr(tr.model, "last_mask_rois", None) if a.config == "maskrcnn" else None
     if mask_rois is not None:
         f_iter += RC.mask_branch_tflop(mask_rois)
@@ -400,6 +413,10 @@ def main():
                     "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                     "traffic_unit": "bytes/launch (HBM+Infinity-Cache side of L2: 2*FETCH_SIZE + WRITE_SIZE)", "traffic_source": src,
                     "algorithmic_bytes_per_launch": round(by / n), "launches": n, "avg_launch_ms": round(tms / n, 4),
+                    "how": ("HIP event pairs on the launch stream around every launch of the class in %d of the %d timed iterations "
+                            "(every %d%s: a pair costs the launch behind it ~6 us, scripts/event_pair_cost.py)"
+                            % (prof_iters, a.steps, prof_every, "th" if prof_every > 1 else "")) if in_region_timed else
+                           "HIP event pairs on the launch stream in 3 extra iterations after the timed region",
                     # like for like: the counter passes' average over the same launch population (joined per dispatch with the layer
                     # each ran), against THAT population's algorithmic bytes
                     "traffic_launches": t_n, "traffic_algorithmic_bytes_per_launch": t_alg,
