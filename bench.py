@@ -341,7 +341,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(a.steps):
-        marked = in_region and i % prof_every == 0
+        marked = in_region and i % prof_every == min(2, prof_every - 1, a.steps - 1)     # (not the first iterations behind the barrier)
         if marked:
             native.prof_enable(dom_list)
             prof_iters += 1
