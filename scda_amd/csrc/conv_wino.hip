@@ -1068,7 +1068,9 @@ static int wino_launch(const float *x, const float *u, const float *bias, float 
     // more 64-row tiles than CUs: one persistent workgroup per CU walks them (see the kernel); SCDA_WINO_PERSIST=0 turns it off
     static const int n_cu = [] { int d = 0, n = 0; if (hipGetDevice(&d) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || n < 8) n = 256; return n / 8 * 8; }();
     const char *pe = getenv("SCDA_WINO_PERSIST");
-    const bool persist = MBv == 2 && wgs > n_cu && g.slabs_per_split >= 2 && g.n_slab >= 2 && !(pe && pe[0] == '0') &&
+    // (a split launch is never persistent: the automatic heuristic only splits launches below one workgroup per CU, but
+    //  SCDA_WINO_SPLITS / SCDA_WINO_MB can force both at once -- the split-slab epilogue exists in the one-tile form only)
+    const bool persist = MBv == 2 && splits == 1 && wgs > n_cu && g.slabs_per_split >= 2 && g.n_slab >= 2 && !(pe && pe[0] == '0') &&
                          (size_t)M * batch * H * W * sizeof(float) < ((size_t)1 << 31);
     g.n_wg = (int)wgs;
     g_wino_last_persist = persist ? 1 : 0;
@@ -1076,7 +1078,10 @@ static int wino_launch(const float *x, const float *u, const float *bias, float 
 #define WINO_LAUNCH(MB_, P_, E_) hipLaunchKernelGGL((conv_wino_kernel<MB_, P_, E_>), dim3((unsigned)((P_) ? n_cu : wgs)), dim3(512), 0, st, u, x, g, e)
 #define WINO_LAUNCH_EPI(MB_, P_)                                                      \
     do {                                                                              \
-        if (epi == WEPI_SPLIT) { if (!(P_)) WINO_LAUNCH(MB_, false, WEPI_SPLIT); }    \
+        if (epi == WEPI_SPLIT) {                                                      \
+            if (P_) { prof_end(st); set_error("conv_wino_kernel: a split launch cannot be persistent"); return SCDA_EINVAL; } \
+            WINO_LAUNCH(MB_, false, WEPI_SPLIT);                                      \
+        }                                                                             \
         else if (epi == WEPI_POOL) WINO_LAUNCH(MB_, P_, WEPI_POOL);                   \
         else if (epi == WEPI_MASK) WINO_LAUNCH(MB_, P_, WEPI_MASK);                   \
         else WINO_LAUNCH(MB_, P_, WEPI_PLAIN);                                        \

@@ -275,6 +275,29 @@ def test_wino_persistent_form_is_bit_identical_to_one_tile_per_workgroup(cuda, c
         assert torch.equal(a, c)
 
 
+@pytest.mark.parametrize("case,splits", [((1, 256, 128, 256, 256), 2), ((1, 128, 64, 128, 128), 2), ((3, 72, 70, 200, 72), 3)])
+def test_wino_forced_split_on_a_launch_of_more_tiles_than_cus(cuda, case, splits, monkeypatch):
+    """SCDA_WINO_SPLITS on a layer of more 64-row tiles than CUs (the persistent form's territory; the automatic heuristic never splits
+    there): the launch must take the one-tile split form + reduce and give the unsplit launch's result to rounding -- a persistent
+    launch has no split-slab epilogue, and once launched nothing and summed an uninitialised workspace (advisor finding, round 5)"""
+    from scda_amd import native
+    B, Cin, H, W, Cout = case
+    g = torch.Generator().manual_seed(sum(case) + 17)
+    x = torch.randn(B, Cin, H, W, generator=g).to(cuda)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).to(cuda)
+    b = torch.randn(Cout, generator=g).to(cuda)
+    u = native.conv2d_wino_pack(w, False)
+    y0 = native.conv2d_wino(x, u, b, Cout, 1, 0.0)
+    was_persistent = native.wino_last_persistent()
+    monkeypatch.setenv("SCDA_WINO_SPLITS", str(splits))
+    native.workspace(1 << 20, x.device).view(torch.float32).fill_(float("nan"))     # a launch that skipped the kernel would sum these
+    y1 = native.conv2d_wino(x, u, b, Cout, 1, 0.0)
+    assert native.wino_last_order()[0][3] == splits and not native.wino_last_persistent(), (native.wino_last_order(), was_persistent)
+    assert torch.isfinite(y1).all()
+    close(y1, y0, 5e-5)
+    close(y1, F.relu(F.conv2d(x.cpu(), w.cpu(), b.cpu(), stride=1, padding=1)))
+
+
 @pytest.mark.parametrize("case", [(512, 64, 64), (37, 72, 40), (6, 512, 512), (130, 128, 256)])
 @pytest.mark.parametrize("masked", [False, True])
 def test_wino_on_stacked_7x7_maps(cuda, case, masked, monkeypatch):

@@ -26,6 +26,9 @@ def rel(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 
+# "fp32, tol 1e-5 rel" (relative to max(1, |loss|)); the achieved deltas are printed and logged by
+# model_common.check_losses
+LOSS_REL = 1e-4
 LOSS_KEYS = ('rpn_cls', 'rpn_loc', 'rcnn_cls', 'rcnn_loc', 'adloss', 'dis_patch_loss', 'recon_loss', 'fake_loss1_source',
              'fake_loss_target', 'fake_loss_source', 'loss')
 
@@ -53,9 +56,7 @@ def test_few_target_proposals_fall_back_to_source_clusters(cuda):
     finally:
         L.Dropout.mask_source = None
     assert not tape
-    for k in LOSS_KEYS:
-        a, b = float(out[k]), float(ref[k])
-        assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), (k, a, b)
+    mc.check_losses(out, ref, LOSS_KEYS, LOSS_REL, "few_target_proposals[256x512]")
 
 
 def test_two_iterations_track_oracle(cuda):
@@ -159,10 +160,7 @@ def test_iteration_matches_oracle(cuda):
         L.Dropout.mask_source = None
     assert not tape, "the device consumed fewer dropout masks than the oracle drew"
 
-    for k in ('rpn_cls', 'rpn_loc', 'rcnn_cls', 'rcnn_loc', 'adloss', 'dis_patch_loss', 'recon_loss', 'fake_loss1_source',
-              'fake_loss_target', 'fake_loss_source', 'loss'):
-        a, b = float(out[k]), float(ref[k])
-        assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), (k, a, b)
+    mc.check_losses(out, ref, LOSS_KEYS, LOSS_REL, "iteration_matches_oracle[256x512]")
     assert abs(float(out['rpn_acc'][0]) - float(ref['rpn_acc'][0])) < 0.5
     assert abs(float(out['rcnn_acc'][0]) - float(ref['rcnn_acc'][0])) < 0.5
 
@@ -238,9 +236,7 @@ def test_gradients_with_replayed_selections(cuda, H, W):
         A.replay = None
         rpn_proposal.rpn_output_hook = None
     assert not tape and used >= 40, used
-    for k in LOSS_KEYS:
-        a, b = float(out[k]), float(ref[k])
-        assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), (k, a, b)
+    mc.check_losses(out, ref, LOSS_KEYS, LOSS_REL, "replayed_selections[%dx%d]" % (H, W))
 
     def rel_l2(a, b):
         a = a.detach().double().cpu(); b = b.detach().double().cpu()
