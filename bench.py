@@ -248,7 +248,7 @@ def launch_ranks(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=200)    # ~4 s of device work: long enough for an outside observer (the driver's gpu_busy sampler) to see the GPU
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--config", choices=["vgg16", "resnet50", "maskrcnn"], default="vgg16",
@@ -338,17 +338,31 @@ def main():
     # samples; SCDA_BENCH_PROF_EVERY=1 marks every iteration, as rounds 1 - 4 did.
     prof_every = max(1, int(os.environ.get("SCDA_BENCH_PROF_EVERY", "5")))
     prof_iters = 0
+    # per-segment device time: in the SAME marked iterations an event goes onto the compute stream at each of the trainer's phase
+    # marks (scda_amd/_timing.py; ~12 queue markers per marked iteration, no profiler), read back after the timed region.
+    # host: CPU time of the main thread (it enqueues everything; it spins while it waits for a device result) and of the whole
+    # process, over the timed region.
+    from scda_amd import _timing as T
+    seg_events = []
     torch.cuda.synchronize()
+    cpu_main0, cpu_proc0 = time.thread_time(), time.process_time()
     t0 = time.perf_counter()
     for i in range(a.steps):
         marked = in_region and i % prof_every == min(2, prof_every - 1, a.steps - 1)     # (not the first iterations behind the barrier)
         if marked:
             native.prof_enable(dom_list)
             prof_iters += 1
+            T.MARKS.clear(); T.EVENTS.clear()
+            T.ENABLED = T.DEVICE = True
         out = tr.step(src, gts, info, tgt, **step_kw)
         if marked:
             native.prof_enable(False)
+            T.ENABLED = T.DEVICE = False
+            end = torch.cuda.Event(enable_timing=True)
+            end.record()
+            seg_events.append(list(T.EVENTS) + [("end", end)])
     torch.cuda.synchronize()
+    cpu_main, cpu_proc = time.thread_time() - cpu_main0, time.process_time() - cpu_proc0
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -393,6 +407,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    segments = None
+    if seg_events:
+        acc, order = {}, []
+        for ev in seg_events:
+            for (la, ea), (lb, eb) in zip(ev, ev[1:]):
+                acc[lb] = acc.get(lb, 0.0) + ea.elapsed_time(eb)
+                if lb not in order:
+                    order.append(lb)
+        n_it = len(seg_events)
+        segments = {"unit": "ms of device time on the compute stream, segment ENDING at the named mark (scda_amd/train_step.py); "
+                            "average of %d marked iterations inside the timed region" % n_it}
+        segments.update({k: round(acc[k] / n_it, 3) for k in order})
+        segments["step_begin->end"] = round(sum(ev[0][1].elapsed_time(ev[-1][1]) for ev in seg_events) / n_it, 3)
     if rank == 0:
         ms = dt / a.steps * 1e3
         value = 2.0 * world * a.steps / dt
@@ -470,6 +497,14 @@ def main():
                        "proposals_post_nms": {"source": tr.last_num_proposals[0], "target": tr.last_num_proposals[1], "quota": quota},
                        "preconditioning_iterations": a.warmup + precond},
             "roofline": roof,
+            # where the iteration's time is (verdict r05 item 2): device time by segment, and what the host spent
+            "segments": segments,
+            "host_ms_per_step": round(cpu_main / a.steps * 1e3, 3),
+            "host": {"main_thread_cpu_ms_per_step": round(cpu_main / a.steps * 1e3, 3),
+                     "process_cpu_ms_per_step": round(cpu_proc / a.steps * 1e3, 3),
+                     "note": "CPU time over the timed region / steps; the main thread enqueues the whole iteration and spins while it waits "
+                             "for a device result (RPN outputs, keep lists), so main-thread time ~ wall time unless blocking waits are on",
+                     "cpu_quota": _hostenv.cpu_quota(), "cpu_count": os.cpu_count()},
         }
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline() if a.config == "vgg16" else cpu_baseline_resnet(a.config == "maskrcnn")

@@ -26,9 +26,10 @@ def rel(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 
-# "fp32, tol 1e-5 rel" (relative to max(1, |loss|)); the achieved deltas are printed and logged by
-# model_common.check_losses
-LOSS_REL = 1e-4
+# "fp32, tol 1e-5 rel" (relative to max(1, |loss|)) -- asserted as stated.  Achieved (round 6, printed and
+# logged by model_common.check_losses): worst 1.3e-6 free-running at 256x512 (fake_loss_target), 1.4e-7 / 1.1e-7 with the oracle's
+# selections replayed at 256x512 / 512x1024 -- the Winograd layers' 3e-5 per-element differences average out in the loss means.
+LOSS_REL = 1e-5
 LOSS_KEYS = ('rpn_cls', 'rpn_loc', 'rcnn_cls', 'rcnn_loc', 'adloss', 'dis_patch_loss', 'recon_loss', 'fake_loss1_source',
              'fake_loss_target', 'fake_loss_source', 'loss')
 
