@@ -1442,6 +1442,280 @@ __global__ __launch_bounds__((GemmGldsCfg<BM, BN>::THREADS)) void gemm_glds_kern
     }
 }
 
+// ---- dense GEMM on the bf16 matrix pipe with EXACT products ("bf16 x 9") -----------------------------------------------------
+// v_mfma_f32_32x32x16_bf16 runs at 16x the rate of the fp32 MFMA.  An fp32 value is the sum of three bf16 pieces by truncation
+// (hi = x & 0xffff0000, mid = (x - hi) & 0xffff0000, lo = x - hi - mid: 8 + 8 + 8 significand bits, both subtractions exact), a
+// bf16 x bf16 product is exact in fp32 (16 significand bits), so the nine piece products of a * b add up to its exact 48-bit
+// product: nine bf16 MFMAs per 16 k do the multiplications of eight fp32 MFMAs in 9/16 of the matrix-pipe time, and nothing is
+// narrower than fp32 anywhere.  What the hardware does with the sums (scripts/micro/bf16x9_probe.hip, profiles/r06_bf16x9_probe.txt):
+// the 16 products and C of one instruction are aligned to the largest and TRUNCATED to ~26 bits (2^26 + 15 x 1 - 2^26 -> 8), so
+// nine such instructions into one accumulator are slightly worse than the fp32 MFMA's fmaf chain at K = 25088 (rms 3.8e-8 vs 2.8e-8
+// of sum|ab|) -- but with the hi x hi products in one accumulator and the eight small products in a second one (2^-8 of the size:
+// its truncations do not count) the error is a THIRD of the fp32 MFMA's (max 0.7 - 1.1e-7 vs 2.0 - 2.6e-7, rms 1.0e-8 vs 2.8e-8).
+// That is the form here: two accumulator sets, added in the epilogue.
+//
+// The split costs ~5 VALU operations per value.  Done per wave on its own fragments it is 6.7 VALU per MFMA -- the in-register form
+// of the probe runs at 123 (64 x 64 wave tile) / 148 TFLOP/s fp32-equivalent, no faster than the fp32 kernel.  So the split is
+// done ONCE PER WORKGROUP through LDS: the fp32 tiles land in a 3-stage ring by LDS-DMA exactly as in gemm_glds_kernel (same
+// stagers, same layouts, same staging waves), and while the compute waves run the MFMAs of slab s out of the bf16 image of slab s
+// each of them converts 1/8 of slab s + 1 (3 x (4 values -> 3 x 8 bytes) per lane) into the other bf16 image: 60 VALU + 12 LDS
+// instructions per 36 MFMAs.  bf16 image: three planes [384 rows][16 k] (32 bytes per row: A rows 0..255, B rows 256..383), the two
+// 16-byte halves of a row swapped by s(row) = ((row >> 2) ^ (row >> 3)) & 1 so that the 16 lanes of a ds_read_b128 pass (and the 8 of
+// a b128 write) hit distinct banks; a lane's fragment = 8 consecutive k of its row = one ds_read_b128 per piece.
+//   iteration s:  wait (own image stores, own share of stage s + 1) | barrier | issue the LDS-DMA of slab s + 3 into ring stage s % 3 |
+//                 12 fragment reads of image s % 2 | 36 MFMAs interleaved with the conversion of ring stage (s + 1) % 3 into image (s + 1) % 2
+//   (ring stage s % 3 was converted during iteration s - 1, image (s + 1) % 2 was last read during iteration s - 1.)  Eight waves, each
+//   computing, converting and staging (3 LDS-DMA instructions per slab): the two accumulator sets + fragments need ~200 registers, which
+//   rules out a third wave per SIMD for dedicated staging.
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4v_t;
+
+struct GemmX9Cfg {
+    static constexpr int BM = 256, BN = 128, ROWS = BM + BN;
+    static constexpr int NWC = 8, THREADS = NWC * 64;                 // every wave computes, converts and stages (two accumulator sets +
+                                                                      // the fragments need > 168 registers: no third wave per SIMD)
+    static constexpr int NSTF = 3, STAGE = BK * ROWS;                 // fp32 ring: floats per stage
+    static constexpr int PLANE = ROWS * 32, IMAGE = 3 * PLANE;        // bf16 image: bytes per piece plane / per image
+    static constexpr int LDS_BYTES = NSTF * STAGE * 4 + 2 * IMAGE;    // 73728 + 73728
+    static constexpr int L = ROWS / 16 / NWC;                         // LDS-DMA instructions per wave and stage (2 of A, 1 of B)
+};
+
+__device__ __forceinline__ int x9_swz(const int row) { return ((row >> 2) ^ (row >> 3)) & 1; }
+
+// four consecutive-k fp32 values of one row -> their three bf16 pieces, packed (k ascending), stored at the row's slot
+__device__ __forceinline__ void x9_convert_store(const float x0, const float x1, const float x2, const float x3, char *img, const int off) {
+    constexpr unsigned SEL = 0x07060302u;     // v_perm_b32: (hi16 of the first operand) << 16 | hi16 of the second
+    const float h0 = __uint_as_float(__float_as_uint(x0) & 0xffff0000u), h1 = __uint_as_float(__float_as_uint(x1) & 0xffff0000u);
+    const float h2 = __uint_as_float(__float_as_uint(x2) & 0xffff0000u), h3 = __uint_as_float(__float_as_uint(x3) & 0xffff0000u);
+    const float r0 = x0 - h0, r1 = x1 - h1, r2 = x2 - h2, r3 = x3 - h3;                        // exact
+    const float m0 = __uint_as_float(__float_as_uint(r0) & 0xffff0000u), m1 = __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+    const float m2 = __uint_as_float(__float_as_uint(r2) & 0xffff0000u), m3 = __uint_as_float(__float_as_uint(r3) & 0xffff0000u);
+    const float l0 = r0 - m0, l1 = r1 - m1, l2 = r2 - m2, l3 = r3 - m3;                        // exact, <= 8 significant bits
+    const u32x2_t hp = {__builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), SEL), __builtin_amdgcn_perm(__float_as_uint(x3), __float_as_uint(x2), SEL)};
+    const u32x2_t mp = {__builtin_amdgcn_perm(__float_as_uint(r1), __float_as_uint(r0), SEL), __builtin_amdgcn_perm(__float_as_uint(r3), __float_as_uint(r2), SEL)};
+    const u32x2_t lp = {__builtin_amdgcn_perm(__float_as_uint(l1), __float_as_uint(l0), SEL), __builtin_amdgcn_perm(__float_as_uint(l3), __float_as_uint(l2), SEL)};
+    *reinterpret_cast<u32x2_t *>(img + off) = hp;
+    *reinterpret_cast<u32x2_t *>(img + GemmX9Cfg::PLANE + off) = mp;
+    *reinterpret_cast<u32x2_t *>(img + 2 * GemmX9Cfg::PLANE + off) = lp;
+}
+
+#define X9_PIN(x) asm volatile("" : "+v"(x))
+// the conversion of one lane's three items (3 x 4 values) as a program of 66 single operations, so that the K loop can place
+// them two at a time behind its MFMAs.  Item t, operation o: 0-3 hi = x & mask (into tmp); 4-7 r = x - hi; 8-9 pack hi; 10-13
+// mid = r & mask; 14-17 l = r - mid; 18-19 pack mid; 20-21 pack lo.
+struct X9Work {
+    float x[3][4], r[3][4], l[3][4];
+    float tmp[4];
+    u32x2_t hp[3], mp[3], lp[3];
+};
+__device__ __forceinline__ void x9_op(const int n, X9Work &w) {
+    constexpr unsigned SEL = 0x07060302u;     // v_perm_b32: (hi16 of the first operand) << 16 | hi16 of the second
+    const int t = n / 22, o = n % 22;
+    if (o < 4) { w.tmp[o] = __uint_as_float(__float_as_uint(w.x[t][o]) & 0xffff0000u); X9_PIN(w.tmp[o]); }
+    else if (o < 8) { w.r[t][o - 4] = w.x[t][o - 4] - w.tmp[o - 4]; X9_PIN(w.r[t][o - 4]); }
+    else if (o < 10) { const int q = o - 8; unsigned v = __builtin_amdgcn_perm(__float_as_uint(w.x[t][2 * q + 1]), __float_as_uint(w.x[t][2 * q]), SEL); X9_PIN(v); w.hp[t][q] = v; }
+    else if (o < 14) { w.tmp[o - 10] = __uint_as_float(__float_as_uint(w.r[t][o - 10]) & 0xffff0000u); X9_PIN(w.tmp[o - 10]); }
+    else if (o < 18) { w.l[t][o - 14] = w.r[t][o - 14] - w.tmp[o - 14]; X9_PIN(w.l[t][o - 14]); }
+    else if (o < 20) { const int q = o - 18; unsigned v = __builtin_amdgcn_perm(__float_as_uint(w.r[t][2 * q + 1]), __float_as_uint(w.r[t][2 * q]), SEL); X9_PIN(v); w.mp[t][q] = v; }
+    else { const int q = o - 20; unsigned v = __builtin_amdgcn_perm(__float_as_uint(w.l[t][2 * q + 1]), __float_as_uint(w.l[t][2 * q]), SEL); X9_PIN(v); w.lp[t][q] = v; }
+}
+__device__ __forceinline__ void x9_store(const X9Work &w, const int t, char *dst) {
+    *reinterpret_cast<u32x2_t *>(dst) = w.hp[t];
+    *reinterpret_cast<u32x2_t *>(dst + GemmX9Cfg::PLANE) = w.mp[t];
+    *reinterpret_cast<u32x2_t *>(dst + 2 * GemmX9Cfg::PLANE) = w.lp[t];
+}
+
+// one operand's conversion items of this thread: ITEMS x (row, 4-k chunk).  KC stage image [rows][16] (chunks XOR-swizzled, see
+// GldsOperand): thread -> (row = id >> 2, physical slot = id & 3); MC stage image [16][BMN]: thread -> (row = id % BMN, chunk = id / BMN)
+template <int BMN, bool MC, int ITEMS>
+struct X9Converter {
+    int src[ITEMS];    // float offset inside the operand's part of a ring stage
+    int dst[ITEMS];    // byte offset inside a piece plane
+    __device__ __forceinline__ void init(const int tid, const int row_base) {
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            const int id = tid + 512 * it;
+            int row, chunk;
+            if (MC) { row = id % BMN; chunk = id / BMN; src[it] = 4 * chunk * BMN + row; }
+            else { row = id >> 2; const int slot = id & 3; chunk = slot ^ ((row >> 2) & 3); src[it] = row * 16 + 4 * slot; }
+            const int gr = row_base + row;
+            dst[it] = gr * 32 + (((chunk >> 1) ^ x9_swz(gr)) * 16) + (chunk & 1) * 8;
+        }
+    }
+    __device__ __forceinline__ void load1(const float *part, const int it, float (&v)[4]) const {
+        if (MC) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = part[src[it] + j * BMN];
+        } else {
+            const f32x4v_t q = *reinterpret_cast<const f32x4v_t *>(part + src[it]);
+            v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
+        }
+    }
+    __device__ __forceinline__ void load(const float *part, float (*v)[4]) const {
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            if (MC) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[it][j] = part[src[it] + j * BMN];
+            } else {
+                const f32x4v_t q = *reinterpret_cast<const f32x4v_t *>(part + src[it]);
+                v[it][0] = q[0]; v[it][1] = q[1]; v[it][2] = q[2]; v[it][3] = q[3];
+            }
+        }
+    }
+    __device__ __forceinline__ void store(const float (*v)[4], char *img) const {
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) x9_convert_store(v[it][0], v[it][1], v[it][2], v[it][3], img, dst[it]);
+    }
+};
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__((GemmX9Cfg::THREADS), 1) void gemm_x9_kernel(const float *__restrict__ A, const float *__restrict__ B,
+                                                                          const GemmGeom g, const Epi e) {
+    using C = GemmX9Cfg;
+    constexpr int BM = C::BM, BN = C::BN, NWC = C::NWC, L = C::L, NSTF = C::NSTF, STAGE = C::STAGE;
+    __shared__ __attribute__((aligned(16))) float lds[C::LDS_BYTES / 4];
+    float *ring = lds;
+    char *images = reinterpret_cast<char *>(lds + NSTF * STAGE);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tx, ty, tz;
+    tile_coords(g.nx, g.ny, g.swz, tx, ty, tz);
+    const int m0 = ty * BM, n0 = tx * BN;
+    const int s_begin = tz * (g.k_per_split / BK);
+    const int s_end = min(g.K, (tz + 1) * g.k_per_split) / BK;
+    const int ns = s_end - s_begin;
+
+    // ---- this wave's share of the fp32 ring (LDS-DMA): issued unconditionally with a clamped slab index -- behind a branch the
+    // compiler's waitcnt pass assumes nothing was issued and drains the prefetch with vmcnt(0); a clamped re-load goes into a ring
+    // stage nobody reads any more
+    GldsStager<BM, TA, NWC> sa;
+    GldsStager<BN, TB, NWC> sb;
+    sa.init(A, g.lda, g.M, m0, wave, lane);
+    sb.init(B, g.ldb, g.N, n0, wave, lane);
+    auto issue = [&](int s, int buf) {
+        float *st = ring + buf * STAGE;
+        const int sc = s_begin + min(s, ns - 1);
+        sa.issue(sc * BK, st);
+        sb.issue(sc * BK, st + BK * BM);
+    };
+    if (ns <= 0) return;      // (never: every split holds slabs)
+    issue(0, 0);
+    issue(1, 1);
+    issue(2, 2);
+
+    // ---- compute waves ------------------------------------------------------------------------------------------------------
+    const int wm = wave >> 1, wn = wave & 1;
+    constexpr int TM = 2, TN = 2;
+    f32x16 acc[TM][TN], acs[TM][TN];     // hi x hi | the eight small products
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; acs[i][j][r] = 0.f; }
+    const int lr = lane & 31, lh = lane >> 5;
+    X9Converter<BM, TA, 2> ca;
+    X9Converter<BN, TB, 1> cb;
+    ca.init(tid, 0);
+    cb.init(tid, BM);
+    // fragment byte offsets inside a piece plane (row = block base + lr: the swizzle only sees lr)
+    const int fa = (wm * 64 + lr) * 32 + ((lh ^ x9_swz(lr)) * 16);
+    const int fb = (BM + wn * 64 + lr) * 32 + ((lh ^ x9_swz(lr)) * 16);
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): no kernel-argument load pending inside the loop
+
+    float va[2][4], vb[1][4];
+    // iteration -1: convert stage 0 into image 0
+    SCDA_WAIT_VMCNT(2 * L);
+    __builtin_amdgcn_s_barrier();
+    ca.load(ring, va);
+    cb.load(ring + BK * BM, vb);
+    ca.store(va, images);
+    cb.store(vb, images);
+    int rbuf = 1, fbuf = 0;   // ring stage of slab s + 1; of slab s (free behind barrier(s))
+    for (int s = 0; s < ns; ++s) {
+        // this wave's image stores are done, its share of stage s + 1 has landed (outstanding: s + 1, s + 2)
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(L) : "memory");
+        __builtin_amdgcn_s_barrier();
+        const char *img = images + (s & 1) * C::IMAGE;
+        char *nimg = images + ((s + 1) & 1) * C::IMAGE;
+        const float *rs = ring + rbuf * STAGE;      // (the last iteration converts a clamped re-load into the image nobody reads:
+        u32x4_t a[TM][3], b[TN][3];                 //  no branch inside the MFMA stream)
+        X9Work w;
+#define X9_FA(I_, P_) a[I_][P_] = *reinterpret_cast<const u32x4_t *>(img + (P_) * C::PLANE + fa + (I_) * 32 * 32)
+#define X9_FB(J_, P_) b[J_][P_] = *reinterpret_cast<const u32x4_t *>(img + (P_) * C::PLANE + fb + (J_) * 32 * 32)
+        // LDS reads in the order the slots below need them (they return in order): the first MFMA waits for two of them
+        X9_FA(0, 0); X9_FB(0, 0);
+        __builtin_amdgcn_sched_barrier(0);          // (the scheduler clusters LDS reads by base register otherwise: conversion reads last)
+        X9_FB(1, 0);
+        ca.load1(rs, 0, w.x[0]);                    // item 0: this lane's first chunk of A (conversion starts in slot 1)
+        X9_FA(1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        X9_FA(0, 2); X9_FB(0, 2); X9_FB(1, 2); X9_FA(1, 2);
+        X9_FA(0, 1); X9_FB(0, 1); X9_FB(1, 1); X9_FA(1, 1);
+        ca.load1(rs, 1, w.x[1]);                    // item 1: its second chunk of A
+        cb.load1(rs + BK * BM, 0, w.x[2]);          // item 2: its chunk of B
+#undef X9_FA
+#undef X9_FB
+        __builtin_amdgcn_sched_barrier(0);
+        // Slot k = MFMA k (product k / 4 on block k % 4: the MFMAs on one accumulator are four instructions apart) + conversion
+        // operations 2(k - 1), 2(k - 1) + 1; an item's three image stores in the slot behind its last operation; this wave's three
+        // LDS-DMA instructions for slab s + 3 in slots 13 / 25 (underneath the MFMA stream, not in the empty pipe behind the barrier).
+        // Written slot by slot and fenced: as blocks (all VALU, then all MFMAs) the two waves of a SIMD stay in phase and the
+        // matrix pipe idles for the VALU's length (scripts/micro/bf16x9_probe.hip part 3); left to the scheduler, the MFMAs of
+        // one accumulator were bunched into dependent runs.
+        // pieces: 0 = hi, 1 = mid, 2 = lo.  hi x hi into acc; the eight small products, smallest first, into acs.
+        constexpr int PA[9] = {0, 2, 2, 1, 2, 0, 1, 1, 0}, PB[9] = {0, 2, 1, 2, 0, 2, 1, 0, 1};
+        const int sc3 = (s_begin + min(s + 3, ns - 1)) * BK;
+        float *fst = ring + fbuf * STAGE;
+#pragma unroll
+        for (int k = 0; k < 36; ++k) {
+            const int pr = k >> 2, i = (k >> 1) & 1, j = k & 1;
+            if (pr == 0) {
+                X9_PIN(acc[i][j]);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[i][0]), __builtin_bit_cast(bf16x8_t, b[j][0]), acc[i][j], 0, 0, 0);
+                X9_PIN(acc[i][j]);
+            } else {
+                X9_PIN(acs[i][j]);
+                acs[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[i][PA[pr]]), __builtin_bit_cast(bf16x8_t, b[j][PB[pr]]), acs[i][j], 0, 0, 0);
+                X9_PIN(acs[i][j]);
+            }
+            if (k >= 1 && 2 * (k - 1) < 66) { x9_op(2 * (k - 1), w); x9_op(2 * (k - 1) + 1, w); }
+            if (k == 12) x9_store(w, 0, nimg + ca.dst[0]);
+            if (k == 23) x9_store(w, 1, nimg + ca.dst[1]);
+            if (k == 34) x9_store(w, 2, nimg + cb.dst[0]);
+            if (k == 13) sa.issue(sc3, fst);
+            if (k == 25) sb.issue(sc3, fst + BK * BM);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        rbuf = rbuf == NSTF - 1 ? 0 : rbuf + 1;
+        fbuf = fbuf == NSTF - 1 ? 0 : fbuf + 1;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + lr;
+        if (n >= g.N) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + frag_row(r, lane);
+                if (m >= g.M) continue;
+                float v = acc[i][j][r] + acs[i][j][r];
+                if (e.splits > 1) {
+                    e.ws[((size_t)tz * g.M + m) * g.N + n] = v;
+                } else {
+                    if (e.bias) v += e.bias_on_n ? e.bias[n] : e.bias[m];
+                    v = apply_act(v, e.act, e.slope);
+                    float *dst = e.out + (size_t)m * g.ldc + n;
+                    *dst = e.accumulate ? *dst + v : v;
+                }
+            }
+    }
+}
+
 // ---- data gradient of a conv with <= 4 INPUT channels (an image-side layer: the discriminators' first conv) -------------
 // The implicit GEMM would have M = Cin <= 4 output rows in a 64-row MFMA tile: 95 % of the matrix work on padding (measured
 // 188 us for the 3-channel 256x256 batch-4 layer).  This is a direct form instead: one thread per input pixel, the <= 4
@@ -2116,6 +2390,37 @@ SCDA_API size_t scda_gemm_workspace_bytes(int M, int N, int K) {
     return (size_t)16 * M * N * sizeof(float);
 }
 
+static int gemm_x9_launch(const float *A, const float *B, float *C, int M, int N, int K, int lda, int ldb, int ldc, int trans_a, int trans_b,
+                          const float *bias, int bias_on_n, int act, float slope, int accumulate, void *ws, size_t ws_bytes, hipStream_t st) {
+    using X = GemmX9Cfg;
+    const int nx = cdiv(N, X::BN), ny = cdiv(M, X::BM);
+    const long long tiles = (long long)nx * ny;
+    // split-K: fill the CUs when there are fewer tiles than CUs (>= 32 slabs per split); SCDA_GEMM_X9_SPLITS forces a count
+    int splits = 1;
+    if (const char *f = getenv("SCDA_GEMM_X9_SPLITS")) splits = atoi(f);
+    else if (tiles < 200) splits = (int)std::min<long long>((256 + tiles / 2) / tiles, std::max(1, K / BK / 32));
+    if (splits < 1) splits = 1;
+    if (ldc != N) splits = 1;
+    while (splits > 1 && (size_t)splits * M * N * sizeof(float) > ws_bytes) --splits;
+    GemmGeom g{M, N, K, lda, ldb, ldc, round_k_per_split(K, splits), zero_page(), nx, ny, xcd_swizzle_enabled()};
+    if (!g.zp) { set_error("scda_gemm_hip: could not allocate the zero page"); return SCDA_ELAUNCH; }
+    splits = cdiv(K, g.k_per_split);
+    static const bool no_mpart = getenv("SCDA_GEMM_NO_MPART") != nullptr;
+    if (!no_mpart && g.swz && g.ny >= 16 && (long long)g.nx * g.ny >= 1024 && (double)M * K * sizeof(float) > 4e6) g.swz |= 2;
+    Epi e{C, (float *)ws, bias, bias_on_n, act, slope, splits, accumulate, nullptr, 0.f};
+    dim3 grid((unsigned)(tiles * splits));
+    note_plan(X::BM, X::BN, splits, 2);      // [3] = 2: the bf16 x 9 kernel ran
+    prof_begin(PK_GEMM, 2.0 * M * (double)N * K, st);
+    if (!trans_a && !trans_b) hipLaunchKernelGGL((gemm_x9_kernel<false, false>), grid, dim3(X::THREADS), 0, st, A, B, g, e);
+    else if (!trans_a && trans_b) hipLaunchKernelGGL((gemm_x9_kernel<false, true>), grid, dim3(X::THREADS), 0, st, A, B, g, e);
+    else if (trans_a && !trans_b) hipLaunchKernelGGL((gemm_x9_kernel<true, false>), grid, dim3(X::THREADS), 0, st, A, B, g, e);
+    else hipLaunchKernelGGL((gemm_x9_kernel<true, true>), grid, dim3(X::THREADS), 0, st, A, B, g, e);
+    prof_end(st);
+    int rc = launch_status("gemm_x9_kernel");
+    if (rc || splits == 1) return rc;
+    return launch_dense_reduce((const float *)ws, splits, (long long)M * N, N, bias, bias_on_n, act, slope, accumulate, C, nullptr, nullptr, 0, 0, st);
+}
+
 // C[M][N] (ldc) = op(A) op(B) (+bias) -> act ; trans_a: A stored [K][M]; trans_b: B stored [K][N]
 SCDA_API int scda_gemm_hip(const float *A, const float *B, float *C, int M, int N, int K, int lda, int ldb, int ldc,
                            int trans_a, int trans_b, const float *bias, int bias_on_n, int act, float slope,
@@ -2128,6 +2433,12 @@ SCDA_API int scda_gemm_hip(const float *A, const float *B, float *C, int M, int 
     const bool glds = !no_glds && (K % BK) == 0 && (lda % 4) == 0 && (ldb % 4) == 0 && ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0 &&
                       (!trans_a || (M % 4) == 0) && (!trans_b || (N % 4) == 0) && (long long)lda * 1024 + (long long)M * 4 < (1LL << 31) &&
                       (long long)ldb * 1024 + (long long)N * 4 < (1LL << 31);
+    // exact-product bf16 x 9 form (gemm_x9_kernel): the FC-sized products; SCDA_GEMM_X9=0 keeps them on the fp32 MFMA
+    // (=2: every product the direct-to-LDS path can take, whatever its size -- tests.  Read per call: tests switch it.)
+    const char *x9_env = getenv("SCDA_GEMM_X9");
+    const int x9_mode = x9_env ? atoi(x9_env) : 1;
+    if (glds && (x9_mode == 2 || (x9_mode == 1 && M >= 256 && N >= 128 && K >= 256 && (double)M * N * K >= 4e9)))
+        return gemm_x9_launch(A, B, C, M, N, K, lda, ldb, ldc, trans_a, trans_b, bias, bias_on_n, act, slope, accumulate, ws, ws_bytes, st);
     const char *fbm = getenv("SCDA_CONV_BM");                              // 256 forces the 8-wave tile where legal
     // (not for the [K][M] x [K][N] form -- the FC weight gradient: measured 112 vs 115 TFLOP/s)
     const bool bm256_ok = glds && (M % 256) == 0 && N > 64 && !(trans_a && trans_b);

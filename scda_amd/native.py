@@ -1067,10 +1067,11 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_de
 
 
 def last_plan():
-    """(tile rows, tile cols, split-K count, direct-to-LDS?) of this thread's most recent conv / GEMM launch"""
+    """(tile rows, tile cols, split-K count, direct-to-LDS?) of this thread's most recent conv / GEMM launch; the last entry is the
+    integer 2 (truthy) when the dense GEMM ran as the exact-product bf16 x 9 kernel"""
     out = (ctypes.c_int * 4)()
     lib().scda_debug_last_plan(out)
-    return out[0], out[1], out[2], bool(out[3])
+    return out[0], out[1], out[2], (2 if out[3] == 2 else bool(out[3]))
 
 
 def wino_last_persistent():
