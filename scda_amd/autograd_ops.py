@@ -480,7 +480,10 @@ class BatchNormAddReluFn(Function):
         x, y, gamma, beta, mean, rstd = ctx.saved_tensors
         sg, sb = _sink(ctx.g_ref), _sink(ctx.b_ref)
         both = sg is not None and sb is not None
-        dx, dres, dg, db = N.batchnorm_add_relu_bwd(_c(dy), x, y, gamma, beta, mean, rstd, need_dx=ctx.needs_input_grad[0],
+        dy = _c(dy)
+        if not N.aligned16(dy):     # a contiguous storage-offset view: the kernel reads float4
+            dy = dy.clone()
+        dx, dres, dg, db = N.batchnorm_add_relu_bwd(dy, x, y, gamma, beta, mean, rstd, need_dx=ctx.needs_input_grad[0],
                                                     out=(sg, sb) if both else None)
         if both:
             dg = db = None

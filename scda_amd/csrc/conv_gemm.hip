@@ -1502,6 +1502,11 @@ __device__ __forceinline__ void x9_convert_store(const float x0, const float x1,
 }
 
 #define X9_PIN(x) asm volatile("" : "+v"(x))
+// timing builds only (scripts/ablate/x9_ablate.sh; results are wrong by construction): 1 no conversion arithmetic, 2 no image stores,
+// 4 fragments read once before the loop, 8 no LDS-DMA inside the loop, 16 no barrier, 32 no ring reads, 64 no MFMAs
+#ifndef X9_ABLATE
+#define X9_ABLATE 0
+#endif
 // the conversion of one lane's three items (3 x 4 values) as a program of 66 single operations, so that the K loop can place
 // them two at a time behind its MFMAs.  Item t, operation o: 0-3 hi = x & mask (into tmp); 4-7 r = x - hi; 8-9 pack hi; 10-13
 // mid = r & mask; 14-17 l = r - mid; 18-19 pack mid; 20-21 pack lo.
@@ -1511,6 +1516,7 @@ struct X9Work {
     u32x2_t hp[3], mp[3], lp[3];
 };
 __device__ __forceinline__ void x9_op(const int n, X9Work &w) {
+    if (X9_ABLATE & 1) return;
     constexpr unsigned SEL = 0x07060302u;     // v_perm_b32: (hi16 of the first operand) << 16 | hi16 of the second
     const int t = n / 22, o = n % 22;
     if (o < 4) { w.tmp[o] = __uint_as_float(__float_as_uint(w.x[t][o]) & 0xffff0000u); X9_PIN(w.tmp[o]); }
@@ -1522,6 +1528,7 @@ __device__ __forceinline__ void x9_op(const int n, X9Work &w) {
     else { const int q = o - 20; unsigned v = __builtin_amdgcn_perm(__float_as_uint(w.l[t][2 * q + 1]), __float_as_uint(w.l[t][2 * q]), SEL); X9_PIN(v); w.lp[t][q] = v; }
 }
 __device__ __forceinline__ void x9_store(const X9Work &w, const int t, char *dst) {
+    if (X9_ABLATE & 2) return;
     *reinterpret_cast<u32x2_t *>(dst) = w.hp[t];
     *reinterpret_cast<u32x2_t *>(dst + GemmX9Cfg::PLANE) = w.mp[t];
     *reinterpret_cast<u32x2_t *>(dst + 2 * GemmX9Cfg::PLANE) = w.lp[t];
@@ -1571,42 +1578,77 @@ struct X9Converter {
     }
 };
 
-template <bool TA, bool TB>
+// Work of a launch = units (tile, slab), tile-major.  SK = false: one workgroup per (tile, K-split) -- the split-K form of the other
+// GEMM kernels (partial slabs + dense reduce).  SK = true ("stream-K"): a PERSISTENT grid of G workgroups (one per CU), logical
+// workgroup w owns the contiguous unit range [w R, (w + 1) R), R = ceil(units / G): launches whose tile count is not a multiple of the
+// CU count lose nothing to the last round (FC6's data gradient: 392 tiles on 256 CUs), and the ring streams ACROSS tile boundaries --
+// the next tile's first slabs are in flight while this tile's epilogue stores (the weight gradient's 3136 32-slab tiles).  A range
+// cuts at most its first and its last tile: such a partial segment goes to workspace slot (w, 0) if it starts the range, (w, 1)
+// otherwise, and gemm_x9_fixup_kernel adds the slots of each cut tile in ascending w (fixed order, no atomics) into C.
+struct X9Stream {
+    int sk;        // stream-K launch?
+    int spt;       // slabs per tile (K / 16)
+    int R;         // units per workgroup
+    int G;         // persistent workgroups (multiple of 8)
+    long long U;   // units
+    float *slots;  // [2 G][256][128] partial tiles
+};
+
+template <bool TA, bool TB, bool SK>
 __global__ __launch_bounds__((GemmX9Cfg::THREADS), 1) void gemm_x9_kernel(const float *__restrict__ A, const float *__restrict__ B,
-                                                                          const GemmGeom g, const Epi e) {
+                                                                          const GemmGeom g, const Epi e, const X9Stream sk) {
     using C = GemmX9Cfg;
     constexpr int BM = C::BM, BN = C::BN, NWC = C::NWC, L = C::L, NSTF = C::NSTF, STAGE = C::STAGE;
     __shared__ __attribute__((aligned(16))) float lds[C::LDS_BYTES / 4];
-    float *ring = lds;
-    char *images = reinterpret_cast<char *>(lds + NSTF * STAGE);
+    // the two bf16 images first: every fragment read / image store is then one per-lane base + a 16-bit immediate (image, plane, block)
+    char *images = reinterpret_cast<char *>(lds);
+    float *ring = lds + 2 * C::IMAGE / 4;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int tx, ty, tz;
-    tile_coords(g.nx, g.ny, g.swz, tx, ty, tz);
-    const int m0 = ty * BM, n0 = tx * BN;
-    const int s_begin = tz * (g.k_per_split / BK);
-    const int s_end = min(g.K, (tz + 1) * g.k_per_split) / BK;
-    const int ns = s_end - s_begin;
+    // this workgroup's units: tile t0 from slab st0 on, nu of them (tile-major: tile = tx * ny + ty, M-tile fastest)
+    int t0, st0, nu, wl = 0, tz = 0;
+    if (SK) {
+        const int id = blockIdx.x;
+        wl = (id & 7) * (sk.G >> 3) + (id >> 3);      // XCD x (workgroups x, x + 8, ...) owns a contiguous run of ranges
+        const long long u0 = (long long)wl * sk.R, u1 = min(sk.U, u0 + sk.R);
+        if (u0 >= u1) return;
+        t0 = (int)(u0 / sk.spt); st0 = (int)(u0 - (long long)t0 * sk.spt); nu = (int)(u1 - u0);
+    } else {
+        int tx, ty;
+        tile_coords(g.nx, g.ny, g.swz, tx, ty, tz);
+        t0 = tx * g.ny + ty;
+        st0 = tz * (g.k_per_split / BK);
+        nu = min(g.K, (tz + 1) * g.k_per_split) / BK - st0;
+        if (nu <= 0) return;      // (never: every split holds slabs)
+    }
+    t0 = __builtin_amdgcn_readfirstlane(t0); st0 = __builtin_amdgcn_readfirstlane(st0); nu = __builtin_amdgcn_readfirstlane(nu);
+    const int spt = SK ? sk.spt : 0x7fffffff;
 
-    // ---- this wave's share of the fp32 ring (LDS-DMA): issued unconditionally with a clamped slab index -- behind a branch the
-    // compiler's waitcnt pass assumes nothing was issued and drains the prefetch with vmcnt(0); a clamped re-load goes into a ring
-    // stage nobody reads any more
+    // ---- this wave's share of the fp32 ring (LDS-DMA): issued unconditionally, the cursor stops at the last unit -- behind a branch
+    // the compiler's waitcnt pass assumes nothing was issued and drains the prefetch with vmcnt(0); a re-load of the last unit goes
+    // into a ring stage nobody reads any more
     GldsStager<BM, TA, NWC> sa;
     GldsStager<BN, TB, NWC> sb;
-    sa.init(A, g.lda, g.M, m0, wave, lane);
-    sb.init(B, g.ldb, g.N, n0, wave, lane);
-    auto issue = [&](int s, int buf) {
-        float *st = ring + buf * STAGE;
-        const int sc = s_begin + min(s, ns - 1);
-        sa.issue(sc * BK, st);
-        sb.issue(sc * BK, st + BK * BM);
+    int it = t0, is = st0, iu = 0;      // issue cursor: tile, slab, unit
+    auto set_tile = [&](int t) {
+        // (readfirstlane: the cursor is uniform, but the compiler loses that across the loop-carried updates and then wraps every
+        //  LDS-DMA instruction -- whose descriptor must be scalar -- in a waterfall loop)
+        t = __builtin_amdgcn_readfirstlane(t);
+        const int tx = t / g.ny, ty = t - tx * g.ny;
+        sa.init(A, g.lda, g.M, ty * BM, wave, lane);
+        sb.init(B, g.ldb, g.N, tx * BN, wave, lane);
     };
-    if (ns <= 0) return;      // (never: every split holds slabs)
-    issue(0, 0);
-    issue(1, 1);
-    issue(2, 2);
+    set_tile(it);
+    auto advance = [&]() {
+        if (iu < nu - 1) {
+            ++iu; ++is;
+            if (SK && is == spt) { is = 0; ++it; set_tile(it); }
+        }
+    };
+    sa.issue(is * BK, ring); sb.issue(is * BK, ring + BK * BM); advance();
+    sa.issue(is * BK, ring + STAGE); sb.issue(is * BK, ring + STAGE + BK * BM); advance();
+    sa.issue(is * BK, ring + 2 * STAGE); sb.issue(is * BK, ring + 2 * STAGE + BK * BM); advance();
 
-    // ---- compute waves ------------------------------------------------------------------------------------------------------
     const int wm = wave >> 1, wn = wave & 1;
     constexpr int TM = 2, TN = 2;
     f32x16 acc[TM][TN], acs[TM][TN];     // hi x hi | the eight small products
@@ -1634,46 +1676,58 @@ __global__ __launch_bounds__((GemmX9Cfg::THREADS), 1) void gemm_x9_kernel(const 
     cb.load(ring + BK * BM, vb);
     ca.store(va, images);
     cb.store(vb, images);
-    int rbuf = 1, fbuf = 0;   // ring stage of slab s + 1; of slab s (free behind barrier(s))
-    for (int s = 0; s < ns; ++s) {
-        // this wave's image stores are done, its share of stage s + 1 has landed (outstanding: s + 1, s + 2)
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(L) : "memory");
-        __builtin_amdgcn_s_barrier();
-        const char *img = images + (s & 1) * C::IMAGE;
-        char *nimg = images + ((s + 1) & 1) * C::IMAGE;
-        const float *rs = ring + rbuf * STAGE;      // (the last iteration converts a clamped re-load into the image nobody reads:
-        u32x4_t a[TM][3], b[TN][3];                 //  no branch inside the MFMA stream)
-        X9Work w;
+    int rbuf = 1, fbuf = 0;   // ring stage of unit s + 1; of unit s (free behind barrier(s))
+    int ct = t0, cs = st0;    // compute cursor: tile, slab of unit s
+    int seg0 = 0;             // unit at which the current tile's segment began
+    u32x4_t a[TM][3], b[TN][3];
 #define X9_FA(I_, P_) a[I_][P_] = *reinterpret_cast<const u32x4_t *>(img + (P_) * C::PLANE + fa + (I_) * 32 * 32)
 #define X9_FB(J_, P_) b[J_][P_] = *reinterpret_cast<const u32x4_t *>(img + (P_) * C::PLANE + fb + (J_) * 32 * 32)
+    if (X9_ABLATE & 4) {
+        const char *img = images;
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) { X9_FA(0, pc); X9_FA(1, pc); X9_FB(0, pc); X9_FB(1, pc); }
+    }
+    for (int s = 0; s < nu; ++s) {
+        // this wave's image stores are done, its share of stage s + 1 has landed (outstanding: s + 1, s + 2 -- and possibly an
+        // epilogue's stores, which are YOUNGER: "at most L outstanding" still implies stage s + 1, loads return in order)
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(L) : "memory");
+        if (!(X9_ABLATE & 16)) __builtin_amdgcn_s_barrier();
+        const char *img = images + (s & 1) * C::IMAGE;
+        char *nimg = images + ((s + 1) & 1) * C::IMAGE;
+        const float *rs = ring + rbuf * STAGE;      // (the last iteration converts a re-load of the last unit into the image nobody
+        X9Work w;                                   //  reads: no branch inside the MFMA stream)
+        if (X9_ABLATE) w = X9Work{};
+        if (!(X9_ABLATE & 4)) {
         // LDS reads in the order the slots below need them (they return in order): the first MFMA waits for two of them
         X9_FA(0, 0); X9_FB(0, 0);
         __builtin_amdgcn_sched_barrier(0);          // (the scheduler clusters LDS reads by base register otherwise: conversion reads last)
         X9_FB(1, 0);
-        ca.load1(rs, 0, w.x[0]);                    // item 0: this lane's first chunk of A (conversion starts in slot 1)
+        if (!(X9_ABLATE & 32)) ca.load1(rs, 0, w.x[0]);      // item 0: this lane's first chunk of A (conversion starts in slot 1)
         X9_FA(1, 0);
         __builtin_amdgcn_sched_barrier(0);
         X9_FA(0, 2); X9_FB(0, 2); X9_FB(1, 2); X9_FA(1, 2);
         X9_FA(0, 1); X9_FB(0, 1); X9_FB(1, 1); X9_FA(1, 1);
-        ca.load1(rs, 1, w.x[1]);                    // item 1: its second chunk of A
-        cb.load1(rs + BK * BM, 0, w.x[2]);          // item 2: its chunk of B
-#undef X9_FA
-#undef X9_FB
+        } else if (!(X9_ABLATE & 32)) ca.load1(rs, 0, w.x[0]);
+        if (!(X9_ABLATE & 32)) {
+            ca.load1(rs, 1, w.x[1]);                // item 1: its second chunk of A
+            cb.load1(rs + BK * BM, 0, w.x[2]);      // item 2: its chunk of B
+        }
         __builtin_amdgcn_sched_barrier(0);
         // Slot k = MFMA k (product k / 4 on block k % 4: the MFMAs on one accumulator are four instructions apart) + conversion
         // operations 2(k - 1), 2(k - 1) + 1; an item's three image stores in the slot behind its last operation; this wave's three
-        // LDS-DMA instructions for slab s + 3 in slots 13 / 25 (underneath the MFMA stream, not in the empty pipe behind the barrier).
+        // LDS-DMA instructions for unit s + 3 in slots 13 / 25 (underneath the MFMA stream, not in the empty pipe behind the barrier).
         // Written slot by slot and fenced: as blocks (all VALU, then all MFMAs) the two waves of a SIMD stay in phase and the
         // matrix pipe idles for the VALU's length (scripts/micro/bf16x9_probe.hip part 3); left to the scheduler, the MFMAs of
         // one accumulator were bunched into dependent runs.
         // pieces: 0 = hi, 1 = mid, 2 = lo.  hi x hi into acc; the eight small products, smallest first, into acs.
         constexpr int PA[9] = {0, 2, 2, 1, 2, 0, 1, 1, 0}, PB[9] = {0, 2, 1, 2, 0, 2, 1, 0, 1};
-        const int sc3 = (s_begin + min(s + 3, ns - 1)) * BK;
         float *fst = ring + fbuf * STAGE;
 #pragma unroll
         for (int k = 0; k < 36; ++k) {
             const int pr = k >> 2, i = (k >> 1) & 1, j = k & 1;
-            if (pr == 0) {
+            if (X9_ABLATE & 64) {
+                X9_PIN(a[i][pr % 3][0]); X9_PIN(b[j][pr % 3][0]);
+            } else if (pr == 0) {
                 X9_PIN(acc[i][j]);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[i][0]), __builtin_bit_cast(bf16x8_t, b[j][0]), acc[i][j], 0, 0, 0);
                 X9_PIN(acc[i][j]);
@@ -1686,33 +1740,106 @@ __global__ __launch_bounds__((GemmX9Cfg::THREADS), 1) void gemm_x9_kernel(const 
             if (k == 12) x9_store(w, 0, nimg + ca.dst[0]);
             if (k == 23) x9_store(w, 1, nimg + ca.dst[1]);
             if (k == 34) x9_store(w, 2, nimg + cb.dst[0]);
-            if (k == 13) sa.issue(sc3, fst);
-            if (k == 25) sb.issue(sc3, fst + BK * BM);
+            if (k == 13 && !(X9_ABLATE & 8)) sa.issue(is * BK, fst);
+            if (k == 25 && !(X9_ABLATE & 8)) sb.issue(is * BK, fst + BK * BM);
             __builtin_amdgcn_sched_barrier(0);
         }
+        advance();
         rbuf = rbuf == NSTF - 1 ? 0 : rbuf + 1;
         fbuf = fbuf == NSTF - 1 ? 0 : fbuf + 1;
-    }
+        // ---- end of this tile's segment: epilogue ---------------------------------------------------------------------------
+        const bool tile_end = SK && cs == spt - 1;
+        if (tile_end || s == nu - 1) {
+            // (opaque copies: computed from the loop-invariant lane / wave numbers, the 64 store offsets were hoisted out of the K loop
+            //  and held -- i.e. spilled -- across it)
+            int lane = tid & 63, lr = lane & 31, wm = wave >> 1, wn = wave & 1;
+            X9_PIN(lane); X9_PIN(lr);
+            asm volatile("" : "+s"(wm), "+s"(wn));
+            const int tx = ct / g.ny, ty = ct - tx * g.ny;
+            const int m0 = ty * BM, n0 = tx * BN;
+            const bool partial = SK && !(tile_end && cs - (s - seg0) == 0);      // the segment does not cover slabs 0 .. spt - 1
+            if (SK && partial) {
+                float *slot = sk.slots + ((size_t)2 * wl + (seg0 == 0 ? 0 : 1)) * (BM * BN);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + lr;
-        if (n >= g.N) continue;
+                for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+                    for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + i * 32 + frag_row(r, lane);
-                if (m >= g.M) continue;
-                float v = acc[i][j][r] + acs[i][j][r];
-                if (e.splits > 1) {
-                    e.ws[((size_t)tz * g.M + m) * g.N + n] = v;
-                } else {
-                    if (e.bias) v += e.bias_on_n ? e.bias[n] : e.bias[m];
-                    v = apply_act(v, e.act, e.slope);
-                    float *dst = e.out + (size_t)m * g.ldc + n;
-                    *dst = e.accumulate ? *dst + v : v;
+                        for (int r = 0; r < 16; ++r)
+                            slot[(wm * 64 + i * 32 + frag_row(r, lane)) * BN + wn * 64 + j * 32 + lr] = acc[i][j][r] + acs[i][j][r];
+            } else {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n = n0 + wn * 64 + j * 32 + lr;
+                    if (n >= g.N) continue;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int m = m0 + wm * 64 + i * 32 + frag_row(r, lane);
+                            if (m >= g.M) continue;
+                            float v = acc[i][j][r] + acs[i][j][r];
+                            if (!SK && e.splits > 1) {
+                                e.ws[((size_t)tz * g.M + m) * g.N + n] = v;
+                            } else {
+                                if (e.bias) v += e.bias_on_n ? e.bias[n] : e.bias[m];
+                                v = apply_act(v, e.act, e.slope);
+                                float *dst = e.out + (size_t)m * g.ldc + n;
+                                *dst = e.accumulate ? *dst + v : v;
+                            }
+                        }
                 }
             }
+            if (SK) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; acs[i][j][r] = 0.f; }
+                seg0 = s + 1;
+            }
+        }
+        if (SK) { if (cs == spt - 1) { cs = 0; ++ct; } else ++cs; }
+    }
+}
+
+#undef X9_FA
+#undef X9_FB
+
+// the cut tiles of a stream-K launch: boundary b (1 .. G - 1) lies inside tile t = b R / spt unless it falls on the tile's first slab;
+// the FIRST boundary inside a tile adds up that tile's partial segments, workgroups wa = b - 1 .. wb in ascending order, and applies
+// the epilogue.  grid (G - 1, 4): blockIdx.y = a quarter of the tile's rows.
+__global__ __launch_bounds__(256) void gemm_x9_fixup_kernel(const GemmGeom g, const Epi e, const X9Stream sk) {
+    constexpr int BM = GemmX9Cfg::BM, BN = GemmX9Cfg::BN;
+    const int b = blockIdx.x + 1;
+    const long long u = (long long)b * sk.R;
+    if (u >= sk.U) return;
+    const int t = (int)(u / sk.spt);
+    const long long F = (long long)t * sk.spt;
+    if (u == F || (long long)(b - 1) * sk.R > F) return;      // not inside a tile / not the first boundary inside it
+    const int wa = b - 1;
+    const int wb = (int)min((F + sk.spt - 1) / sk.R, (long long)sk.G - 1);
+    const int slot_a = (long long)wa * sk.R == F ? 0 : 1;
+    const int tx = t / g.ny, ty = t - tx * g.ny;
+    const int m0 = ty * BM, n0 = tx * BN;
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    for (int idx = threadIdx.x; idx < (BM / 4) * (BN / 4); idx += 256) {
+        const int row = blockIdx.y * (BM / 4) + idx / (BN / 4), col = (idx % (BN / 4)) * 4;
+        f32x4_t v = *reinterpret_cast<const f32x4_t *>(sk.slots + ((size_t)2 * wa + slot_a) * (BM * BN) + row * BN + col);
+        for (int w = wa + 1; w <= wb; ++w) v += *reinterpret_cast<const f32x4_t *>(sk.slots + ((size_t)2 * w) * (BM * BN) + row * BN + col);
+        const int m = m0 + row;
+        if (m >= g.M) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = n0 + col + q;
+            if (n >= g.N) continue;
+            float x = v[q];
+            if (e.bias) x += e.bias_on_n ? e.bias[n] : e.bias[m];
+            x = apply_act(x, e.act, e.slope);
+            float *dst = e.out + (size_t)m * g.ldc + n;
+            *dst = e.accumulate ? *dst + x : x;
+        }
     }
 }
 
@@ -2385,9 +2512,15 @@ SCDA_API void scda_debug_last_plan(int *out4) {
     for (int i = 0; i < 4; ++i) out4[i] = g_last_plan[i];
 }
 
+static int x9_persistent_workgroups() {
+    static const int n_cu = [] { int d = 0, n = 0; if (hipGetDevice(&d) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || n < 8) n = 256; return n / 8 * 8; }();
+    return n_cu;
+}
+
 SCDA_API size_t scda_gemm_workspace_bytes(int M, int N, int K) {
     (void)K;
-    return (size_t)16 * M * N * sizeof(float);
+    // split-K slabs, or the stream-K form's two partial-tile slots per persistent workgroup (gemm_x9_kernel)
+    return std::max((size_t)16 * M * N * sizeof(float), (size_t)2 * x9_persistent_workgroups() * GemmX9Cfg::BM * GemmX9Cfg::BN * sizeof(float));
 }
 
 static int gemm_x9_launch(const float *A, const float *B, float *C, int M, int N, int K, int lda, int ldb, int ldc, int trans_a, int trans_b,
@@ -2395,10 +2528,17 @@ static int gemm_x9_launch(const float *A, const float *B, float *C, int M, int N
     using X = GemmX9Cfg;
     const int nx = cdiv(N, X::BN), ny = cdiv(M, X::BM);
     const long long tiles = (long long)nx * ny;
-    // split-K: fill the CUs when there are fewer tiles than CUs (>= 32 slabs per split); SCDA_GEMM_X9_SPLITS forces a count
+    const int n_cu = x9_persistent_workgroups();
+    // more tiles than CUs: the persistent stream-K form (SCDA_GEMM_X9_SK=0 keeps one workgroup per tile, =2 forces it for any count)
+    const char *sk_env = getenv("SCDA_GEMM_X9_SK");
+    const int sk_mode = sk_env ? atoi(sk_env) : 1;
+    const size_t slot_bytes = (size_t)2 * n_cu * X::BM * X::BN * sizeof(float);
+    const bool stream = !getenv("SCDA_GEMM_X9_SPLITS") && ws_bytes >= slot_bytes && (sk_mode == 2 || (sk_mode == 1 && tiles > n_cu));
+    // split-K (one workgroup per (tile, split)): fill the CUs when there are fewer tiles than CUs (>= 32 slabs per split);
+    // SCDA_GEMM_X9_SPLITS forces a count
     int splits = 1;
     if (const char *f = getenv("SCDA_GEMM_X9_SPLITS")) splits = atoi(f);
-    else if (tiles < 200) splits = (int)std::min<long long>((256 + tiles / 2) / tiles, std::max(1, K / BK / 32));
+    else if (!stream && tiles < 200) splits = (int)std::min<long long>((256 + tiles / 2) / tiles, std::max(1, K / BK / 32));
     if (splits < 1) splits = 1;
     if (ldc != N) splits = 1;
     while (splits > 1 && (size_t)splits * M * N * sizeof(float) > ws_bytes) --splits;
@@ -2408,16 +2548,34 @@ static int gemm_x9_launch(const float *A, const float *B, float *C, int M, int N
     static const bool no_mpart = getenv("SCDA_GEMM_NO_MPART") != nullptr;
     if (!no_mpart && g.swz && g.ny >= 16 && (long long)g.nx * g.ny >= 1024 && (double)M * K * sizeof(float) > 4e6) g.swz |= 2;
     Epi e{C, (float *)ws, bias, bias_on_n, act, slope, splits, accumulate, nullptr, 0.f};
-    dim3 grid((unsigned)(tiles * splits));
-    note_plan(X::BM, X::BN, splits, 2);      // [3] = 2: the bf16 x 9 kernel ran
+    X9Stream sk{0, K / BK, 0, n_cu, 0, (float *)ws};
+    if (stream) {
+        sk.sk = 1;
+        sk.U = tiles * sk.spt;
+        sk.R = (int)((sk.U + n_cu - 1) / n_cu);
+    }
+    dim3 grid(stream ? (unsigned)n_cu : (unsigned)(tiles * splits));
+    note_plan(X::BM, X::BN, stream ? -1 : splits, 2);      // [3] = 2: the bf16 x 9 kernel ran; [2] = -1: as a stream-K launch
     prof_begin(PK_GEMM, 2.0 * M * (double)N * K, st);
-    if (!trans_a && !trans_b) hipLaunchKernelGGL((gemm_x9_kernel<false, false>), grid, dim3(X::THREADS), 0, st, A, B, g, e);
-    else if (!trans_a && trans_b) hipLaunchKernelGGL((gemm_x9_kernel<false, true>), grid, dim3(X::THREADS), 0, st, A, B, g, e);
-    else if (trans_a && !trans_b) hipLaunchKernelGGL((gemm_x9_kernel<true, false>), grid, dim3(X::THREADS), 0, st, A, B, g, e);
-    else hipLaunchKernelGGL((gemm_x9_kernel<true, true>), grid, dim3(X::THREADS), 0, st, A, B, g, e);
+#define X9_LAUNCH(TA_, TB_)                                                                                                       \
+    do {                                                                                                                          \
+        if (stream) hipLaunchKernelGGL((gemm_x9_kernel<TA_, TB_, true>), grid, dim3(X::THREADS), 0, st, A, B, g, e, sk);          \
+        else hipLaunchKernelGGL((gemm_x9_kernel<TA_, TB_, false>), grid, dim3(X::THREADS), 0, st, A, B, g, e, sk);                \
+    } while (0)
+    if (!trans_a && !trans_b) X9_LAUNCH(false, false);
+    else if (!trans_a && trans_b) X9_LAUNCH(false, true);
+    else if (trans_a && !trans_b) X9_LAUNCH(true, false);
+    else X9_LAUNCH(true, true);
+#undef X9_LAUNCH
     prof_end(st);
     int rc = launch_status("gemm_x9_kernel");
-    if (rc || splits == 1) return rc;
+    if (rc) return rc;
+    if (stream) {
+        if (sk.U % sk.R == 0 && sk.R % sk.spt == 0) return SCDA_OK;      // every range is whole tiles: nothing was cut
+        hipLaunchKernelGGL(gemm_x9_fixup_kernel, dim3((unsigned)(n_cu - 1), 4), dim3(256), 0, st, g, e, sk);
+        return launch_status("gemm_x9_fixup_kernel");
+    }
+    if (splits == 1) return rc;
     return launch_dense_reduce((const float *)ws, splits, (long long)M * N, N, bias, bias_on_n, act, slope, accumulate, C, nullptr, nullptr, 0, 0, st);
 }
 

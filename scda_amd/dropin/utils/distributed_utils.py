@@ -59,6 +59,9 @@ class SegmentedReduce:
 
     def launch_early(self):
         lo, hi = self.early
+        # (a head gradient that autograd -- or a foreign optimiser's zero_grad(set_to_none=True) -- left OUTSIDE the bucket is moved
+        #  into it first: launch_rest()'s check would otherwise overwrite the reduced slice with the local gradient afterwards)
+        self.flat.check_aliases((lo, hi))
         self.flat.finalize_grads((lo, hi))
         self.works.append(dist.all_reduce(self.flat.grad[lo:hi], async_op=True))
         self.early_done = True

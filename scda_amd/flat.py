@@ -58,11 +58,16 @@ class FlatParams:
         return t is not None and t.device == bucket.device and \
             bucket.data_ptr() <= t.data_ptr() < bucket.data_ptr() + self.numel * 4
 
-    def check_aliases(self):
+    def check_aliases(self, span=None):
         """Every parameter must still be a view of `data` and its gradient a view of `grad`.  A gradient that was set to None
         or replaced by a fresh tensor (Module.zero_grad(set_to_none=True), an optimiser other than FlatAdam) is copied into the
-        bucket and re-attached; a parameter that was re-homed (`module.cpu()`, `.to()`, `.half()`) cannot be repaired here."""
+        bucket and re-attached; a parameter that was re-homed (`module.cpu()`, `.to()`, `.half()`) cannot be repaired here.
+        span = (lo, hi): only the parameters that lie inside that slice of the bucket."""
         for p in self.params:
+            if span is not None:
+                off = (p.data.data_ptr() - self.data.data_ptr()) // 4
+                if off < span[0] or off + p.numel() > span[1]:
+                    continue
             if not self._inside(p.data, self.data):
                 raise RuntimeError("a parameter of this FlatParams bucket no longer lives in it (module.to()/.cpu()/.half() after "
                                    "flattening?): re-create FlatParams, or copy state_dict() instead of moving the module")

@@ -40,17 +40,35 @@ class Conv2d(nn.Conv2d):
         self.pool_next = False
         self._pool_ref = None
 
+    def _my_pool(self):
+        """the MaxPool2x2 the fusion plan paired with THIS module object, or None.  The pairing is checked from both sides: a shallow
+        copy of the model (nn.DataParallel replicas copy __dict__) carries the original's weak reference, but the original's pool names
+        the original conv as its producer -- the copy then simply runs un-fused instead of signalling a pool it does not feed."""
+        pool = self._pool_ref() if self._pool_ref is not None else None
+        if pool is None or pool._producer is None or pool._producer() is not self:
+            return None
+        return pool
+
+    def __getstate__(self):
+        # copy.deepcopy / pickle / torch.save(model): weak references do not travel.  The copy runs un-fused until plan_act_fusion is
+        # called on it (the model constructors do that; a deep copy of a planned model can call it again).
+        state = dict(self.__dict__)
+        state["_pool_ref"] = None
+        state["pool_next"] = False
+        return state
+
     def forward(self, x):
-        if self.pool_next and A.replay is None and self.fused_act == A.ACT_RELU and self.defer_act_bwd:
+        pool = self._my_pool() if self.pool_next else None
+        if pool is not None:
+            pool._pooled_shape = None        # (an announcement left behind by a call that raised between this conv and its pool)
+        if pool is not None and A.replay is None and self.fused_act == A.ACT_RELU and self.defer_act_bwd:
             B, Cin, IH, IW = x.shape
             if x.is_cuda and N.conv_pool_fusable(B, Cin, IH, IW, self.out_channels, self.kernel_size[0], self.kernel_size[1],
                                                  self.stride[0], self.padding[0], self.row_period):
                 # conv + ReLU + the 2x2 max-pool behind it in one launch; the pool module recognises the pooled tensor and passes it on
-                pool = self._pool_ref() if self._pool_ref is not None else None
-                if pool is not None:
-                    y = A.ConvPoolFn.apply(x, self.weight, self.bias, self.slope, self.input_act)
-                    pool.expect_pooled(tuple(y.shape))
-                    return y
+                y = A.ConvPoolFn.apply(x, self.weight, self.bias, self.slope, self.input_act)
+                pool.expect_pooled(tuple(y.shape))
+                return y
         return A.conv2d(x, self.weight, self.bias, self.stride[0], self.padding[0], self.fused_act, self.slope,
                         (self.input_act, self.defer_act_bwd), self.row_period)
 
@@ -117,6 +135,13 @@ class Linear(nn.Linear):
 class MaxPool2x2(nn.Module):
     relu_input = False             # fusion plan: this pool's backward also applies the ReLU gradient of the conv in front of it
     _pooled_shape = None           # set by the conv in front (Conv2d.forward) when IT pooled: the shape of the tensor to pass through
+    _producer = None               # weak reference to that conv (plan_act_fusion): see Conv2d._my_pool
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state["_producer"] = None
+        state["_pooled_shape"] = None
+        return state
 
     def expect_pooled(self, shape):
         self._pooled_shape = shape
@@ -210,6 +235,7 @@ def plan_act_fusion(*sequentials):
                 a.defer_act_bwd, b.relu_input = True, True
                 a.pool_next = True
                 a._pool_ref = weakref.ref(b)
+                b._producer = weakref.ref(a)
             elif isinstance(a, Linear) and a.fused_act == A.ACT_RELU and isinstance(b, Dropout):
                 a.defer_act_bwd, b.relu_input = True, True
             else:
@@ -266,7 +292,8 @@ class BatchNorm2d(nn.BatchNorm2d):
         serves (batch 1); the batch norm followed by the join kernel otherwise (eval mode, other shapes, a fused activation of its
         own, the parity tests' replay hook: they replay the join's mask)."""
         if (self.training and self.fused_act == A.ACT_NONE and A.replay is None and self.momentum is not None and x.dim() == 4
-                and x.shape == residual.shape and N.batchnorm_add_relu_ok(x) and not os.environ.get("SCDA_BN_NO_JOIN")):
+                and x.shape == residual.shape and N.batchnorm_add_relu_ok(x) and x.is_contiguous() and residual.is_contiguous()
+                and N.aligned16(x, residual) and not os.environ.get("SCDA_BN_NO_JOIN")):
             if self.num_batches_tracked is not None:
                 self._nbt_pending = getattr(self, "_nbt_pending", 0) + 1
             return A.BatchNormAddReluFn.apply(x, residual, self.weight, self.bias, self.running_mean, self.running_var, self.eps,

@@ -508,11 +508,19 @@ def conv2d_pack_all(flat):
                 off += n
                 tiles += int(L.scda_conv2d_pack_tiles(i32(Cout), i32(Cin), i32(KH), i32(KW), i32(d)))
         desc = upload(torch.tensor(rows, dtype=torch.int64), flat.data.device)
-        out = torch.empty(off, dtype=torch.float32, device=flat.data.device)
-        if len(plans) >= 8:          # (bounded: eligibility patterns of a real data set are few)
-            plans.clear()
-        plan = plans[wino] = (desc, out, entries, tiles, wino)
-    desc, out, entries, tiles, _ = plan
+        while len(plans) >= 4:       # least recently used first (dicts keep insertion order; a hit re-inserts below)
+            plans.pop(next(iter(plans)))
+        plan = (desc, off, entries, tiles, wino)
+    else:
+        plans.pop(wino)
+    plans[wino] = plan
+    desc, total, entries, tiles, _ = plan
+    # ONE output buffer for every plan, sized for the largest layout: a plan is a descriptor table, not a copy of the packed weights
+    # (eight kept plans were eight such buffers -- several hundred MB for VGG16 with variable-size inputs).  Sharing is safe: this
+    # function runs behind an optimiser step, whose epoch bump has already invalidated every cache entry of the previous layout.
+    out = flat.__dict__.get("_scda_pack_out")
+    if out is None or out.numel() < total:
+        out = flat.__dict__["_scda_pack_out"] = torch.empty(total, dtype=torch.float32, device=flat.data.device)
     _check(L.scda_conv2d_pack_weights_batched_hip(_p(flat.data), _p(out), _p(desc), i32(len(entries)),
                                                   ctypes.c_longlong(tiles), _stream()), "scda_conv2d_pack_weights_batched_hip")
     for w, d, off, n in entries:
@@ -947,6 +955,12 @@ def batchnorm_add_relu_ok(x):
     """is relu(bn(x) + residual) served as one kernel for this map?  (batch 1, plane of a multiple of 4 up to 40960 elements)"""
     B, C, H, W = x.shape
     return bool(lib().scda_batchnorm_add_relu_ok(i32(B), i32(H * W)))
+
+
+def aligned16(*tensors):
+    """the 16-byte alignment the plane kernels' float4 accesses need (a contiguous but OFFSET view -- a sliced residual, a dy that
+    autograd hands over as a storage-offset view -- is contiguous and still not aligned)"""
+    return all(t.data_ptr() % 16 == 0 for t in tensors)
 
 
 def batchnorm_add_relu_fwd(x, residual, gamma, beta, run_mean, run_var, eps, momentum):

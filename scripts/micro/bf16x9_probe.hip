@@ -120,6 +120,43 @@ __global__ __launch_bounds__(512) void rate(float *out, int iters, float seed) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+
+// (4) what the matrix pipe leaves for the other instructions of the SAME waves: 36 MFMAs per iteration on eight accumulators (the
+// kernel's dependency distance: four instructions) with NV independent VALU operations / ND LDS reads fenced in behind every MFMA
+template <int NV, int ND>
+__global__ __launch_bounds__(512) void slots(float *out, int iters, float seed) {
+    __shared__ float lds[8192];
+    f32x16 acc[8];
+    for (int i = 0; i < 8; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    u32x4 a = {threadIdx.x, 2u, 3u, 4u}, b = {5u, 6u, threadIdx.x * 3u, 8u};
+    float v[8];
+    for (int i = 0; i < 8; ++i) v[i] = seed + i + threadIdx.x;
+    lds[threadIdx.x] = seed; lds[threadIdx.x + 512] = seed;
+    __syncthreads();
+    float d = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < 36; ++k) {
+            asm volatile("" : "+v"(acc[k & 7]));
+            MF(a, b, acc[k & 7]);
+            asm volatile("" : "+v"(acc[k & 7]));
+#pragma unroll
+            for (int n = 0; n < NV; ++n) {
+                const int q = (k * NV + n) & 7;
+                if (n & 1) v[q] = v[q] - __uint_as_float(__float_as_uint(v[(q + 3) & 7]) & 0xffff0000u);
+                else v[q] = __uint_as_float(__builtin_amdgcn_perm(__float_as_uint(v[q]), __float_as_uint(v[(q + 5) & 7]), 0x07060302u));
+                asm volatile("" : "+v"(v[q]));
+            }
+#pragma unroll
+            for (int n = 0; n < ND; ++n) { d += lds[(threadIdx.x + 64 * (k + n)) & 8191]; asm volatile("" : "+v"(d)); }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    float s = d;
+    for (int i = 0; i < 8; ++i) { for (int r = 0; r < 16; ++r) s += acc[i][r]; s += v[i]; }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 static double frand() { return (double)rand() / RAND_MAX; }
 static float gauss() { return (float)(sqrt(-2.0 * log(frand() + 1e-300)) * cos(6.283185307179586 * frand())); }
 
@@ -208,6 +245,22 @@ int main() {
         run(rate<2, 2, true>, "64 x 64 wave tile, 36 MFMAs + in-register split of 32 values", 2, 2);
         run(rate<2, 4, false>, "64 x 128 wave tile, 72 MFMAs per k16, no split", 2, 4);
         run(rate<2, 4, true>, "64 x 128 wave tile, 72 MFMAs + in-register split of 48 values", 2, 4);
+    }
+    {
+        float *out; hipMalloc(&out, (size_t)256 * 512 * 4);
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        const int iters = 2000;
+        auto run = [&](auto kern, int nv, int nd) {
+            kern<<<256, 512>>>(out, 10, 1.f);
+            hipEventRecord(e0);
+            kern<<<256, 512>>>(out, iters, 1.f);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            printf("  %d VALU + %d ds_read_b32 behind every MFMA: %.3f ms = %.2f us per 72 MFMAs of a SIMD (bare %s)\n", nv, nd, ms, ms * 1e3 / iters, nv + nd ? "see 0 + 0" : "loop");
+        };
+        printf("(4) issue slots beside the MFMA stream, 8 waves per CU (two per SIMD), 36 MFMAs per wave and iteration:\n");
+        run(slots<0, 0>, 0, 0); run(slots<1, 0>, 1, 0); run(slots<2, 0>, 2, 0); run(slots<3, 0>, 3, 0); run(slots<4, 0>, 4, 0); run(slots<6, 0>, 6, 0);
+        run(slots<0, 1>, 0, 1); run(slots<2, 1>, 2, 1);
     }
     return 0;
 }

@@ -12,6 +12,19 @@ P = {"p1_256_64": (1, 256, 200, 336, 64), "p1_64_256": (1, 64, 200, 336, 256), "
      "p2_128_512": (1, 128, 100, 168, 512), "p3_1024_256": (1, 1024, 50, 84, 256), "p3_256_1024": (1, 256, 50, 84, 1024),
      "p4_2048_512": (1, 2048, 3584, 7, 512), "p4_512_2048": (1, 512, 3584, 7, 2048)}
 name, what, n = sys.argv[1], sys.argv[2], int(sys.argv[3])
+FC = {"fc6": (512, 25088, 4096), "fc7": (512, 4096, 4096)}      # (RoIs, in, out): the dense GEMMs (SCDA_GEMM_X9=0: the fp32-MFMA kernel)
+if name in FC:
+    R, fin, fout = FC[name]
+    dev = torch.device("cuda:0")
+    x = torch.randn(R, fin, device=dev).clamp_min(0); w = torch.randn(fout, fin, device=dev) / fin ** 0.5; dy = torch.randn(R, fout, device=dev)
+    dw = torch.zeros(fout, fin, device=dev)
+    fn = {"fwd": lambda: native.linear_fwd(x, w, None), "dgrad": lambda: native.linear_dgrad(dy, w),
+          "wgrad": lambda: native.linear_wgrad(dy, x, out=dw, accumulate=False)}[what]
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    print(name, what, native.last_plan())
+    sys.exit(0)
 ks, pad = (1, 0) if name in P else (3, 1)
 B, Cin, H, W, Cout = (P if name in P else L)[name]
 dev = torch.device("cuda:0")

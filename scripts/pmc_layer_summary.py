@@ -14,7 +14,7 @@ for f in sorted(glob.glob(os.path.join(out, "p*", "*counter_collection.csv"))):
             d[k][n].append(v)
 lines = []
 for k, c in d.items():
-    if not any(x in k for x in ("igemm", "wgrad", "gemm_glds", "wino")):
+    if not any(x in k for x in ("igemm", "wgrad", "gemm_glds", "gemm_x9", "wino")):
         continue
     lines.append("## %s  (%d launches, %.1f us)" % (k, len(c['_ns']), sum(c['_ns']) / len(c['_ns']) / 1e3))
     for n in sorted(c):

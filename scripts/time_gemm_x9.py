@@ -5,6 +5,9 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch
 from scda_amd import native
+if os.environ.get("SCDA_X9_LIB"):      # scripts/ablate/x9_ablate.sh: a timing build of the library
+    native.LIB_PATH = os.path.abspath(os.environ["SCDA_X9_LIB"])
+X9ONLY = len(sys.argv) > 1 and sys.argv[1] == "x9only"
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(0)
 R = 512
@@ -20,7 +23,7 @@ def timed(fn, n=20):
     return e0.elapsed_time(e1) / n
 
 
-for name, fin, fout in (("FC6", 25088, 4096), ("FC7", 4096, 4096)):
+for name, fin, fout in ((("FC6", 25088, 4096),) if X9ONLY else (("FC6", 25088, 4096), ("FC7", 4096, 4096))):
     x = torch.randn(R, fin, generator=g).clamp_min(0).to(dev)
     w = (torch.randn(fout, fin, generator=g) / fin ** 0.5).to(dev)
     dy = (torch.randn(R, fout, generator=g) / 100).to(dev)
@@ -30,7 +33,7 @@ for name, fin, fout in (("FC6", 25088, 4096), ("FC7", 4096, 4096)):
     refs = {"fwd": (xs @ ws.t(), xs.abs() @ ws.abs().t()),
             "dgrad": (dys[:128] @ w[:, :128].cpu().double(), dys[:128].abs() @ w[:, :128].cpu().double().abs()),
             "wgrad": (dys[:, :128].t() @ x[:, :128].cpu().double(), dys[:, :128].abs().t() @ x[:, :128].cpu().double().abs())}
-    for mode in ("0", "1"):
+    for mode in (("1",) if X9ONLY else ("0", "1")):
         os.environ["SCDA_GEMM_X9"] = mode
         outs = {"fwd": native.linear_fwd(x, w, None), "dgrad": native.linear_dgrad(dy, w), "wgrad": native.linear_wgrad(dy, x, out=dw, accumulate=False)}
         plans = {}
