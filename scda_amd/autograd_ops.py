@@ -12,12 +12,11 @@ from . import native as N
 ACT_NONE, ACT_RELU, ACT_LEAKY = N.ACT_NONE, N.ACT_RELU, N.ACT_LEAKY
 
 
-# Parity-test hook (tests/model_common.py: ReplaySource).  ReLU / LeakyReLU / max-pool / RoI max-pool are not differentiable
-# at ties: two correct fp32 implementations whose activations differ by 1e-7 route a gradient differently wherever a
-# pre-activation sits within round-off of zero.  With `replay` set, each of these ops asks the hook for the selection the
-# CPU oracle made at the same site (matched by the output's shape and L1 norm) and differentiates through THAT instead of
-# its own, so the gradient comparison measures the kernels' arithmetic, not tie-breaking.  None in production.
-replay = None
+# Parity tests (scda_amd/probe.py): with a Probe carrying a `replay` object installed, each op that makes a non-differentiable
+# selection -- ReLU / LeakyReLU sign masks, max-pool winners, RoI max-pool argmax -- asks it for the selection the CPU oracle made at
+# the same site (matched by the output's shape and L1 norm) and differentiates through THAT instead of its own, so the gradient
+# comparison measures the kernels' arithmetic, not tie-breaking.  _replay() is None outside a probed trainer step.
+from .probe import replay as _replay
 
 
 def _c(t):
@@ -26,8 +25,9 @@ def _c(t):
 
 def _mask_src(ctx, y, kind="act"):
     """tensor whose sign the backward's act' reads: y itself, or the oracle's selection when a replay hook is installed"""
-    if replay is not None and any(ctx.needs_input_grad):
-        return replay.act(y)
+    r = _replay()
+    if r is not None and any(ctx.needs_input_grad):
+        return r.act(y)
     return y
 
 
@@ -55,7 +55,7 @@ class Conv2dFn(Function):
             w = w.contiguous()
         # row_period: x is a vertical stack of independent maps of that many rows (channel-major RoI head, scda_ops.h)
         y = N.conv2d_fwd(x, w, b, stride, pad, act, slope, row_period=row_period)
-        in_act, defer = fuse if replay is None else (None, False)   # parity tests replay act masks: plain un-fused backward
+        in_act, defer = fuse if _replay() is None else (None, False)   # parity tests replay act masks: plain un-fused backward
         ctx.cfg = (stride, pad, act, slope, in_act, defer)
         ctx.row_period = row_period
         ctx.has_bias = b is not None
@@ -151,7 +151,7 @@ class LinearFn(Function):
         """defer: the consumer of y (a Dropout, see DropoutSeededFn) applies this layer's ReLU gradient"""
         x = _c(x); w = _c(w)
         y = N.linear_fwd(x, w, b, act)
-        defer = defer and replay is None
+        defer = defer and _replay() is None
         ctx.act = act if not defer else ACT_NONE
         ctx.has_bias = b is not None
         ctx.bias_ref, ctx.w_ref = b, w   # the Parameter objects themselves (they carry the flat-bucket gradient views)
@@ -187,9 +187,10 @@ class MaxPool2x2Fn(Function):
         """relu_input: x is the output of a ReLU whose owner defers its gradient to this pool's backward (fusion plan)"""
         x = _c(x)
         y, idx = N.maxpool2x2_fwd(x)
-        if replay is not None and any(ctx.needs_input_grad):
-            idx = replay.pool(y, idx)
-        fuse = relu_input and replay is None
+        r = _replay()
+        if r is not None and any(ctx.needs_input_grad):
+            idx = r.pool(y, idx)
+        fuse = relu_input and r is None
         ctx.save_for_backward(idx, y if fuse else None)
         ctx.xshape = tuple(x.shape)
         return y
@@ -324,8 +325,9 @@ class RoIPoolFn(Function):
         if not features.is_contiguous() or not rois.is_contiguous():
             raise AssertionError("RoIPool needs contiguous features and rois")  # roi_pool.py:25-26
         out, arg = N.roi_pool_fwd(features, rois, ph, pw, scale)
-        if replay is not None and any(ctx.needs_input_grad):
-            arg = replay.roi(out, arg)
+        r = _replay()
+        if r is not None and any(ctx.needs_input_grad):
+            arg = r.roi(out, arg)
         ctx.save_for_backward(rois, arg)
         ctx.cfg = (tuple(features.shape), ph, pw, scale)
         return out

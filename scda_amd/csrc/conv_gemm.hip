@@ -2378,6 +2378,9 @@ SCDA_API size_t scda_conv2d_workspace_bytes(int batch, int Cin, int IH, int IW, 
     return need > minimum ? need : minimum;
 }
 
+static int conv1x1_as_x9(const float *A, const float *B, float *C, int M, int N, int K, int lda, int ldb, int trans_a, int trans_b,
+                         const float *bias, int act, float slope, int accumulate, void *ws, size_t ws_bytes, hipStream_t st);
+
 SCDA_API int scda_conv2d_fwd_hip(const float *x, const float *w, const float *bias, float *y, int batch, int Cin, int IH,
                                  int IW, int Cout, int KH, int KW, int S, int P, int row_period_arg, int act, float slope, void *ws,
                                  size_t ws_bytes, void *stream) {
@@ -2394,6 +2397,10 @@ SCDA_API int scda_conv2d_fwd_hip(const float *x, const float *w, const float *bi
     g.slab_aligned = (Cin % BK) == 0;
     g.zp = zero_page();
     g.row_period = row_period;
+    if (batch == 1 && KH == 1 && KW == 1 && S == 1 && P == 0 && g.slab_aligned) {      // w is packed [Cin][mpad]: the GEMM's A stored [K][M]
+        const int rc = conv1x1_as_x9(w, x, y, Cout, IH * IW, Cin, conv_packed_mpad(Cout), IH * IW, 1, 1, bias, act, slope, 0, ws, ws_bytes, as_stream(stream));
+        if (rc <= 0) return rc;
+    }
     Epi e{y, nullptr, bias, 0, act, slope, 1, 0, nullptr, 0.f};
     if (KH == 7 && KW == 7 && S == 2)   // the ResNet stem (3 -> 64, frozen in the reference: models/mask_rcnn/resnet.py:230-238): forward only
         return launch_conv<7, 7, 2, false>(w, x, g, e, (float *)ws, ws_bytes, as_stream(stream));
@@ -2423,6 +2430,10 @@ SCDA_API int scda_conv2d_dgrad_act_hip(const float *dy, const float *wt, float *
     g.zp = zero_page();
     g.row_period = row_period;
     if (!g.zp) { set_error("scda_conv2d_dgrad_hip: could not allocate the zero page"); return SCDA_ELAUNCH; }
+    if (batch == 1 && KH == 1 && KW == 1 && S == 1 && P == 0 && g.slab_aligned && !act_src) {   // wt is packed [Cout][mpad(Cin)]
+        const int rc = conv1x1_as_x9(wt, dy, dx, Cin, IH * IW, Cout, conv_packed_mpad(Cin), IH * IW, 1, 1, nullptr, (int)ACT_NONE, 0.f, 0, ws, ws_bytes, as_stream(stream));
+        if (rc <= 0) return rc;
+    }
     Epi e{dx, nullptr, nullptr, 0, (int)ACT_NONE, 0.f, 1, 0, act_src, act_slope};
     CONV_DISPATCH(launch_conv, , true > (wt, dy, g, e, (float *)ws, ws_bytes, as_stream(stream)))
 }
@@ -2482,6 +2493,10 @@ SCDA_API int scda_conv2d_wgrad_hip(const float *dy, const float *x, float *dw, i
     g.zp = zero_page();
     g.row_period = row_period;
     if (!g.zp) { set_error("scda_conv2d_wgrad_hip: could not allocate the zero page"); return SCDA_ELAUNCH; }
+    if (batch == 1 && KH == 1 && KW == 1 && S == 1 && P == 0) {      // dW[Cout][Cin] (+)= dY[Cout][HW] X[Cin][HW]^T: both K-contiguous
+        const int rc = conv1x1_as_x9(dy, x, dw, Cout, Cin, IH * IW, IH * IW, IH * IW, 0, 0, nullptr, (int)ACT_NONE, 0.f, accumulate, ws, ws_bytes, as_stream(stream));
+        if (rc <= 0) return rc;
+    }
     CONV_DISPATCH(launch_wgrad, > (dy, x, g, dw, accumulate, (float *)ws, ws_bytes, as_stream(stream)))
 }
 
@@ -2579,6 +2594,31 @@ static int gemm_x9_launch(const float *A, const float *B, float *C, int M, int N
     return launch_dense_reduce((const float *)ws, splits, (long long)M * N, N, bias, bias_on_n, act, slope, accumulate, C, nullptr, nullptr, 0, 0, st);
 }
 
+// may this product run on the direct-to-LDS GEMM kernels (whole 16-deep slabs, 16-byte addressable rows, 32-bit lane offsets)?
+static bool gemm_glds_operands_ok(const float *A, const float *B, int M, int N, int K, int lda, int ldb, int trans_a, int trans_b) {
+    return (K % BK) == 0 && (lda % 4) == 0 && (ldb % 4) == 0 && ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0 &&
+           (!trans_a || (M % 4) == 0) && (!trans_b || (N % 4) == 0) && (long long)lda * 1024 + (long long)M * 4 < (1LL << 31) &&
+           (long long)ldb * 1024 + (long long)N * 4 < (1LL << 31);
+}
+
+// should it take the exact-product bf16 x 9 kernel?  SCDA_GEMM_X9: 0 never, 2 whatever its size (tests), default: the FC-sized ones
+static bool gemm_x9_wanted(int M, int N, int K) {
+    const char *x9_env = getenv("SCDA_GEMM_X9");      // (read per call: tests switch it)
+    const int x9_mode = x9_env ? atoi(x9_env) : 1;
+    return x9_mode == 2 || (x9_mode == 1 && M >= 256 && N >= 128 && K >= 256 && (double)M * N * K >= 4e9);
+}
+
+// A batch-1 1x1 convolution IS a dense GEMM on the NCHW tensors as they lie: Y[Cout][HW] = W[Cout][Cin] X[Cin][HW] (and its two
+// gradients likewise).  The ones that are large in every dimension -- the ResNet-50 C4 detector's layer3 / RoI-head bottlenecks
+// (models/mask_rcnn/resnet.py:111-148: 1024 <-> 512 <-> 2048 channels on 25088 stacked pixels) -- take the bf16 x 9 kernel; returns
+// +1 (not a status code) when the call is not one of them (the caller goes on to the convolution kernels).  SCDA_CONV1X1_X9=0 turns the routing off.
+static int conv1x1_as_x9(const float *A, const float *B, float *C, int M, int N, int K, int lda, int ldb, int trans_a, int trans_b,
+                         const float *bias, int act, float slope, int accumulate, void *ws, size_t ws_bytes, hipStream_t st) {
+    static const bool off = [] { const char *v = getenv("SCDA_CONV1X1_X9"); return v && atoi(v) == 0; }();
+    if (off || !ws || (((uintptr_t)C) & 15) || !gemm_glds_operands_ok(A, B, M, N, K, lda, ldb, trans_a, trans_b) || !gemm_x9_wanted(M, N, K)) return 1;
+    return gemm_x9_launch(A, B, C, M, N, K, lda, ldb, N, trans_a, trans_b, bias, 0, act, slope, accumulate, ws, ws_bytes, st);
+}
+
 // C[M][N] (ldc) = op(A) op(B) (+bias) -> act ; trans_a: A stored [K][M]; trans_b: B stored [K][N]
 SCDA_API int scda_gemm_hip(const float *A, const float *B, float *C, int M, int N, int K, int lda, int ldb, int ldc,
                            int trans_a, int trans_b, const float *bias, int bias_on_n, int act, float slope,
@@ -2588,14 +2628,9 @@ SCDA_API int scda_gemm_hip(const float *A, const float *B, float *C, int M, int 
     // direct-to-LDS kernel: whole 16-deep slabs, 16-byte addressable rows
     static const bool no_glds = getenv("SCDA_GEMM_NO_GLDS") != nullptr;   // A/B knob
     // (+ 32-bit lane offsets inside a descriptor: 256 rows of either operand stay below 2 GB)
-    const bool glds = !no_glds && (K % BK) == 0 && (lda % 4) == 0 && (ldb % 4) == 0 && ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0 &&
-                      (!trans_a || (M % 4) == 0) && (!trans_b || (N % 4) == 0) && (long long)lda * 1024 + (long long)M * 4 < (1LL << 31) &&
-                      (long long)ldb * 1024 + (long long)N * 4 < (1LL << 31);
+    const bool glds = !no_glds && gemm_glds_operands_ok(A, B, M, N, K, lda, ldb, trans_a, trans_b);
     // exact-product bf16 x 9 form (gemm_x9_kernel): the FC-sized products; SCDA_GEMM_X9=0 keeps them on the fp32 MFMA
-    // (=2: every product the direct-to-LDS path can take, whatever its size -- tests.  Read per call: tests switch it.)
-    const char *x9_env = getenv("SCDA_GEMM_X9");
-    const int x9_mode = x9_env ? atoi(x9_env) : 1;
-    if (glds && (x9_mode == 2 || (x9_mode == 1 && M >= 256 && N >= 128 && K >= 256 && (double)M * N * K >= 4e9)))
+    if (glds && gemm_x9_wanted(M, N, K))
         return gemm_x9_launch(A, B, C, M, N, K, lda, ldb, ldc, trans_a, trans_b, bias, bias_on_n, act, slope, accumulate, ws, ws_bytes, st);
     const char *fbm = getenv("SCDA_CONV_BM");                              // 256 forces the 8-wave tile where legal
     // (not for the [K][M] x [K][N] form -- the FC weight gradient: measured 112 vs 115 TFLOP/s)

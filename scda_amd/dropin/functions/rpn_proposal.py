@@ -9,12 +9,12 @@ from scda_amd.dropin import backend
 from scda_amd.dropin.utils import anchor_helper, bbox_helper
 
 
-# Parity-test hook: callable(conv_cls, conv_loc) -> (conv_cls, conv_loc), None in production.  The ranking below is a
+# Parity tests (scda_amd/probe.py `rpn_output`: callable(conv_cls, conv_loc) -> (conv_cls, conv_loc)).  The ranking below is a
 # discontinuous function of the scores: among 30720 fp32 soft-max outputs some pairs sit closer than the 1e-6 by which two
 # correct implementations differ, and ONE swapped pair changes which RoIs get sampled downstream.  The full-size parity test
-# records the CPU oracle's RPN outputs here and hands them to the device run (after asserting agreement to 1e-5), so that
-# everything after this point is compared on identical discrete decisions (tests/model_common.py).
-rpn_output_hook = None
+# records the CPU oracle's RPN outputs and hands them to the device run here (after asserting agreement to 1e-5), so that
+# everything after this point is compared on identical discrete decisions (tests/model_common.py).  None outside a probed step.
+from scda_amd.probe import rpn_output as _probe_rpn_output
 
 
 def compute_rpn_proposals(conv_cls, conv_loc, cfg, image_info):
@@ -24,9 +24,10 @@ def compute_rpn_proposals(conv_cls, conv_loc, cfg, image_info):
     cls_host = loc_host = None
     if host is not None:
         cls_host, loc_host = host()
-    if rpn_output_hook is not None:
+    hook = _probe_rpn_output()
+    if hook is not None:
         dev = conv_loc.device
-        cls_host, loc_host = rpn_output_hook(cls_host if cls_host is not None else conv_cls,
+        cls_host, loc_host = hook(cls_host if cls_host is not None else conv_cls,
                                              loc_host if loc_host is not None else conv_loc)
         if cls_host.is_cuda:
             cls_host = loc_host = None

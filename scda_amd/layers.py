@@ -14,6 +14,7 @@ import torch.nn as nn
 
 from . import autograd_ops as A
 from . import native as N
+from . import probe as P
 
 
 class Conv2d(nn.Conv2d):
@@ -61,7 +62,7 @@ class Conv2d(nn.Conv2d):
         pool = self._my_pool() if self.pool_next else None
         if pool is not None:
             pool._pooled_shape = None        # (an announcement left behind by a call that raised between this conv and its pool)
-        if pool is not None and A.replay is None and self.fused_act == A.ACT_RELU and self.defer_act_bwd:
+        if pool is not None and P.replay() is None and self.fused_act == A.ACT_RELU and self.defer_act_bwd:
             B, Cin, IH, IW = x.shape
             if x.is_cuda and N.conv_pool_fusable(B, Cin, IH, IW, self.out_channels, self.kernel_size[0], self.kernel_size[1],
                                                  self.stride[0], self.padding[0], self.row_period):
@@ -184,9 +185,9 @@ class Activation(nn.Module):
 class Dropout(nn.Module):
     """nn.Dropout(p).  The keep-mask comes from the library's counter-based generator; its 64-bit seed is drawn from
     torch's CPU generator, so runs are reproducible under torch.manual_seed() and resumable through torch.get_rng_state().
-    Tests inject masks through `mask_source` so that the CPU oracle and the device see the same Bernoulli draws."""
+    Parity tests hand over masks through a Probe (scda_amd/probe.py: `dropout_masks`, callable(shape, p, device) -> uint8 mask) so that
+    the CPU oracle and the device see the same Bernoulli draws."""
 
-    mask_source = None  # callable(shape, p, device) -> uint8 mask, or None
     relu_input = False  # fusion plan: the backward also applies the ReLU gradient of the Linear in front (eval mode: see forward)
 
     def __init__(self, p=0.5):
@@ -194,12 +195,13 @@ class Dropout(nn.Module):
         self.p = float(p)
 
     def forward(self, x):
-        fused = self.relu_input and A.replay is None
+        fused = self.relu_input and P.replay() is None
         if not self.training or self.p == 0.0:
             # identity -- but a producer that deferred its ReLU gradient to us still needs it applied
             return A.ActFn.apply(x, N.ACT_MODE["relu"], 0.0) if fused and torch.is_grad_enabled() and x.requires_grad else x
-        if Dropout.mask_source is not None:
-            mask = Dropout.mask_source(tuple(x.shape), self.p, x.device)
+        masks = P.dropout_masks()
+        if masks is not None:
+            mask = masks(tuple(x.shape), self.p, x.device)
             if fused:   # replayed masks (parity tests of the FUSED path): explicit mask, ReLU gradient through a no-op ReLU
                 x = A.ActFn.apply(x, N.ACT_MODE["relu"], 0.0)
             return A.DropoutFn.apply(x, mask, 1.0 / (1.0 - self.p))
@@ -255,7 +257,7 @@ class InstanceNorm2d(nn.Module):
         self.slope = slope
 
     def forward(self, x):
-        if A.replay is not None and self.fused_act != A.ACT_NONE:   # parity tests: activation un-fused so its mask can be replayed
+        if P.replay() is not None and self.fused_act != A.ACT_NONE:   # parity tests: activation un-fused so its mask can be replayed
             y = A.InstanceNormFn.apply(x, self.eps, A.ACT_NONE, self.slope)
             return A.ActFn.apply(y, 0 if self.fused_act == A.ACT_RELU else 1, self.slope)
         return A.InstanceNormFn.apply(x, self.eps, self.fused_act, self.slope)
@@ -279,7 +281,7 @@ class BatchNorm2d(nn.BatchNorm2d):
             raise NotImplementedError("scda_amd.BatchNorm2d: momentum=None (cumulative average) is not implemented")
         if self.num_batches_tracked is not None:
             self._nbt_pending = getattr(self, "_nbt_pending", 0) + 1    # counted on the host, written into the buffer when it is read
-        if A.replay is not None and self.fused_act != A.ACT_NONE:   # parity tests: see InstanceNorm2d
+        if P.replay() is not None and self.fused_act != A.ACT_NONE:   # parity tests: see InstanceNorm2d
             y = A.BatchNormTrainFn.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
                                          self.momentum, A.ACT_NONE, self.slope)
             return A.ActFn.apply(y, 0 if self.fused_act == A.ACT_RELU else 1, self.slope)
@@ -291,7 +293,7 @@ class BatchNorm2d(nn.BatchNorm2d):
         """relu(self(x) + residual) -- the residual join of a ResNet block.  One kernel in training mode on the maps the plane form
         serves (batch 1); the batch norm followed by the join kernel otherwise (eval mode, other shapes, a fused activation of its
         own, the parity tests' replay hook: they replay the join's mask)."""
-        if (self.training and self.fused_act == A.ACT_NONE and A.replay is None and self.momentum is not None and x.dim() == 4
+        if (self.training and self.fused_act == A.ACT_NONE and P.replay() is None and self.momentum is not None and x.dim() == 4
                 and x.shape == residual.shape and N.batchnorm_add_relu_ok(x) and x.is_contiguous() and residual.is_contiguous()
                 and N.aligned16(x, residual) and not os.environ.get("SCDA_BN_NO_JOIN")):
             if self.num_batches_tracked is not None:

@@ -22,6 +22,7 @@ import torch.distributed as dist
 
 from . import autograd_ops as A
 from . import native as N
+from . import probe as P
 from .flat import FlatAdam, FlatParams
 from ._timing import mark
 from .dropin.models.faster_rcnn.faster_rcnn_adver_expansion_reweight_cluster import (GAN_decoder_AE, GAN_dis_AE,
@@ -125,20 +126,6 @@ class _Frozen:
     def __exit__(self, *a):
         for p in self.params:
             p.requires_grad_(True)
-
-
-def active_test_hooks(fail=False):
-    """The parity tests steer three module-level hooks of the product path (selection replay in scda_amd.autograd_ops, the RPN-output
-    hand-over in dropin.functions.rpn_proposal, injected dropout masks in scda_amd.layers).  -> names of those that are set.  A
-    trainer refuses to start with a stale one (left behind by an earlier user of the process) unless SCDA_ALLOW_TEST_HOOKS=1
-    (tests/conftest.py sets it and checks after every test that none is left behind)."""
-    from . import layers as L
-    from .dropin.functions import rpn_proposal
-    on = [n for n, v in (("scda_amd.autograd_ops.replay", A.replay), ("dropin.functions.rpn_proposal.rpn_output_hook",
-                         rpn_proposal.rpn_output_hook), ("scda_amd.layers.Dropout.mask_source", L.Dropout.mask_source)) if v is not None]
-    if on and fail:
-        raise RuntimeError("test hooks are installed in the product path: %s (set SCDA_ALLOW_TEST_HOOKS=1 if that is intended)" % ", ".join(on))
-    return on
 
 
 class _GanGraphs:
@@ -258,7 +245,7 @@ class _recording:
 
 class ScdaTrainer:
     def __init__(self, cfg, device, lr=1.25e-5, cluster_num=4, threshold=128, recon_size=256, new_w=1024, new_h=512,
-                 weight_decay=1e-4, world_size=1, models=None, recon_hw=None, reference_style=False, collectives=None):
+                 weight_decay=1e-4, world_size=1, models=None, recon_hw=None, reference_style=False, collectives=None, probe=None):
         """recon_hw: (height, width) of the reconstructions / image crops when they are not recon_size x recon_size (a
         detector whose RoI feature does not unfold to a square map: see scda_amd/resnet_config.py).
         reference_style: run the iteration the way the reference's own driver would on top of the drop-in modules -- four
@@ -269,7 +256,9 @@ class ScdaTrainer:
         collectives: issue the four per-phase all-reduces (default: world_size > 1).  True with a one-rank process group runs
         the whole RCCL path -- async all-reduce on the device buckets, waits, stream hand-over -- on a single GPU
         (tests/test_distributed_gpu.py::test_rccl_one_rank_group_matches_plain_step)."""
-        active_test_hooks(fail=os.environ.get("SCDA_ALLOW_TEST_HOOKS") != "1")
+        # parity tests: a scda_amd.probe.Probe (replayed selections / RPN outputs / dropout masks of the CPU oracle), visible to the
+        # product's modules while THIS trainer's step() runs and at no other time; None in production
+        self.probe = probe
         self.cfg, self.device = cfg, device
         self.collectives = (world_size > 1) if collectives is None else bool(collectives)
         self.early_reduces = 0      # all-reduces launched from inside a detector backward (SegmentedReduce) so far
@@ -490,7 +479,7 @@ class ScdaTrainer:
             # 27.6 ms per iteration with the graphs, 19.7 without, 19.4 without collectives) -- data-parallel runs stay eager
             return False
         if not (os.environ.get("SCDA_GAN_GRAPH", "1") != "0" and self.device.type == "cuda" and not self.capture and self.early_backward
-                and A.replay is None and L.Dropout.mask_source is None and self.flat):
+                and not P.active() and self.flat):
             return False
         ok = getattr(self, "_graphable_nets", None)
         if ok is None:
@@ -519,6 +508,10 @@ class ScdaTrainer:
     def step(self, image, gts, image_info, target, gt_masks=None):
         """image/target [1,3,H,W] on the device; gts [1,G,5]; image_info [1,3]; gt_masks [1,G,H,W] binary (detectors with a mask
         branch, BASELINE configs[4]) -> dict of 0-dim loss tensors"""
+        with P.installed(self.probe):
+            return self._step(image, gts, image_info, target, gt_masks)
+
+    def _step(self, image, gts, image_info, target, gt_masks=None):
         dev, ws, C = self.device, float(self.world_size), self.cluster_num
         x = {'cfg': self.cfg, 'image': image, 'image_info': image_info, 'ground_truth_bboxes': gts,
              'ignore_regions': None, 'cluster_num': self.cluster_num, 'threshold': self.threshold}

@@ -15,7 +15,7 @@ torch.manual_seed(1)
 tr = ScdaTrainer(mc.CFG, dev, lr=1e-3, new_w=W, new_h=H, models=mc.seeded_models(build_product))
 src, tgt, gts, info = mc.seeded_inputs(H, W)
 tape = list(masks)
-L.Dropout.mask_source = lambda shape, p, device: tape.pop(0).to(device)
+tr.probe = mc.Probe(dropout_masks=lambda shape, p, device: tape.pop(0).to(device))
 grabbed = {}
 orig = tr.model.forward
 def fwd(x, target):
@@ -26,7 +26,7 @@ tr.model.forward = fwd
 np.random.seed(mc.SEEDS['numpy'])
 out = tr.step(src.to(dev), gts, info, tgt.to(dev))
 torch.cuda.synchronize()
-L.Dropout.mask_source = None
+tr.probe = None
 po = grabbed
 p_ref, p_got = ro['predict'][0].numpy(), po['predict'][0].cpu().numpy()
 print("source proposals", p_ref.shape, p_got.shape, "boxes equal:", np.array_equal(p_ref[:, :5], p_got[:, :5]) if p_ref.shape == p_got.shape else None)

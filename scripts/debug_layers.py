@@ -43,7 +43,7 @@ for n, (oi, pi) in WATCH.items():
     pmodels[0].features[pi].register_forward_hook(hook("p", n))
 ptr = ScdaTrainer(mc.CFG, cuda, lr=lr, new_w=W, new_h=H, models=pmodels)
 tape = list(masks)
-L.Dropout.mask_source = lambda shape, p, device: tape.pop(0).to(device)
+ptr.probe = mc.Probe(dropout_masks=lambda shape, p, device: tape.pop(0).to(device))
 np.random.seed(mc.SEEDS['numpy'])
 ptr.step(src.to(cuda), gts, info, tgt.to(cuda))
 for n in WATCH:

@@ -17,7 +17,7 @@ tr = ScdaTrainer(mc.CFG, cuda, lr=lr, new_w=W, new_h=H, models=models); tr.captu
 src, tgt, gts, info = mc.seeded_inputs(H, W)
 tape = list(masks)
 print("mask shapes:", [tuple(m.shape) for m in masks])
-L.Dropout.mask_source = lambda shape, p, device: tape.pop(0).to(device)
+tr.probe = mc.Probe(dropout_masks=lambda shape, p, device: tape.pop(0).to(device))
 np.random.seed(mc.SEEDS['numpy'])
 out = tr.step(src.to(cuda), gts, info, tgt.to(cuda))
 for name in ('dis', 'dis_patch', 'dec', 'det'):

@@ -8,7 +8,6 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-os.environ["SCDA_ALLOW_TEST_HOOKS"] = "1"     # the parity tests steer the product path's three test hooks (train_step.active_test_hooks)
 
 
 def pytest_configure(config):
@@ -29,10 +28,9 @@ def cuda():
 
 
 @pytest.fixture(autouse=True)
-def no_test_hook_left_behind():
-    """a hook one test forgets to clear would silently change every later test of the process"""
+def no_probe_left_behind():
+    """scda_amd.probe only ever exposes a Probe inside a trainer step or a with-block: nothing can be left behind -- checked anyway"""
     yield
     import sys
-    if "scda_amd.train_step" in sys.modules:
-        left = sys.modules["scda_amd.train_step"].active_test_hooks()
-        assert not left, "test left product-path hooks installed: %s" % left
+    if "scda_amd.probe" in sys.modules:
+        assert not sys.modules["scda_amd.probe"].active(), "a scda_amd.probe.Probe is still installed after the test"

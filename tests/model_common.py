@@ -1,4 +1,5 @@
 """shared set-up for the model-level tests (oracle on CPU, product on the GPU)"""
+import contextlib
 import os
 import sys
 
@@ -11,6 +12,25 @@ import seeded_init as si  # noqa: E402
 from test_host_functions import CFG  # noqa: E402
 
 SEEDS = dict(det=11, dec=12, dis=13, dis_patch=14, images=21, gts=22, torch=31, numpy=32)
+
+
+def _probe_mod():
+    from scda_amd import probe
+    return probe
+
+
+def Probe(**kw):
+    """scda_amd.probe.Probe(replay=, rpn_output=, dropout_masks=): hand it to ScdaTrainer(probe=...) / trainer.probe"""
+    return _probe_mod().Probe(**kw)
+
+
+@contextlib.contextmanager
+def probed(dropout_masks=None, replay=None, rpn_output=None):
+    """the oracle's discrete decisions visible to the product's modules inside the with-block (for code that drives modules or a
+    trainer without a probe of its own)"""
+    P = _probe_mod()
+    with P.installed(P.Probe(replay=replay, rpn_output=rpn_output, dropout_masks=dropout_masks)) as p:
+        yield p
 
 
 def check_losses(out, ref, keys, rel, tag):
@@ -54,7 +74,7 @@ def seeded_inputs(H, W, G=6, sample=0):
 
 
 class ReplaySource:
-    """scda_amd.autograd_ops.replay hook: hands the device ops the selections the CPU oracle made at the same site
+    """the `replay` object of a scda_amd.probe.Probe: hands the device ops the selections the CPU oracle made at the same site
     (oracle.torch_ref.SelectionRecorder), matched by the output's kind, shape and three moments (relative 1e-4; the two
     implementations agree to ~1e-6, distinct call sites of one shape differ by far more)."""
 
@@ -110,21 +130,19 @@ def oracle_iteration(H, W, lr=1e-3, record_masks=False, capture=False, cfg=None,
         R.RecordingDropout.tape = [] if record_masks else None
         rec = R.SelectionRecorder() if record_selections else None
         handles = rec.attach(*models) if rec else None
-        from scda_amd.dropin.functions import rpn_proposal
-        if rec:
-            def record_rpn(cls, loc):
-                rec.add("rpn_cls", cls, cls.detach().clone())
-                rec.add("rpn_loc", loc, loc.detach().clone())
-                return cls, loc
-            rpn_proposal.rpn_output_hook = record_rpn
+        def record_rpn(cls, loc):       # the oracle's RPN outputs on their way into the (shared) proposal ranking
+            rec.add("rpn_cls", cls, cls.detach().clone())
+            rec.add("rpn_loc", loc, loc.detach().clone())
+            return cls, loc
         torch.manual_seed(SEEDS['torch'])
         np.random.seed(SEEDS['numpy'])
-        res = tr.step(src, gts, info, tgt)
-        res['_lr'] = tr.opt.param_groups[0]['lr']
-        history = [res]
-        for _ in range(steps - 1):          # same inputs again; RNG streams simply continue
-            history.append(tr.step(src, gts, info, tgt))
-            history[-1]['_lr'] = tr.opt.param_groups[0]['lr']
+        with probed(rpn_output=record_rpn) if rec else contextlib.nullcontext():
+            res = tr.step(src, gts, info, tgt)
+            res['_lr'] = tr.opt.param_groups[0]['lr']
+            history = [res]
+            for _ in range(steps - 1):          # same inputs again; RNG streams simply continue
+                history.append(tr.step(src, gts, info, tgt))
+                history[-1]['_lr'] = tr.opt.param_groups[0]['lr']
         if steps > 1:
             res = dict(history[-1], _history=history)
         masks = R.RecordingDropout.tape
@@ -135,6 +153,5 @@ def oracle_iteration(H, W, lr=1e-3, record_masks=False, capture=False, cfg=None,
     finally:
         R.reset_backend()
         R.SelectionRecorder.active = None
-        rpn_proposal.rpn_output_hook = None
     res['_trace'] = tr.trace
     return res, models, masks

@@ -118,12 +118,11 @@ def _grad_worker(rank, world, port, out_dir):
     tr.capture = True
     src, tgt, gts, info = mc.seeded_inputs(H, W, sample=rank)
     tape = torch.load(os.path.join(out_dir, "masks%d.pt" % rank))
-    L.Dropout.mask_source = lambda shape, p, device: tape.pop(0).to(device)
-    # identical proposal ranking on both sides (scda_amd/dropin/functions/rpn_proposal.py: rpn_output_hook)
+    # the oracle's dropout masks, and an identical proposal ranking on both sides (scda_amd/probe.py: rpn_output), through the trainer
     import types
-    from scda_amd.dropin.functions import rpn_proposal
     rec = types.SimpleNamespace(records=torch.load(os.path.join(out_dir, "rpn%d.pt" % rank)))
-    rpn_proposal.rpn_output_hook = mc.ReplaySource(rec, torch.device("cpu")).rpn
+    tr.probe = mc.Probe(dropout_masks=lambda shape, p, device: tape.pop(0).to(device),
+                        rpn_output=mc.ReplaySource(rec, torch.device("cpu")).rpn)
     np.random.seed(mc.SEEDS['numpy'])
     out = tr.step(src.to(dev), gts, info, tgt.to(dev))
     torch.cuda.synchronize()

@@ -75,15 +75,11 @@ def test_scda_nets_on_rectangular_maps_match_oracle(cuda):
         si.seeded_reinit(m, seed, 'gan')
         assert sorted(m.state_dict()) == sorted(r.state_dict())
         m.to(cuda).train()
-    L.Dropout.mask_source = lambda shape, p, device: tape.pop(0).to(device)
-    A.replay = mc.ReplaySource(rec, cuda)
-    try:
+    rp = mc.ReplaySource(rec, cuda)
+    with mc.probed(dropout_masks=lambda shape, p, device: tape.pop(0).to(device), replay=rp):
         got = run(dec, dis, dis_patch, cuda)
         torch.cuda.synchronize()
-        used = A.replay.used
-    finally:
-        L.Dropout.mask_source = None
-        A.replay = None
+        used = rp.used
     assert not tape and used >= 20, (len(tape), used)
     for k in want:
         assert rel_l2(got[k], want[k]) <= 1e-4, (k, rel_l2(got[k], want[k]))

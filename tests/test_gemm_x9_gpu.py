@@ -140,3 +140,45 @@ def test_fc_sized_products_take_the_x9_kernel_by_default(cuda, monkeypatch):
     wh = (torch.randn(36, 4096, generator=g) / 64).to(cuda)
     native.linear_fwd(x, wh, None)
     assert native.last_plan()[3] != 2
+
+
+@pytest.mark.parametrize("case", [(512, 1024, 448, 7), (1024, 512, 448, 7), (256, 1024, 50, 84), (2048, 512, 98, 7)])
+def test_batch1_1x1_convolutions_route_to_the_x9_gemm(cuda, case, monkeypatch):
+    """a batch-1 1x1 convolution is a dense GEMM on the NCHW tensors as they lie (csrc/conv_gemm.hip conv1x1_as_x9: the ResNet-50 C4
+    detector's layer3 / RoI-head bottlenecks, models/mask_rcnn/resnet.py:111-148): forward (+ bias + ReLU), data gradient and weight
+    gradient (overwrite and accumulate) through the convolution entry points against torch's conv2d on the CPU, and the routing is
+    really taken (forced here on shapes below the size threshold; 50 x 84 planes are not a multiple of 16: their weight gradient stays
+    on the convolution kernel)"""
+    import torch.nn.functional as F
+    from scda_amd import native
+    Cin, Cout, H, W = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(1, Cin, H, W, generator=g).clamp_min(0)
+    w = (torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5).requires_grad_()
+    b = torch.randn(Cout, generator=g)
+    dy = torch.randn(1, Cout, H, W, generator=g)
+    xr = x.clone().requires_grad_()
+    yr = F.conv2d(xr, w, b)
+    yr.backward(dy)
+    monkeypatch.setenv("SCDA_GEMM_X9", "2")
+    xd, wd, dyd = x.to(cuda), w.detach().to(cuda), dy.to(cuda)
+
+    def close(a, ref, tol=2e-5):
+        err = (a.cpu().double() - ref.double()).abs().max() / ref.double().abs().max()
+        assert err < tol, float(err)
+    y = native.conv2d_fwd(xd, wd, b.to(cuda), 1, 0, native.ACT_RELU)
+    assert native.last_plan()[3] == 2, native.last_plan()
+    close(y, F.relu(yr.detach()))
+    dx = native.conv2d_dgrad(dyd, wd, tuple(x.shape), 1, 0)
+    assert native.last_plan()[3] == 2, native.last_plan()
+    close(dx, xr.grad)
+    dw = native.conv2d_wgrad(dyd, xd, tuple(w.shape), 1, 0)
+    assert (native.last_plan()[3] == 2) == ((H * W) % 16 == 0), native.last_plan()
+    close(dw, w.grad)
+    acc = torch.ones(Cout, Cin, 1, 1, device=cuda)
+    native.conv2d_wgrad(dyd, xd, tuple(w.shape), 1, 0, out=acc)
+    close(acc - 1.0, w.grad)
+    monkeypatch.setenv("SCDA_GEMM_X9", "0")
+    y0 = native.conv2d_fwd(xd, wd, b.to(cuda), 1, 0, native.ACT_RELU)
+    assert native.last_plan()[3] != 2
+    close(y, y0.cpu())

@@ -217,7 +217,6 @@ FULL_ITERS = 400      # mAP 54 on the held-out set (300: 30, 200: 20 -- scripts:
 
 if __name__ == "__main__":
     import tempfile
-    os.environ.setdefault("SCDA_ALLOW_TEST_HOOKS", "1")
     it = int(sys.argv[1]) if len(sys.argv) > 1 else 400
     lr = float(sys.argv[2]) if len(sys.argv) > 2 else 1e-4
     ev = int(sys.argv[3]) if len(sys.argv) > 3 else None

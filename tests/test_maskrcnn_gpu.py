@@ -39,7 +39,6 @@ def test_mask_detector_losses_and_gradients_match_oracle(cuda):
     from oracle import resnet_ref as RR, torch_ref as R
     from scda_amd import autograd_ops as A
     from scda_amd import resnet_config as RC
-    from scda_amd.dropin.functions import rpn_proposal
     from scda_amd.dropin.models.mask_rcnn.resnet import resnet50
     import seeded_init
     H, W, G = 256, 384, 4
@@ -66,14 +65,13 @@ def test_mask_detector_losses_and_gradients_match_oracle(cuda):
         rec.add("rpn_loc", loc, loc.detach().clone())
         return cls, loc
     R.use_cpu_backend()
-    rpn_proposal.rpn_output_hook = record_rpn
     try:
-        np.random.seed(7)
-        torch.set_num_threads(16)
-        want = ref(inputs(), tgt)
-        sum(want['losses']).backward()
+        with mc.probed(rpn_output=record_rpn):
+            np.random.seed(7)
+            torch.set_num_threads(16)
+            want = ref(inputs(), tgt)
+            sum(want['losses']).backward()
     finally:
-        rpn_proposal.rpn_output_hook = None
         rec.detach(handles)
         R.reset_backend()
         torch.set_num_threads(1)
@@ -84,16 +82,12 @@ def test_mask_detector_losses_and_gradients_match_oracle(cuda):
     det = det.to(cuda).train()
     det.tall_head = False              # replayed selections are keyed by output shape (see tests/test_resnet_oracle_gpu.py)
     assert sorted(k for k in det.state_dict() if k.startswith('mask_head')) == sorted(k for k in ref.state_dict() if k.startswith('mask_head'))
-    A.replay = mc.ReplaySource(rec, cuda)
-    rpn_proposal.rpn_output_hook = A.replay.rpn
-    try:
+    rsrc = mc.ReplaySource(rec, cuda)
+    with mc.probed(replay=rsrc, rpn_output=rsrc.rpn):
         np.random.seed(7)
         got = det(inputs(cuda), tgt.to(cuda))
         sum(got['losses']).backward()
         torch.cuda.synchronize()
-    finally:
-        A.replay = None
-        rpn_proposal.rpn_output_hook = None
     assert det.last_mask_rois == ref.last_mask_rois >= 4, (det.last_mask_rois, ref.last_mask_rois)
     for name, a, b in zip(("rpn_cls", "rpn_loc", "rcnn_cls", "rcnn_loc", "mask"), got['losses'], want['losses']):
         assert abs(float(a) - float(b)) <= 1e-4 * max(1.0, abs(float(b))), (name, float(a), float(b))

@@ -41,7 +41,6 @@ def rel_l2(a, b):
 def test_resnet_detector_losses_and_gradients_match_oracle(cuda, H, W, G):
     from oracle import resnet_ref as RR, torch_ref as R
     from scda_amd import autograd_ops as A
-    from scda_amd.dropin.functions import rpn_proposal
     from scda_amd.dropin.models.mask_rcnn.resnet import resnet50
     import seeded_init
     torch.manual_seed(1)
@@ -65,14 +64,13 @@ def test_resnet_detector_losses_and_gradients_match_oracle(cuda, H, W, G):
         rec.add("rpn_loc", loc, loc.detach().clone())
         return cls, loc
     R.use_cpu_backend()
-    rpn_proposal.rpn_output_hook = record_rpn
     try:
-        np.random.seed(7)
-        torch.set_num_threads(16)
-        want = ref(inputs(), tgt)
-        sum(want['losses']).backward()
+        with mc.probed(rpn_output=record_rpn):
+            np.random.seed(7)
+            torch.set_num_threads(16)
+            want = ref(inputs(), tgt)
+            sum(want['losses']).backward()
     finally:
-        rpn_proposal.rpn_output_hook = None
         rec.detach(handles)
         R.reset_backend()
         torch.set_num_threads(1)
@@ -86,17 +84,13 @@ def test_resnet_detector_losses_and_gradients_match_oracle(cuda, H, W, G):
     # the product runs by default is compared with THIS layout tensor by tensor in tests/test_resnet_gpu.py
     # (test_channel_major_roi_head_equals_reference_layout).
     det.tall_head = False
-    A.replay = mc.ReplaySource(rec, cuda)
-    rpn_proposal.rpn_output_hook = A.replay.rpn
-    try:
+    rsrc = mc.ReplaySource(rec, cuda)
+    with mc.probed(replay=rsrc, rpn_output=rsrc.rpn):
         np.random.seed(7)
         got = det(inputs(cuda), tgt.to(cuda))
         sum(got['losses']).backward()
         torch.cuda.synchronize()
-        used = A.replay.used
-    finally:
-        A.replay = None
-        rpn_proposal.rpn_output_hook = None
+        used = rsrc.used
     assert used >= 30, used
     for name, a, b in zip(("rpn_cls", "rpn_loc", "rcnn_cls", "rcnn_loc"), got['losses'], want['losses']):
         assert abs(float(a) - float(b)) <= 1e-4 * max(1.0, abs(float(b))), (name, float(a), float(b))

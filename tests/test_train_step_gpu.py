@@ -49,13 +49,10 @@ def test_few_target_proposals_fall_back_to_source_clusters(cuda):
     tr = ScdaTrainer(cfg, cuda, lr=lr, new_w=W, new_h=H, models=mc.seeded_models(build_product))
     src, tgt, gts, info = mc.seeded_inputs(H, W)
     tape = list(masks)
-    L.Dropout.mask_source = lambda shape, p, device: tape.pop(0).to(device)
-    try:
+    with mc.probed(dropout_masks=lambda shape, p, device: tape.pop(0).to(device)):
         np.random.seed(mc.SEEDS['numpy'])
         out = tr.step(src.to(cuda), gts, info, tgt.to(cuda))
         torch.cuda.synchronize()
-    finally:
-        L.Dropout.mask_source = None
     assert not tape
     mc.check_losses(out, ref, LOSS_KEYS, LOSS_REL, "few_target_proposals[256x512]")
 
@@ -76,13 +73,10 @@ def test_two_iterations_track_oracle(cuda):
     src, tgt, gts, info = mc.seeded_inputs(H, W)
     src, tgt = src.to(cuda), tgt.to(cuda)
     tape = list(masks)
-    L.Dropout.mask_source = lambda shape, p, device: tape.pop(0).to(device)
-    try:
+    with mc.probed(dropout_masks=lambda shape, p, device: tape.pop(0).to(device)):
         np.random.seed(mc.SEEDS['numpy'])
         outs = [tr.step(src, gts, info, tgt) for _ in range(2)]
         torch.cuda.synchronize()
-    finally:
-        L.Dropout.mask_source = None
     assert not tape
     for i, (out, want) in enumerate(zip(outs, ref['_history'])):
         for k in LOSS_KEYS:
@@ -107,16 +101,13 @@ def test_three_warmup_iterations_track_oracle(cuda):
     src, tgt, gts, info = mc.seeded_inputs(H, W)
     src, tgt = src.to(cuda), tgt.to(cuda)
     tape = list(masks)
-    L.Dropout.mask_source = lambda shape, p, device: tape.pop(0).to(device)
     outs, lrs = [], []
-    try:
+    with mc.probed(dropout_masks=lambda shape, p, device: tape.pop(0).to(device)):
         np.random.seed(mc.SEEDS['numpy'])
         for _ in range(3):
             outs.append(tr.step(src, gts, info, tgt))
             lrs.append([o.param_groups[0]['lr'] for o in tr.opt.values()])
         torch.cuda.synchronize()
-    finally:
-        L.Dropout.mask_source = None
     assert not tape
     for i, want in enumerate(ref['_history']):
         assert all(abs(v - want['_lr']) <= 1e-12 * want['_lr'] for v in lrs[i]), (i, lrs[i], want['_lr'])
@@ -152,13 +143,10 @@ def test_iteration_matches_oracle(cuda):
         assert tuple(m.shape) == tuple(shape), (m.shape, shape)
         return m.to(device)
 
-    L.Dropout.mask_source = replay
-    try:
+    with mc.probed(dropout_masks=replay):
         np.random.seed(mc.SEEDS['numpy'])
         out = tr.step(src.to(cuda), gts, info, tgt.to(cuda))
         torch.cuda.synchronize()
-    finally:
-        L.Dropout.mask_source = None
     assert not tape, "the device consumed fewer dropout masks than the oracle drew"
 
     mc.check_losses(out, ref, LOSS_KEYS, LOSS_REL, "iteration_matches_oracle[256x512]")
@@ -210,7 +198,7 @@ def test_iteration_matches_oracle(cuda):
 @pytest.mark.parametrize("H,W", [(256, 512), (512, 1024)])
 def test_gradients_with_replayed_selections(cuda, H, W):
     """The same iteration with the oracle's non-differentiable SELECTIONS replayed on the device (ReLU / LeakyReLU sign masks,
-    2x2 max-pool winners, RoI max-pool argmax -- scda_amd.autograd_ops.replay) in addition to the dropout masks: what is left
+    2x2 max-pool winners, RoI max-pool argmax -- a scda_amd.probe.Probe's `replay`) in addition to the dropout masks: what is left
     is the kernels' arithmetic.  Every gradient tensor of every phase then agrees with the oracle's to 1e-4 relative L2
     (test_iteration_matches_oracle, which lets each side break its own ties, needs 5e-2)."""
     from scda_amd import autograd_ops as A
@@ -223,19 +211,14 @@ def test_gradients_with_replayed_selections(cuda, H, W):
     tr.capture = True
     src, tgt, gts, info = mc.seeded_inputs(H, W)
     tape = list(masks)
-    L.Dropout.mask_source = lambda shape, p, device: tape.pop(0).to(device)
-    from scda_amd.dropin.functions import rpn_proposal
-    A.replay = mc.ReplaySource(ref['_selections'], cuda)
-    rpn_proposal.rpn_output_hook = A.replay.rpn     # identical proposal ranking (see rpn_proposal.rpn_output_hook)
-    try:
-        np.random.seed(mc.SEEDS['numpy'])
-        out = tr.step(src.to(cuda), gts, info, tgt.to(cuda))
-        torch.cuda.synchronize()
-        used = A.replay.used
-    finally:
-        L.Dropout.mask_source = None
-        A.replay = None
-        rpn_proposal.rpn_output_hook = None
+    rp = mc.ReplaySource(ref['_selections'], cuda)
+    # the Probe goes in through the trainer (scda_amd/probe.py): selections, identical proposal ranking (rpn_output), dropout masks
+    tr.probe = mc.Probe(replay=rp, rpn_output=rp.rpn, dropout_masks=lambda shape, p, device: tape.pop(0).to(device))
+    np.random.seed(mc.SEEDS['numpy'])
+    out = tr.step(src.to(cuda), gts, info, tgt.to(cuda))
+    torch.cuda.synchronize()
+    used = rp.used
+    tr.probe = None
     assert not tape and used >= 40, used
     mc.check_losses(out, ref, LOSS_KEYS, LOSS_REL, "replayed_selections[%dx%d]" % (H, W))
 
@@ -295,13 +278,10 @@ def test_fullsize_free_running_iteration_tracks_oracle(cuda, monkeypatch):
 
     tr.model.forward = grabbing
     tape = list(masks)
-    L.Dropout.mask_source = lambda shape, p, device: tape.pop(0).to(device)
-    try:
+    with mc.probed(dropout_masks=lambda shape, p, device: tape.pop(0).to(device)):
         np.random.seed(mc.SEEDS['numpy'])
         out = tr.step(src.to(cuda), gts, info, tgt.to(cuda))
         torch.cuda.synchronize()
-    finally:
-        L.Dropout.mask_source = None
     assert not tape
     # anchor labelling: a function of the ground truth and numpy's generator alone
     assert len(counts) == 2 and counts[0] == counts[1], counts
