@@ -2603,6 +2603,7 @@ static bool gemm_glds_operands_ok(const float *A, const float *B, int M, int N, 
 
 // should it take the exact-product bf16 x 9 kernel?  SCDA_GEMM_X9: 0 never, 2 whatever its size (tests), default: the FC-sized ones
 static bool gemm_x9_wanted(int M, int N, int K) {
+    if (getenv("SCDA_PLAN_FORCE")) return false;      // a forced (tile, split) plan names an fp32-MFMA instantiation: that one runs
     const char *x9_env = getenv("SCDA_GEMM_X9");      // (read per call: tests switch it)
     const int x9_mode = x9_env ? atoi(x9_env) : 1;
     return x9_mode == 2 || (x9_mode == 1 && M >= 256 && N >= 128 && K >= 256 && (double)M * N * K >= 4e9);
