@@ -77,7 +77,7 @@ for _k in CFG:
 H, W, G = 512, 1024, 12
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 F_ITER_TFLOP = 2.255          # necessary conv / FC / convT work of one iteration
-PMC_TRAFFIC_FILES = ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
+PMC_TRAFFIC_FILES = ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
 # Winograd-eligible share of F_iter (direct-form TFLOP of the launches the F(2x2,3x3) kernels take; scripts/wino_iteration_flops.py
 # sums the library's launch log of one iteration): detector forward + data gradient 0.9857, its weight gradients 0.3286, the SCDA
 # nets' stride-1 3x3 layers (decoder residual / up-sampling convolutions, forward + both gradients).  F_exec = F_iter - eligible * (1 - 1/2.25)

@@ -27,8 +27,14 @@ if [ "${1:-}" = "--install" ]; then
   for f in device_phase_times.txt host_cpu.txt resnet50_plan_search.txt plan_search.txt s2_conv_layers.txt host_budget.txt onerank_rccl.txt allreduce_contention.txt wino_layers.txt eval.txt; do
     [ -s $S/$f ] && cp $S/$f $D/${TAG}_$f
   done
-  for f in $D/${TAG}_*; do [ -s $f ] || echo "WARNING: $f is empty"; done
-  exit 0
+  for f in bf16x9_probe.txt gemm_x9.txt pmc_fc6.txt; do
+    [ -s $S/$f ] && cp $S/$f $D/${TAG}_$f
+  done
+  bad=0
+  for f in $D/${TAG}_*; do      # an artefact that is empty or only a header line is a failed collection, not evidence
+    if [ ! -s $f ] || [ "$(wc -l < $f)" -lt 2 -a "${f##*.}" != "json" ]; then echo "ERROR: $f is empty (or one line)"; bad=1; fi
+  done
+  exit $bad
 fi
 TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -72,8 +78,15 @@ SCDA_GAN_GRAPH=1 python scripts/host_budget_8ranks.py block >> $OUT/host_budget.
 GPU_MAX_HW_QUEUES=8 SCDA_GAN_GRAPH=0 python scripts/host_budget_8ranks.py spin >> $OUT/host_budget.txt 2>/dev/null
 GPU_MAX_HW_QUEUES=8 SCDA_GAN_GRAPH=0 python scripts/host_budget_8ranks.py block >> $OUT/host_budget.txt 2>/dev/null
 bash scripts/onerank_matrix.sh $TAG/onerank > /dev/null 2>&1; cp $OUT/onerank/onerank_rccl.txt $OUT/onerank_rccl.txt
+[ -s scripts/micro/build/libring_standin.so ] || echo "ERROR: scripts/micro/build/libring_standin.so is missing (python -c 'import __graft_entry__ as g; g.build()' builds it in the container)" >&2
 ( python scripts/allreduce_contention.py 32 4; echo; echo "GPU_MAX_HW_QUEUES=8:"; GPU_MAX_HW_QUEUES=8 python scripts/allreduce_contention.py 32 4 ) 2>/dev/null > $OUT/allreduce_contention.txt
 python scripts/bench_wino.py > $OUT/wino_layers.txt 2>/dev/null
+# the exact-product bf16 x 9 GEMM: what the instruction does with its sums / the FC products on both kernels / counters of FC6
+[ -x scripts/micro/bf16x9_probe ] && ./scripts/micro/bf16x9_probe > $OUT/bf16x9_probe.txt 2>&1
+python scripts/time_gemm_x9.py 2>/dev/null | grep -v amdgpu.ids > $OUT/gemm_x9.txt
+( for w in fwd dgrad wgrad; do bash scripts/pmc_layer.sh fc6 $w $TAG/pmc_fc6_$w 2>/dev/null | grep -A30 "gemm_x9_kernel"; done
+  SCDA_GEMM_X9=0 bash scripts/pmc_layer.sh fc6 fwd $TAG/pmc_fc6_fwd_f32 2>/dev/null | grep -A30 "gemm_glds_kernel" ) > $OUT/pmc_fc6.txt 2>/dev/null
+rm -rf $OUT/pmc_fc6_*/p[123]
 python scripts/time_eval.py 2>/dev/null > $OUT/eval.txt
 if [ "${2:-}" = "full" ]; then
   python scripts/tune_plans.py resnet > $OUT/resnet50_plan_search.txt 2>/dev/null

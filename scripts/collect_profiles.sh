@@ -10,7 +10,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
-python $R/bench.py --steps 30 --warmup 8 > $OUT/bench_1gpu.json 2> $OUT/bench_1gpu.err
+python $R/bench.py > $OUT/bench_1gpu.json 2> $OUT/bench_1gpu.err      # the driver's exact command (defaults: 200 steps, 5 warm-up)
 export SCDA_BENCH_NO_TEMPLATE_PASS=1   # the traces below hold exactly warm-up + timed iterations
 rocprofv3 --kernel-trace --stats -d $OUT/kt -o prof -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/kt.log 2>&1
 grep '^{' $OUT/kt.log > $OUT/bench_under_rocprof.json

@@ -28,6 +28,8 @@ t0, t1 = sel[0][0], max(r[1] for r in sel)
 
 
 def is_mfma(name):
+    if "gemm_x9_fixup" in name:
+        return False
     return ("conv_igemm" in name) or ("conv_wgrad" in name) or ("gemm_" in name) or ("conv_wino" in name)
 
 

@@ -12,6 +12,8 @@ def cat(k):
     if 'conv_igemm_glds' in k: return 'conv fwd/dgrad (direct-to-LDS MFMA)'
     if 'conv_igemm_kernel' in k: return 'conv gather (MFMA)'
     if 'conv_wgrad' in k: return 'conv wgrad (MFMA)'
+    if 'gemm_x9_fixup' in k: return 'split-K reduce'
+    if 'gemm_x9' in k: return 'dense GEMM (bf16 x 9 MFMA)'
     if 'gemm_' in k: return 'dense GEMM (MFMA)'
     if 'splitk_reduce' in k: return 'split-K reduce'
     if 'at::native' in k or 'rocclr' in k: return 'torch / runtime (fill, copy, add, cat ...)'
