@@ -17,6 +17,6 @@ if [ "$1" = build ]; then
 else
   for f in $OUT/libscda_ops_*.so; do
     echo "== $f"
-    SCDA_X9_LIB=$f python scripts/time_gemm_x9.py x9only 2>&1 | grep -v amdgpu.ids
+    SCDA_OPS_LIB=$PWD/$f python scripts/time_gemm_x9.py x9only 2>&1 | grep -v amdgpu.ids
   done
 fi

@@ -21,5 +21,10 @@ for k, c in d.items():
         if n != '_ns':
             v = c[n][1:] or c[n]     # skip the first (cold) launch
             lines.append("  %-34s %16.0f" % (n, sum(v) / len(v)))
+    if 'GRBM_GUI_ACTIVE' in c and 'SQ_VALU_MFMA_BUSY_CYCLES' in c:      # (both summed over their instances: 8 XCDs / 1024 SIMDs)
+        g = sum(c['GRBM_GUI_ACTIVE'][1:] or c['GRBM_GUI_ACTIVE']) / len(c['GRBM_GUI_ACTIVE'][1:] or c['GRBM_GUI_ACTIVE']) / 8
+        m = sum(c['SQ_VALU_MFMA_BUSY_CYCLES'][1:] or c['SQ_VALU_MFMA_BUSY_CYCLES']) / len(c['SQ_VALU_MFMA_BUSY_CYCLES'][1:] or c['SQ_VALU_MFMA_BUSY_CYCLES']) / 1024
+        ns = sum(c['_ns'][1:] or c['_ns']) / len(c['_ns'][1:] or c['_ns'])
+        lines.append("  => active cycles per XCD %.0f = %.2f GHz over the launch; MFMA pipe busy %.1f %% of them" % (g, g / ns, 100.0 * m / g))
 open(os.path.join(out, "summary.txt"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))

@@ -17,8 +17,10 @@ with open(sys.argv[2], "w") as f:
     f.write("# rocprofv3 PMC: MFMA pipe utilisation per kernel\n\n"
             "`rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline`\n"
             "(counter pass only, kernels run one at a time).  util = MFMA-busy cycles summed over the 1024 SIMDs / (active cycles per XCD x 1024);\n"
-            "for the fp32 `v_mfma_f32_32x32x2_f32` (64 cycles, 4096 FLOP) util x 157.3 TFLOP/s is the achieved rate.  Clock = active cycles / duration.\n\n"
+            "for the fp32 `v_mfma_f32_32x32x2_f32` (64 cycles, 4096 FLOP) util x 157.3 TFLOP/s is the achieved rate; for `gemm_x9_kernel` (nine\n"
+            "`v_mfma_f32_32x32x16_bf16` of 32 cycles per 32 x 32 x 16 fp32 products) util x 157.3 x 16 / 9 = the fp32-EQUIVALENT rate.  Clock = active cycles /\n"
+            "duration (meaningful for launches of >= 100 us; isolated launches of a counter pass run at higher clocks than the iteration holds).\n\n"
             "| kernel | launches | MFMA util | = TFLOP/s | avg us | clock MHz |\n|---|---:|---:|---:|---:|---:|\n")
     for m, k, n, u, us, mhz in rows[:24]:
-        f.write("| `%s` | %d | %.1f %% | %.0f | %.1f | %.0f |\n" % (k[:90], n, 100 * u, u * 157.3, us, mhz))
+        f.write("| `%s` | %d | %.1f %% | %.0f | %.1f | %.0f |\n" % (k[:90], n, 100 * u, u * 157.3 * (16.0 / 9.0 if "gemm_x9_kernel" in k else 1.0), us, mhz))
 print(open(sys.argv[2]).read()[:2500])

@@ -1,12 +1,11 @@
 """FC6 / FC7's three products (forward, data gradient, weight gradient; 512 RoIs) on the fp32-MFMA kernel and on the exact-product
 bf16 x 9 kernel (csrc/conv_gemm.hip gemm_x9_kernel): time per launch (HIP events, 20 launches), fp32-equivalent TFLOP/s, and the error
-of each against an fp64 product on a 128 x 128 block of the result."""
+of each against an fp64 product on a 128 x 128 block of the result.  `x9only`: FC6 on the bf16 x 9 kernel only (scripts/ablate/x9_ablate.sh
+times its ablation builds through SCDA_OPS_LIB)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch
 from scda_amd import native
-if os.environ.get("SCDA_X9_LIB"):      # scripts/ablate/x9_ablate.sh: a timing build of the library
-    native.LIB_PATH = os.path.abspath(os.environ["SCDA_X9_LIB"])
 X9ONLY = len(sys.argv) > 1 and sys.argv[1] == "x9only"
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(0)
