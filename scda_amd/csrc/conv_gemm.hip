@@ -1843,6 +1843,40 @@ __global__ __launch_bounds__(256) void gemm_x9_fixup_kernel(const GemmGeom g, co
     }
 }
 
+// ---- forward of a 3x3, stride-1, pad-1 conv with <= 4 INPUT channels (VGG conv1_1: 3 -> 64 on the full-resolution image) ------
+// The GEMM view has K = 27: the gather kernel's two 16-deep slabs are half padding and its register-staged 64 x 64 tiles stream
+// the 134 MB result at 2 TB/s (67 us at 512 x 1024).  Direct form: one thread per output pixel (lanes along W: every store of a wave
+// is 256 contiguous bytes of one channel row), its 9 x Cin input values in registers, the [Cout][9 * Cin] weights (the gather kernel's
+// tap-major packing, as given) read through the scalar unit -- the index is wave-uniform -- as the SGPR operand of the FMAs.  Bound
+// by the result's stores.  Same products summed tap-major / channel-minor per output: the gather kernel's K order.
+template <int CIN>
+__global__ __launch_bounds__(256) void conv3x3_small_cin_fwd_kernel(const float *__restrict__ x, const float *__restrict__ wk,
+                                                                    const float *__restrict__ bias, float *__restrict__ y, const int H,
+                                                                    const int W, const int Cout, const int act, const float slope) {
+    const int px = blockIdx.x * 256 + threadIdx.x, py = blockIdx.y, img = blockIdx.z;
+    if (px >= W) return;
+    const float *xi = x + (size_t)img * CIN * H * W;
+    float v[9 * CIN];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int iy = py + kh - 1, ix = px + kw - 1;
+            const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) v[(kh * 3 + kw) * CIN + c] = ok ? xi[((size_t)c * H + iy) * W + ix] : 0.f;
+        }
+    float *yo = y + ((size_t)img * Cout * H + py) * W + px;
+    for (int m = 0; m < Cout; ++m) {
+        const float *wm = wk + m * (9 * CIN);
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9 * CIN; ++k) a = fmaf(wm[k], v[k], a);
+        if (bias) a += bias[m];
+        yo[(size_t)m * H * W] = apply_act(a, act, slope);
+    }
+}
+
 // ---- data gradient of a conv with <= 4 INPUT channels (an image-side layer: the discriminators' first conv) -------------
 // The implicit GEMM would have M = Cin <= 4 output rows in a 64-row MFMA tile: 95 % of the matrix work on padding (measured
 // 188 us for the 3-channel 256x256 batch-4 layer).  This is a direct form instead: one thread per input pixel, the <= 4
@@ -2400,6 +2434,20 @@ SCDA_API int scda_conv2d_fwd_hip(const float *x, const float *w, const float *bi
     if (batch == 1 && KH == 1 && KW == 1 && S == 1 && P == 0 && g.slab_aligned) {      // w is packed [Cin][mpad]: the GEMM's A stored [K][M]
         const int rc = conv1x1_as_x9(w, x, y, Cout, IH * IW, Cin, conv_packed_mpad(Cout), IH * IW, 1, 1, bias, act, slope, 0, ws, ws_bytes, as_stream(stream));
         if (rc <= 0) return rc;
+    }
+    static const bool no_direct = getenv("SCDA_CONV_NO_SMALL_CIN_FWD") != nullptr;      // A/B knob
+    if (!no_direct && KH == 3 && KW == 3 && S == 1 && P == 1 && Cin <= 4 && !g.slab_aligned && row_period == 0 && IW >= 64) {
+        // image-side 3x3 layer (VGG conv1_1): direct kernel on the tap-major [Cout][9 Cin] weights the gather kernel takes
+        const dim3 grid((unsigned)cdiv(IW, 256), (unsigned)IH, (unsigned)batch);
+        hipStream_t st = as_stream(stream);
+        note_plan(0, 0, 1, 0);
+        prof_begin(PK_CONV_GATHER, 2.0 * Cout * (double)g.N * g.K, st);
+        if (Cin == 1) hipLaunchKernelGGL((conv3x3_small_cin_fwd_kernel<1>), grid, dim3(256), 0, st, x, w, bias, y, IH, IW, Cout, act, slope);
+        else if (Cin == 2) hipLaunchKernelGGL((conv3x3_small_cin_fwd_kernel<2>), grid, dim3(256), 0, st, x, w, bias, y, IH, IW, Cout, act, slope);
+        else if (Cin == 3) hipLaunchKernelGGL((conv3x3_small_cin_fwd_kernel<3>), grid, dim3(256), 0, st, x, w, bias, y, IH, IW, Cout, act, slope);
+        else hipLaunchKernelGGL((conv3x3_small_cin_fwd_kernel<4>), grid, dim3(256), 0, st, x, w, bias, y, IH, IW, Cout, act, slope);
+        prof_end(st);
+        return launch_status("conv3x3_small_cin_fwd_kernel");
     }
     Epi e{y, nullptr, bias, 0, act, slope, 1, 0, nullptr, 0.f};
     if (KH == 7 && KW == 7 && S == 2)   // the ResNet stem (3 -> 64, frozen in the reference: models/mask_rcnn/resnet.py:230-238): forward only
