@@ -37,3 +37,8 @@ def test_bench_two_ranks(cuda, how):
     assert abs(d["value"] - 2 * 2 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-3      # whole-job images/s
     assert d["roofline"]["launches"] > 0
     assert d["collective"]["ranks"] == 2 and d["collective"]["backend"] == "gloo"
+    # where the time is: device time between the trainer's phase marks (events in the marked iterations) and the host's CPU time per step
+    seg = d["segments"]
+    assert seg["step_begin->end"] > 0 and all(k in seg for k in ("backbones_enqueued", "det_backward_enqueued", "phase2", "phase3", "phase4+det_step"))
+    assert abs(sum(v for k, v in seg.items() if k not in ("unit", "step_begin->end")) - seg["step_begin->end"]) <= 0.05 * seg["step_begin->end"]
+    assert d["host_ms_per_step"] > 0 and d["host"]["process_cpu_ms_per_step"] >= d["host"]["main_thread_cpu_ms_per_step"] * 0.5
