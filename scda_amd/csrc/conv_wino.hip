@@ -54,7 +54,7 @@ __device__ __forceinline__ void wino_dma_b32(const void *base, const unsigned vo
 __device__ __forceinline__ void wino_dma_b32(const void *, const unsigned, float *, const int) {}
 #endif
 #ifndef SCDA_WINO_ABLATE
-#define SCDA_WINO_ABLATE 0     // timing ablations of conv_wino_kernel's K loop (scripts/ablate/wino_ablate.sh): 4 no barrier, 8 no patch DMA, 16 no LDS reads; weight gradient: 128 / 64 / 32
+#define SCDA_WINO_ABLATE 0     // timing ablations of conv_wino_kernel's K loop (scripts/ablate/wino_ablate.sh): 4 no barrier, 8 no patch DMA, 16 no LDS reads; weight gradient: 128 / 64 / 32, 256 no epilogue, 512 no operand transforms, 1024 epilogue without its stores
 #endif
 #define WINO_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 // An empty volatile asm that "rewrites" a register value: it is ordered among the side-effecting nodes (sched_barrier, s_barrier, the
@@ -803,6 +803,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino_wgrad_kernel(const float *__
         };
         auto valu_z = [&](const int mb, float (&Z)[2][2]) {
             WINO_PIN(ry[mb][0]);
+#if (SCDA_WINO_ABLATE & 512)
+            Z[0][mb] = ry[mb][0][0]; Z[1][mb] = ry[mb][1][1]; WINO_PIN(Z[0][mb]); WINO_PIN(Z[1][mb]);
+            return;
+#endif
             const wino_f2 sq = ya * ry[mb][0] + yb2 * ry[mb][1];                      // A row a over the tile's two rows: (s0, s1)
             if (BSEL) { Z[0][mb] = sq[0] + sq[1]; Z[1][mb] = sq[0] - sq[1]; }         // b = 1, 2
             else { Z[0][mb] = sq[0]; Z[1][mb] = -sq[1]; }                             // b = 0, 3
@@ -811,6 +815,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino_wgrad_kernel(const float *__
         };
         auto valu_v = [&](const int cb, float (&V)[2][2]) {
             WINO_PIN(rx[cb][0]);
+#if (SCDA_WINO_ABLATE & 512)
+            V[0][cb] = rx[cb][0][0] + rx[cb][2][1]; V[1][cb] = rx[cb][1][0] + rx[cb][3][1]; WINO_PIN(V[0][cb]); WINO_PIN(V[1][cb]);
+            return;
+#endif
             const wino_f2 p01 = rx[cb][0] + sgn * rx[cb][2], p23 = rx[cb][1] + sgn * rx[cb][3];   // BT row a: (p0, p1), (p2, p3)
             if (BSEL) {
                 V[0][cb] = p01[1] + p23[0];       // b = 1: d1 + d2
@@ -888,6 +896,21 @@ __global__ __launch_bounds__(512, 2) void conv_wino_wgrad_kernel(const float *__
 
     // ---- epilogue: 4 passes of 16 output-channel rows through LDS, G^T . G, partial dg slab ---------------------------------------------
     const size_t wrow = (size_t)g.C * 9;
+#if (SCDA_WINO_ABLATE & 256)
+    {
+        float tot = 0.f;
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) tot += acc[x][mb][cb][r];
+        if (tot == 123.456f) ws[0] = 1.f;
+        return;
+    }
+#endif
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
         const int mb = pass >> 1, half = pass & 1;
@@ -919,6 +942,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino_wgrad_kernel(const float *__
             }
             if (m >= g.M || c >= g.C) continue;
             float *o = ws + ((size_t)sp * g.M + m) * wrow + (size_t)c * 9;
+#if (SCDA_WINO_ABLATE & 1024)
+            {
+                float tot = 0.f;
+#pragma unroll
+                for (int u = 0; u < 3; ++u) tot += (t[u][0] + 0.5f * (t[u][1] + t[u][2])) + 0.5f * (t[u][1] - t[u][2]) + (0.5f * (t[u][1] + t[u][2]) + t[u][3]);
+                if (tot == 123.456f) o[0] = tot;
+                continue;
+            }
+#endif
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
                 o[u * 3 + 0] = t[u][0] + 0.5f * (t[u][1] + t[u][2]);

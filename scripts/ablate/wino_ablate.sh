@@ -10,14 +10,14 @@ if [ "${1:-}" = "run" ]; then
     lib=$O/libscda_ops_A$n.so; [ $n = 0 ] && lib=$R/scda_amd/libscda_ops.so
     echo "== ablate $n"; SCDA_OPS_LIB=$lib python $R/scripts/bench_wino.py conv2_2 conv3_2 conv4_2 2>&1 | grep -v amdgpu | cut -c1-8,48-110
   done
-  for n in 0 32 64 128 224; do      # the weight gradient's knobs
+  for n in ${WG_SET:-0 32 64 128 224 256 512 992}; do      # the weight gradient's knobs (256 no epilogue, 512 no operand transforms, 992 all)
     lib=$O/libscda_ops_A$n.so; [ $n = 0 ] && lib=$R/scda_amd/libscda_ops.so
     echo "== wgrad ablate $n"; SCDA_OPS_LIB=$lib python $R/scripts/bench_wino.py conv2_2 conv3_2 conv4_2 2>&1 | grep -v amdgpu | sed "s/ GFLOP.*| wgrad/ wgrad/"
   done
   exit 0
 fi
 cd $R/scda_amd/csrc
-for n in 4 8 16 28 32 64 128 224; do
+for n in ${BUILD_SET:-4 8 16 28 32 64 128 224 256 512 992}; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wno-unused-function -DSCDA_WINO_ABLATE=$n -c conv_wino.hip -o $O/conv_wino_A$n.o &&
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $O/libscda_ops_A$n.so detection_ops.o box_ops.o conv_gemm.o $O/conv_wino_A$n.o nn_ops.o image_ops.o && echo built $n
 done
