@@ -397,6 +397,18 @@ int scda_batchnorm_eval_hip(const float *x, const float *dy_or_null, float *out,
 /* Interpolate(scale_factor=2, 'bilinear', align_corners=True) : common_net.py:160-170 */
 int scda_upsample2x_fwd_hip(const float *x, float *y, int planes, int IH, int IW, void *stream);
 int scda_upsample2x_bwd_hip(const float *dy, float *dx, int planes, int IH, int IW, void *stream);
+/* Instance norm (+ fused activation, or + the residual block's dropout-and-add tail) and the Interpolate behind it as ONE launch
+ * (common_net.py:59-80 / :288-289 feeding :279-293 -- in the decoders nothing but the Interpolate reads those norms' outputs):
+ * y2 [planes, 2 IH, 2 IW] = upsample2x(instance_norm...(x)), bit-identical to the two launches; mean / rstd as scda_instnorm_fwd_hip
+ * (the backward is scda_upsample2x_bwd_hip followed by scda_instnorm_bwd_hip / scda_instnorm_drop_bwd_hip: it needs x, not the small
+ * plane).  Planes of 4096 or 16384 elements, IW % 32 == 0, 16-byte aligned tensors (scda_instnorm_up2_supported; SCDA_EINVAL otherwise). */
+int scda_instnorm_up2_supported(int IH, int IW);
+int scda_instnorm_up2_fwd_hip(const float *x, float *y2, float *mean, float *rstd, int planes, int IH, int IW, float eps, int act,
+                              float slope, void *stream);
+int scda_instnorm_drop_add_up2_fwd_hip(const float *x, const float *residual, float *y2, float *mean, float *rstd, int planes, int IH,
+                                       int IW, float eps, float p, uint64_t seed, float scale /* 1 / (1 - p) */, void *stream);
+int scda_instnorm_drop_add_up2_fwd_dev_hip(const float *x, const float *residual, float *y2, float *mean, float *rstd, int planes,
+                                           int IH, int IW, float eps, float p, const uint64_t *seed_dev, float scale, void *stream);
 /* F.binary_cross_entropy(p, t), mean : tools/faster_rcnn_train_val.py:584-600,627-628,675-687,723-732 */
 int scda_bce_fwd_hip(const float *p, const float *t, int n, float *out1, void *stream);
 int scda_bce_bwd_hip(const float *p, const float *t, int n, const float *grad_scalar, float *dp, void *stream);

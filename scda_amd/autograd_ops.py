@@ -441,6 +441,48 @@ class InstNormDropAddFn(Function):
         return dx, (dy if ctx.needs_input_grad[1] else None), None, None, None
 
 
+class InstanceNormUpFn(Function):
+    """Upsample2x(act(InstanceNorm(x))) as ONE launch (N.instnorm_up2_fwd): the small normalised plane never reaches memory.  The
+    backward is the two existing kernels -- the bilinear gather, then the norm's gradient, which needs x / mean / rstd only.
+    Bit-identical to InstanceNormFn -> Upsample2xFn in both directions."""
+
+    @staticmethod
+    def forward(ctx, x, eps, act, slope):
+        x = _c(x)
+        y2, mean, rstd = N.instnorm_up2_fwd(x, eps, act, slope)
+        ctx.save_for_backward(x, mean, rstd)
+        ctx.cfg = (act, slope)
+        return y2
+
+    @staticmethod
+    def backward(ctx, dy2):
+        x, mean, rstd = ctx.saved_tensors
+        act, slope = ctx.cfg
+        return N.instnorm_bwd(N.upsample2x_bwd(_c(dy2)), x, mean, rstd, act, slope), None, None, None
+
+
+class InstNormDropAddUpFn(Function):
+    """Upsample2x(residual + Dropout_p(InstanceNorm(x))): the tail of the LAST INSResBlock of a decoder and the Interpolate of the
+    up-sampling block behind it as one launch; backward as InstNormDropAddFn's behind the bilinear gather.  Bit-identical to
+    InstNormDropAddFn -> Upsample2xFn."""
+
+    @staticmethod
+    def forward(ctx, x, residual, eps, p, seed):
+        x = _c(x)
+        y2, mean, rstd = N.instnorm_drop_add_up2_fwd(x, _c(residual), eps, p, seed)
+        ctx.save_for_backward(x, mean, rstd)
+        ctx.cfg = (p, seed)
+        return y2
+
+    @staticmethod
+    def backward(ctx, dy2):
+        x, mean, rstd = ctx.saved_tensors
+        p, seed = ctx.cfg
+        dy = N.upsample2x_bwd(_c(dy2))
+        dx = N.instnorm_drop_bwd(dy, x, mean, rstd, p, seed) if ctx.needs_input_grad[0] else None
+        return dx, (dy if ctx.needs_input_grad[1] else None), None, None, None
+
+
 class BatchNormTrainFn(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, run_mean, run_var, eps, momentum, act, slope):

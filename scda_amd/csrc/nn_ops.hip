@@ -929,6 +929,22 @@ __global__ __launch_bounds__(256) void batchnorm_eval_kernel(const float *__rest
 // One workgroup = ROWS consecutive output rows of one plane (OH % ROWS == 0), a thread = four consecutive output pixels per step
 // (16-byte stores).  (One workgroup per output ROW with a pixel per thread was 65536 half-empty workgroups for the decoders'
 // [4, 64, 128, 128] -> 256 x 256 stage: 39-48 us for 84 MB, workgroup dispatch, not memory, set its pace.)
+// The two forward kernels that blend (upsample2_fwd_kernel, instnorm_up2_fwd_kernel) must agree bit for bit, and the compiler
+// contracts `fy - y0` and the blend differently from one kernel body to the next -- so the roundings are spelled out (they are the
+// ones upsample2_fwd_kernel was compiled to before: the fraction as ONE fma of scale and index, clamped; each row pair as
+// fma(l0, a, l1 * b); the two rows as fma(ly0, top, ly1 * bottom)).
+__device__ __forceinline__ void up2_taps(const float s, const int o, const int In, int &i0, int &i1, float &l0, float &l1) {
+    i0 = (int)__fmul_rn(s, (float)o);
+    i1 = i0 + (i0 < In - 1 ? 1 : 0);
+    l1 = fminf(fmaxf(__fmaf_rn(s, (float)o, -(float)i0), 0.f), 1.f);
+    l0 = __fsub_rn(1.f, l1);
+}
+__device__ __forceinline__ float up2_blend(const float ly0, const float ly1, const float lx0, const float lx1, const float a, const float b,
+                                           const float c, const float d) {
+    const float top = __fmaf_rn(lx0, a, __fmul_rn(lx1, b)), bot = __fmaf_rn(lx0, c, __fmul_rn(lx1, d));
+    return __fmaf_rn(ly0, top, __fmul_rn(ly1, bot));
+}
+
 template <int ROWS>
 __global__ __launch_bounds__(256) void upsample2_fwd_kernel(const float *__restrict__ x, float *__restrict__ y,
                                                             const int IH, const int IW, const int OH, const int OW,
@@ -939,19 +955,18 @@ __global__ __launch_bounds__(256) void upsample2_fwd_kernel(const float *__restr
     for (int i = threadIdx.x; i < ROWS * q_per_row; i += 256) {
         const int r = i / q_per_row, q = i - r * q_per_row;
         const int oy = oy0 + r;
-        const float fy = sh * (float)oy;
-        const int y0 = (int)fy, y1 = y0 + (y0 < IH - 1 ? 1 : 0);
-        const float ly1 = fminf(fmaxf(fy - (float)y0, 0.f), 1.f), ly0 = 1.f - ly1;
+        int y0, y1;
+        float ly0, ly1;
+        up2_taps(sh, oy, IH, y0, y1, ly0, ly1);
         const float *p0 = plane + (size_t)y0 * IW, *p1 = plane + (size_t)y1 * IW;
         float *out = y + ((size_t)row0 + r) * OW;
         float v[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int ox = min(q * 4 + k, OW - 1);
-            const float fx = sw * (float)ox;
-            const int x0 = (int)fx, x1 = x0 + (x0 < IW - 1 ? 1 : 0);
-            const float lx1 = fminf(fmaxf(fx - (float)x0, 0.f), 1.f), lx0 = 1.f - lx1;
-            v[k] = ly0 * (lx0 * p0[x0] + lx1 * p0[x1]) + ly1 * (lx0 * p1[x0] + lx1 * p1[x1]);
+            int x0, x1;
+            float lx0, lx1;
+            up2_taps(sw, min(q * 4 + k, OW - 1), IW, x0, x1, lx0, lx1);
+            v[k] = up2_blend(ly0, ly1, lx0, lx1, p0[x0], p0[x1], p1[x0], p1[x1]);
         }
         if (q * 4 + 3 < OW && (OW & 3) == 0) {
             *reinterpret_cast<float4 *>(out + q * 4) = make_float4(v[0], v[1], v[2], v[3]);
@@ -959,6 +974,79 @@ __global__ __launch_bounds__(256) void upsample2_fwd_kernel(const float *__restr
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if (q * 4 + k < OW) out[q * 4 + k] = v[k];
+        }
+    }
+}
+
+// Instance norm (+ fused activation, or + the residual block's dropout-and-add tail) AND the bilinear x2 behind it in one launch
+// (round 6; common_net.py:59-80 -> :279-293: in both decoders every Interpolate reads the output of an instance norm and nothing
+// else does): the norm's workgroup holds the whole plane, so the normalised plane goes to LDS instead of HBM and the same 1024
+// threads write the 2H x 2W map from there -- a lane owns output columns (its four taps' columns and weights are computed once), a
+// wave a set of output rows; stores are 256-byte runs.  The small plane is never written (its backward needs x, mean, rstd only)
+// and never re-read; values are those of instnorm_fwd_kernel followed by upsample2_fwd_kernel, bit for bit (up2_taps / up2_blend).
+template <int VPT>
+__global__ __launch_bounds__(1024) void instnorm_up2_fwd_kernel(const float *__restrict__ x, float *__restrict__ y2,
+                                                                float *__restrict__ mean_out, float *__restrict__ rstd_out,
+                                                                const int IH, const int IW, const float eps, const int act,
+                                                                const float slope, const DropTail dt, const float sh, const float sw) {
+    constexpr int HW = VPT * 4096;
+    __shared__ float red[16];
+    __shared__ __attribute__((aligned(16))) float plane[HW];
+    const size_t base = (size_t)blockIdx.x * HW;
+    const unsigned long long dseed = dt.seed_ptr ? *dt.seed_ptr : dt.seed;
+    auto tail = [&](float o, const size_t i) -> float {      // as in instnorm_fwd_kernel
+        if (!dt.residual) return o;
+        const float d = mix_hash(dseed, (uint64_t)i) >= dt.thr ? o * dt.scale : 0.f;
+        return d + dt.residual[i];
+    };
+    {
+        const float4 *x4 = reinterpret_cast<const float4 *>(x + base);
+        float4 v[VPT];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) {
+            v[j] = x4[j * 1024 + threadIdx.x];
+            s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+        }
+        const float mean = block_sum(s, red) / (float)HW;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) {
+            const float a = v[j].x - mean, b = v[j].y - mean, c = v[j].z - mean, d = v[j].w - mean;
+            q += (a * a + b * b) + (c * c + d * d);
+        }
+        const float rstd = 1.f / sqrtf(block_sum(q, red) / (float)HW + eps);
+        float4 *p4 = reinterpret_cast<float4 *>(plane);
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) {
+            float4 o;
+            const size_t i0 = base + 4 * (size_t)(j * 1024 + threadIdx.x);
+            o.x = tail(inorm_act((v[j].x - mean) * rstd, act, slope), i0);
+            o.y = tail(inorm_act((v[j].y - mean) * rstd, act, slope), i0 + 1);
+            o.z = tail(inorm_act((v[j].z - mean) * rstd, act, slope), i0 + 2);
+            o.w = tail(inorm_act((v[j].w - mean) * rstd, act, slope), i0 + 3);
+            p4[j * 1024 + threadIdx.x] = o;
+        }
+        if (threadIdx.x == 0) { mean_out[blockIdx.x] = mean; rstd_out[blockIdx.x] = rstd; }
+    }
+    __syncthreads();
+    const int OH = 2 * IH, OW = 2 * IW;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float *out = y2 + (size_t)blockIdx.x * 4 * HW;
+    for (int c0 = 0; c0 < OW; c0 += 256) {        // (one round for the decoders' maps: OW = 128 / 256)
+        int x0[4], x1[4];
+        float lx0[4], lx1[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) up2_taps(sw, min(c0 + k * 64 + lane, OW - 1), IW, x0[k], x1[k], lx0[k], lx1[k]);
+        for (int oy = wave; oy < OH; oy += 16) {
+            int y0, y1;
+            float ly0, ly1;
+            up2_taps(sh, oy, IH, y0, y1, ly0, ly1);
+            const float *p0 = plane + y0 * IW, *p1 = plane + y1 * IW;
+            float *orow = out + (size_t)oy * OW + c0 + lane;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (c0 + k * 64 + lane < OW) orow[k * 64] = up2_blend(ly0, ly1, lx0[k], lx1[k], p0[x0[k]], p0[x1[k]], p1[x0[k]], p1[x1[k]]);
         }
     }
 }
@@ -1596,6 +1684,46 @@ SCDA_API int scda_upsample2x_bwd_hip(const float *dy, float *dx, int planes, int
         hipLaunchKernelGGL(upsample2_bwd_kernel<1>, dim3(planes * IH), dim3(256), 0, as_stream(stream), dy, dx, IH, IW, OH, OW,
                            up_scale(IH, OH), up_scale(IW, OW));
     return launch_status("upsample2_bwd_kernel");
+}
+
+// instance norm (+ act / + dropout-and-add tail) and the bilinear x2 behind it as ONE launch: y2 [planes, 2 IH, 2 IW]
+SCDA_API int scda_instnorm_up2_supported(int IH, int IW) {
+    const long long hw = (long long)IH * IW;
+    return IH > 1 && IW > 1 && (hw == 4096 || hw == 16384) && (IW % 32) == 0 && !getenv("SCDA_NO_NORM_UP_FUSION");
+}
+
+static int instnorm_up2_launch(const float *x, float *y2, float *mean, float *rstd, int planes, int IH, int IW, float eps, int act,
+                               float slope, const DropTail dt, void *stream, const char *who) {
+    if (!scda_instnorm_up2_supported(IH, IW)) { set_error("%s: planes of %d x %d are not supported (scda_instnorm_up2_supported)", who, IH, IW); return SCDA_EINVAL; }
+    if (((((uintptr_t)x) | ((uintptr_t)y2) | ((uintptr_t)dt.residual)) & 15) != 0) { set_error("%s: x, y2 and residual must be 16-byte aligned", who); return SCDA_EINVAL; }
+    const float sh = up_scale(IH, 2 * IH), sw = up_scale(IW, 2 * IW);
+    if ((long long)IH * IW == 4096)
+        hipLaunchKernelGGL(instnorm_up2_fwd_kernel<1>, dim3(planes), dim3(1024), 0, as_stream(stream), x, y2, mean, rstd, IH, IW, eps, act, slope, dt, sh, sw);
+    else
+        hipLaunchKernelGGL(instnorm_up2_fwd_kernel<4>, dim3(planes), dim3(1024), 0, as_stream(stream), x, y2, mean, rstd, IH, IW, eps, act, slope, dt, sh, sw);
+    return launch_status("instnorm_up2_fwd_kernel");
+}
+
+SCDA_API int scda_instnorm_up2_fwd_hip(const float *x, float *y2, float *mean, float *rstd, int planes, int IH, int IW, float eps,
+                                       int act, float slope, void *stream) {
+    NN_CHECK(x && y2 && mean && rstd && planes > 0, "scda_instnorm_up2_fwd_hip")
+    return instnorm_up2_launch(x, y2, mean, rstd, planes, IH, IW, eps, act, slope, DropTail{nullptr, 0u, 0ull, 1.f, 0, nullptr}, stream,
+                               "scda_instnorm_up2_fwd_hip");
+}
+
+SCDA_API int scda_instnorm_drop_add_up2_fwd_hip(const float *x, const float *residual, float *y2, float *mean, float *rstd, int planes,
+                                                int IH, int IW, float eps, float p, uint64_t seed, float scale, void *stream) {
+    NN_CHECK(x && residual && y2 && mean && rstd && planes > 0 && p >= 0.f && p < 1.f, "scda_instnorm_drop_add_up2_fwd_hip")
+    return instnorm_up2_launch(x, y2, mean, rstd, planes, IH, IW, eps, 0, 0.f, DropTail{residual, drop_threshold(p), seed, scale, 1, nullptr}, stream,
+                               "scda_instnorm_drop_add_up2_fwd_hip");
+}
+
+SCDA_API int scda_instnorm_drop_add_up2_fwd_dev_hip(const float *x, const float *residual, float *y2, float *mean, float *rstd, int planes,
+                                                    int IH, int IW, float eps, float p, const uint64_t *seed_dev, float scale,
+                                                    void *stream) {
+    NN_CHECK(x && residual && y2 && mean && rstd && seed_dev && planes > 0 && p >= 0.f && p < 1.f, "scda_instnorm_drop_add_up2_fwd_dev_hip")
+    return instnorm_up2_launch(x, y2, mean, rstd, planes, IH, IW, eps, 0, 0.f, DropTail{residual, drop_threshold(p), 0ull, scale, 1, (const unsigned long long *)seed_dev}, stream,
+                               "scda_instnorm_drop_add_up2_fwd_dev_hip");
 }
 
 SCDA_API int scda_bce_fwd_hip(const float *p, const float *t, int n, float *out1, void *stream) {

@@ -9,9 +9,10 @@ import torch
 import torch.nn as nn
 
 from scda_amd import layers as L
+from scda_amd import native as N
 from scda_amd import probe as P
 from scda_amd import seeds
-from scda_amd.autograd_ops import ACT_LEAKY, ACT_NONE, ACT_RELU, AddFn, InstNormDropAddFn
+from scda_amd.autograd_ops import ACT_LEAKY, ACT_NONE, ACT_RELU, AddFn, InstNormDropAddFn, InstNormDropAddUpFn
 from scda_amd.dropin.models.faster_rcnn.init import gaussian_weights_init, xavier_weights_init  # noqa: F401
 
 
@@ -29,6 +30,12 @@ class INSResBlock(nn.Module):
             seq.append(L.Dropout(p=dropout))
         self.model = nn.Sequential(*seq)
         self.model.apply(gaussian_weights_init)
+        self._up_ref = None      # layers.pair_norm_upsample: the Upsample2x behind this block, if this block's output feeds nothing else
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state["_up_ref"] = None
+        return state
 
     def tail_fusable(self):
         """IN -> Dropout -> (+ x) of this block can run as one launch each way (training mode, a real dropout rate)"""
@@ -43,8 +50,34 @@ class INSResBlock(nn.Module):
             # Dropout module draws it, so the torch generator is consumed identically
             h = self.model[:-2](x)
             seed = seeds.draw()      # an int, or a device slot while the trainer records a hipGraph (scda_amd/seeds.py)
+            up = L.my_upsample(self)
+            if up is not None and N.instnorm_up2_ok(h) and x.is_contiguous() and N.aligned16(x):
+                # ... and the Interpolate of the up-sampling block behind this (the decoder's last) residual block in the same launch
+                y2 = InstNormDropAddUpFn.apply(h, x, tail[0].eps, tail[1].p, seed)
+                up.expect_upsampled(tuple(y2.shape))
+                return y2
             return InstNormDropAddFn.apply(h, x, tail[0].eps, tail[1].p, seed)
         return AddFn.apply(self.model(x), x)
+
+
+def pair_decoder_upsamples(seq):
+    """fusion plan of a decoder branch (an nn.Sequential of the blocks above): every LeakyReLUConvTranspose2d_2's Interpolate reads
+    the output of the block in front and nothing else does, so when that output is produced by an instance norm -- the fused tail of
+    the last INSResBlock, or the IN + LeakyReLU of the previous up-sampling block -- the norm's launch may write the up-sampled map
+    (layers.pair_norm_upsample).  Returns the number of pairs."""
+    n = 0
+    blocks = list(seq.children())
+    for a, b in zip(blocks, blocks[1:]):
+        if not isinstance(b, LeakyReLUConvTranspose2d_2) or not isinstance(b.model[0], Interpolate):
+            continue
+        if isinstance(a, INSResBlock) and a.tail_fusable():
+            L.pair_norm_upsample(a, b.model[0].up)
+        elif isinstance(a, LeakyReLUConvTranspose2d_2) and isinstance(a.model[2], L.InstanceNorm2d):
+            L.pair_norm_upsample(a.model[2], b.model[0].up)
+        else:
+            continue
+        n += 1
+    return n
 
 
 class LinUnsRes_cluster(nn.Module):

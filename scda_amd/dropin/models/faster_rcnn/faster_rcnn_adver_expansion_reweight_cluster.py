@@ -23,7 +23,7 @@ from scda_amd.dropin.functions.predict_bbox import compute_predicted_bboxes
 from scda_amd.dropin.functions.proposal_target import compute_proposal_targets
 from scda_amd.dropin.functions.rpn_proposal import compute_rpn_proposals
 from scda_amd.dropin.models.faster_rcnn.common_net import (INSResBlock, LeakyReLUConv2d, LeakyReLUConvTranspose2d_2, LinUnsRes_cluster2,
-                                                           LinUnsRes_cluster, ResDis_cluster, gaussian_weights_init)
+                                                           LinUnsRes_cluster, ResDis_cluster, gaussian_weights_init, pair_decoder_upsamples)
 
 logger = logging.getLogger('global')
 
@@ -350,6 +350,8 @@ class GAN_decoder_AE(nn.Module):
         self.decode_B.apply(gaussian_weights_init)
         self.decode_A = dec_a
         self.decode_A.apply(gaussian_weights_init)
+        for dec in (self.decode_A, self.decode_B):       # norm + Interpolate pairs as one launch (common_net.pair_decoder_upsamples)
+            pair_decoder_upsamples(dec)
 
     def forward(self, x_aa, x_bb):
         return _two_branches(self, lambda: self.decode_A(x_aa), lambda: self.decode_B(x_bb))

@@ -256,10 +256,23 @@ class InstanceNorm2d(nn.Module):
         self.fused_act = fused_act
         self.slope = slope
 
+        self._up_ref = None        # weak reference to the Upsample2x that consumes this norm's output and nothing else does (pair_norm_upsample)
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state["_up_ref"] = None     # weak references do not travel (see Conv2d.__getstate__): a copy runs un-fused until paired again
+        return state
+
     def forward(self, x):
         if P.replay() is not None and self.fused_act != A.ACT_NONE:   # parity tests: activation un-fused so its mask can be replayed
             y = A.InstanceNormFn.apply(x, self.eps, A.ACT_NONE, self.slope)
             return A.ActFn.apply(y, 0 if self.fused_act == A.ACT_RELU else 1, self.slope)
+        up = my_upsample(self)
+        if up is not None and N.instnorm_up2_ok(x):
+            # the norm AND the bilinear x2 behind it in one launch; the Upsample2x module recognises the up-sampled tensor and passes it on
+            y2 = A.InstanceNormUpFn.apply(x, self.eps, self.fused_act, self.slope)
+            up.expect_upsampled(tuple(y2.shape))
+            return y2
         return A.InstanceNormFn.apply(x, self.eps, self.fused_act, self.slope)
 
 
@@ -339,10 +352,47 @@ def flush_counters(module):
 
 
 class Upsample2x(nn.Module):
-    """Interpolate(scale_factor=2, mode='bilinear', align_corners=True)"""
+    """Interpolate(scale_factor=2, mode='bilinear', align_corners=True).  In the decoders its input is the output of an instance norm
+    that nothing else reads (pair_norm_upsample): that norm's launch then writes the up-sampled map itself and announces it here --
+    the hand-over is structural, as Conv2d -> MaxPool2x2's (a shape announced by the producer, checked on arrival)."""
+    _upsampled_shape = None        # set by the producer when IT up-sampled: the shape of the tensor to pass through
+    _producer = None               # weak reference to that producer (an InstanceNorm2d, or the INSResBlock whose fused tail holds the norm)
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state["_producer"] = None
+        state["_upsampled_shape"] = None
+        return state
+
+    def expect_upsampled(self, shape):
+        self._upsampled_shape = shape
 
     def forward(self, x):
+        if self._upsampled_shape is not None:
+            want, self._upsampled_shape = self._upsampled_shape, None
+            if tuple(x.shape) != want:
+                raise RuntimeError("Upsample2x: the instance norm in front up-sampled in its own launch and announced %s, but a tensor of "
+                                   "shape %s arrived (a hook between the two modules?)" % (want, tuple(x.shape)))
+            return x
         return A.Upsample2xFn.apply(x)
+
+
+def my_upsample(producer):
+    """the Upsample2x paired with THIS producer object (pair_norm_upsample), or None; checked from both sides like Conv2d._my_pool, and
+    a stale announcement (a call that raised between producer and consumer) is cleared"""
+    ref = getattr(producer, "_up_ref", None)
+    up = ref() if ref is not None else None
+    if up is None or up._producer is None or up._producer() is not producer or os.environ.get("SCDA_NO_NORM_UP_FUSION"):
+        return None
+    up._upsampled_shape = None
+    return up
+
+
+def pair_norm_upsample(producer, up):
+    """declare that `up` (an Upsample2x) is the ONLY consumer of `producer`'s output (an InstanceNorm2d, or a module that runs one in a
+    fused tail): the producer may then write the up-sampled map itself"""
+    producer._up_ref = weakref.ref(up)
+    up._producer = weakref.ref(producer)
 
 
 class GlobalAvgPool(nn.Module):

@@ -1011,6 +1011,45 @@ def upsample2x_fwd(x):
     return y
 
 
+def instnorm_up2_ok(x):
+    """instance norm + the bilinear x2 behind it can run as one launch on this tensor (scda_instnorm_up2_supported + alignment)"""
+    return (x.dim() == 4 and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and aligned16(x)
+            and bool(lib().scda_instnorm_up2_supported(i32(x.shape[2]), i32(x.shape[3]))))
+
+
+def instnorm_up2_fwd(x, eps, act, slope):
+    """upsample2x(act(instance_norm(x))) in one launch -> (y2 [B, C, 2H, 2W], mean, rstd)"""
+    _req(x, "x")
+    B, C, H, W = x.shape
+    y2 = torch.empty(B, C, 2 * H, 2 * W, dtype=torch.float32, device=x.device)
+    mean = torch.empty(B * C, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(B * C, dtype=torch.float32, device=x.device)
+    _check(lib().scda_instnorm_up2_fwd_hip(_p(x), _p(y2), _p(mean), _p(rstd), i32(B * C), i32(H), i32(W), f32(eps), i32(act), f32(slope),
+                                           _stream()), "scda_instnorm_up2_fwd_hip")
+    return y2, mean, rstd
+
+
+def instnorm_drop_add_up2_fwd(x, residual, eps, p, seed):
+    """upsample2x(residual + dropout_{p,seed}(instance_norm(x))) in one launch -> (y2, mean, rstd)"""
+    _req(x, "x"); _req(residual, "residual")
+    if residual.shape != x.shape:
+        raise ValueError("residual must have the shape of x")
+    B, C, H, W = x.shape
+    y2 = torch.empty(B, C, 2 * H, 2 * W, dtype=torch.float32, device=x.device)
+    mean = torch.empty(B * C, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(B * C, dtype=torch.float32, device=x.device)
+    if torch.is_tensor(seed):     # a slot of a scda_amd.seeds.SeedArena (see instnorm_drop_add_fwd)
+        _req(seed, "seed", torch.int64)
+        _check(lib().scda_instnorm_drop_add_up2_fwd_dev_hip(_p(x), _p(residual), _p(y2), _p(mean), _p(rstd), i32(B * C), i32(H), i32(W),
+                                                            f32(eps), f32(p), _p(seed), f32(1.0 / (1.0 - p)), _stream()),
+               "scda_instnorm_drop_add_up2_fwd_dev_hip")
+        return y2, mean, rstd
+    _check(lib().scda_instnorm_drop_add_up2_fwd_hip(_p(x), _p(residual), _p(y2), _p(mean), _p(rstd), i32(B * C), i32(H), i32(W), f32(eps),
+                                                    f32(p), u64(seed & 0xFFFFFFFFFFFFFFFF), f32(1.0 / (1.0 - p)), _stream()),
+           "scda_instnorm_drop_add_up2_fwd_hip")
+    return y2, mean, rstd
+
+
 def upsample2x_bwd(dy):
     _req(dy, "dy")
     B, C, OH, OW = dy.shape

@@ -443,3 +443,95 @@ def test_ins_res_block_uses_fused_tail(cuda, monkeypatch):
         blk.zero_grad()
     a, b = outs
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and all(torch.equal(u, v) for u, v in zip(a[2], b[2])) and a[3] == b[3]
+
+
+@pytest.mark.parametrize("act", [0, 1, 2])
+@pytest.mark.parametrize("shape", [(4, 128, 64, 64), (4, 64, 128, 128), (2, 3, 32, 128), (1, 2, 128, 32)])
+def test_norm_and_upsample_in_one_launch_equals_two(cuda, shape, act):
+    """Upsample2x(act(InstanceNorm(x))) as ONE launch (autograd_ops.InstanceNormUpFn: the normalised plane goes to LDS, the same
+    workgroup writes the 2H x 2W map) against InstanceNormFn -> Upsample2xFn: output and gradient bit for bit"""
+    from scda_amd import autograd_ops as A, native as N
+    g = gen(93)
+    x = torch.randn(*shape, generator=g).to(cuda)
+    dy = torch.randn(shape[0], shape[1], 2 * shape[2], 2 * shape[3], generator=g).to(cuda)
+    assert N.instnorm_up2_ok(x)
+    x1 = x.clone().requires_grad_()
+    y1 = A.InstanceNormUpFn.apply(x1, 1e-5, act, 0.01); y1.backward(dy)
+    x2 = x.clone().requires_grad_()
+    y2 = A.Upsample2xFn.apply(A.InstanceNormFn.apply(x2, 1e-5, act, 0.01)); y2.backward(dy)
+    assert y1.shape == y2.shape and torch.equal(y1, y2) and torch.equal(x1.grad, x2.grad)
+
+
+@pytest.mark.parametrize("shape", [(4, 128, 64, 64), (2, 5, 128, 128)])
+def test_resblock_tail_and_upsample_in_one_launch_equals_two(cuda, shape):
+    """Upsample2x(x + Dropout(InstanceNorm(h))) as ONE launch (InstNormDropAddUpFn) against InstNormDropAddFn -> Upsample2xFn, with the
+    seed as an integer and as a device slot: outputs and both gradients bit for bit"""
+    from scda_amd import autograd_ops as A
+    g = gen(94)
+    h = torch.randn(*shape, generator=g).to(cuda); x = torch.randn(*shape, generator=g).to(cuda)
+    dy = torch.randn(shape[0], shape[1], 2 * shape[2], 2 * shape[3], generator=g).to(cuda)
+    p, seed = 0.5, 0x0FEDCBA987654321
+    for sd in (seed, torch.tensor([seed], dtype=torch.int64, device=cuda)):
+        h1, x1 = h.clone().requires_grad_(), x.clone().requires_grad_()
+        y1 = A.InstNormDropAddUpFn.apply(h1, x1, 1e-5, p, sd); y1.backward(dy)
+        h2, x2 = h.clone().requires_grad_(), x.clone().requires_grad_()
+        y2 = A.Upsample2xFn.apply(A.InstNormDropAddFn.apply(h2, x2, 1e-5, p, sd)); y2.backward(dy)
+        assert torch.equal(y1, y2) and torch.equal(h1.grad, h2.grad) and torch.equal(x1.grad, x2.grad)
+
+
+def test_norm_upsample_unsupported_shapes_fail_loudly(cuda):
+    from scda_amd import native as N
+    x = torch.randn(1, 2, 48, 48, device=cuda)
+    assert not N.instnorm_up2_ok(x)
+    with pytest.raises(RuntimeError, match="not supported"):
+        N.instnorm_up2_fwd(x, 1e-5, 0, 0.0)
+    x = torch.randn(1, 1, 64, 64 + 1, device=cuda)[..., 1:]       # contiguous-looking shape on an offset, unaligned view
+    assert not N.instnorm_up2_ok(x)
+
+
+def test_decoder_fuses_norm_upsample_pairs_with_identical_results(cuda, monkeypatch):
+    """a decoder branch (residual blocks -> two up-sampling blocks -> 1x1 -> tanh) with the norm + Interpolate pairs as one launch each
+    (common_net.pair_decoder_upsamples: both Interpolates have a paired producer) and with SCDA_NO_NORM_UP_FUSION=1: same seed draws,
+    outputs, input gradient and every parameter gradient bit for bit; a deep copy runs un-fused until paired again"""
+    import copy
+    from scda_amd import layers as L
+    from scda_amd.dropin.models.faster_rcnn.faster_rcnn_adver_expansion_reweight_cluster import GAN_decoder_AE
+    torch.manual_seed(5)
+    dec = GAN_decoder_AE({'input_dim_b': 3, 'ch': 16, 'n_gen_res_blk': 2, 'n_gen_front_blk': 3, 'res_dropout_ratio': 0.5}).to(cuda).train()
+    ups = [m for m in dec.decode_A.modules() if isinstance(m, L.Upsample2x)]
+    assert len(ups) == 2 and all(u._producer is not None and u._producer() is not None for u in ups)
+    xa = torch.randn(4, 16, 64 * 64, generator=gen(95)).to(cuda); xb = torch.randn(4, 16, 64 * 64, generator=gen(96)).to(cuda)
+    calls = []
+    real = L.A.Upsample2xFn.apply
+    monkeypatch.setattr(L.A.Upsample2xFn, "apply", staticmethod(lambda *a: (calls.append(1), real(*a))[1]))
+    outs = []
+    for off in ("", "1"):
+        if off:
+            monkeypatch.setenv("SCDA_NO_NORM_UP_FUSION", off)
+        torch.manual_seed(11)
+        a, b = xa.clone().requires_grad_(), xb.clone().requires_grad_()
+        n0 = len(calls)
+        ya, yb = dec(a, b)
+        outs.append((len(calls) - n0, ya.detach().clone(), yb.detach().clone()))
+        (ya.square().sum() + yb.square().sum()).backward()
+        outs[-1] += (a.grad.clone(), b.grad.clone(), [p.grad.clone() for p in dec.parameters()], torch.rand(1).item())
+        dec.zero_grad()
+    f, u = outs
+    assert f[0] == 0 and u[0] == 4, (f[0], u[0])         # fused: no stand-alone bilinear launch; un-fused: two per branch
+    assert ya.shape == (4, 3, 256, 256)
+    assert torch.equal(f[1], u[1]) and torch.equal(f[2], u[2]) and torch.equal(f[3], u[3]) and torch.equal(f[4], u[4])
+    assert all(torch.equal(p, q) for p, q in zip(f[5], u[5])) and f[6] == u[6]
+    monkeypatch.delenv("SCDA_NO_NORM_UP_FUSION")
+    clone = copy.deepcopy(dec)
+    n0 = len(calls)
+    clone(xa, xb)
+    assert len(calls) - n0 == 4          # weak references do not travel: the copy is correct and un-fused
+
+
+def test_upsample_rejects_a_tensor_that_is_not_the_announced_one(cuda):
+    from scda_amd import layers as L
+    up = L.Upsample2x()
+    up.expect_upsampled((1, 2, 8, 8))
+    with pytest.raises(RuntimeError, match="announced"):
+        up(torch.zeros(1, 2, 4, 4, device=cuda))
+    assert up(torch.ones(1, 2, 4, 4, device=cuda)).shape == (1, 2, 8, 8)       # the announcement is consumed either way
