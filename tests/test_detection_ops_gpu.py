@@ -138,6 +138,30 @@ def test_roi_pool_fwd_bwd_bit_exact(cuda, shape, R):
         np.testing.assert_array_equal(g, orc.roi_pool_bwd(top, ea, rois, shape, 7, 7, 1 / 16.))
 
 
+@pytest.mark.parametrize("step", [2, 3, 5])
+def test_roi_pool_bwd_on_shared_maxima(cuda, step):
+    """the ordered-scatter backward where bins share their maxima all over the place: a feature map with one dominant pixel every
+    `step` rows and columns, RoIs from 1 to 20 feature pixels a side (up to 28 bins of a RoI on one pixel) -- bit-identical to the
+    oracle's (roi, ph, pw)-ordered sum, on planes the scatter kernel takes and on one that is too large for its LDS (gather kernel)"""
+    from scda_amd import native
+    rs = np.random.RandomState(100 + step)
+    for shape, R in (((1, 16, 32, 64), 300), ((2, 4, 24, 40), 200), ((1, 2, 100, 120), 150)):
+        B, C, H, W = shape
+        feat = (0.01 * rs.randn(*shape)).astype(np.float32)
+        feat[:, :, ::step, ::step] += 10.0 + rs.rand(B, C, (H + step - 1) // step, (W + step - 1) // step).astype(np.float32)
+        rois = np.zeros((R, 5), np.float32)
+        rois[:, 0] = rs.randint(0, B, R)
+        wd = rs.randint(1, 21, R) * 16.0; ht = rs.randint(1, 21, R) * 16.0
+        rois[:, 1] = rs.randint(-2, W - 1, R) * 16.0 + rs.randint(0, 16, R); rois[:, 2] = rs.randint(-2, H - 1, R) * 16.0 + rs.randint(0, 16, R)
+        rois[:, 3] = rois[:, 1] + wd - 1; rois[:, 4] = rois[:, 2] + ht - 1
+        eo, ea = orc.roi_pool_fwd(feat, rois, 7, 7, 1 / 16.)
+        shared = sum(len(a) - len(np.unique(a)) for a in (ea[r, c].ravel()[ea[r, c].ravel() >= 0] for r in range(R) for c in range(C)))
+        assert shared > R * C, shared          # the case under test occurs: more than one shared maximum per (RoI, channel) on average
+        top = rs.randn(*eo.shape).astype(np.float32)
+        g = native.roi_pool_bwd(dev(top, cuda), dev(ea, cuda), dev(rois, cuda), shape, 7, 7, 1 / 16.).cpu().numpy()
+        np.testing.assert_array_equal(g, orc.roi_pool_bwd_scatter(top, ea, shape, 7, 7))
+
+
 def test_roi_pool_equals_reference_roi_pool_py(cuda, golden_dir):
     """scda_roi_pool_fwd_hip against outputs of the REFERENCE's own roi_pool_py.py (tests/golden/roi_pool_ref.npz), bit for bit, at
     [1,512,32,64] x 512 RoIs and two ragged shapes; the argmax contract (first maximum in scan order, -1 for empty bins) derived from
