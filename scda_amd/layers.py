@@ -255,7 +255,6 @@ class InstanceNorm2d(nn.Module):
         self.eps = eps
         self.fused_act = fused_act
         self.slope = slope
-
         self._up_ref = None        # weak reference to the Upsample2x that consumes this norm's output and nothing else does (pair_norm_upsample)
 
     def __getstate__(self):

@@ -48,3 +48,43 @@ def test_a_stale_announcement_is_cleared_by_the_next_unfused_call():
     except Exception:
         pass
     assert seq[1]._pooled_shape is None            # ... but the announcement is gone before anything else happens
+
+
+def _decoder_branch():
+    from scda_amd.dropin.models.faster_rcnn import common_net as cn
+    seq = nn.Sequential(cn.LinUnsRes_cluster(16, 64, 64, 4), cn.INSResBlock(16, 16, dropout=0.5), cn.INSResBlock(16, 16, dropout=0.5),
+                        cn.LeakyReLUConvTranspose2d_2(16, 8, kernel_size=3, stride=1, padding=1, output_padding=0),
+                        cn.LeakyReLUConvTranspose2d_2(8, 4, kernel_size=3, stride=1, padding=1, output_padding=0))
+    return cn, seq
+
+
+def test_decoder_pairs_each_interpolate_with_the_norm_in_front():
+    """common_net.pair_decoder_upsamples: the first up-sampling block's Interpolate is fed by the LAST residual block (whose fused tail
+    holds the norm), the second one's by the first block's instance norm; residual blocks that feed another residual block stay unpaired"""
+    from scda_amd import layers as L
+    cn, seq = _decoder_branch()
+    assert cn.pair_decoder_upsamples(seq) == 2
+    up1, up2 = seq[3].model[0].up, seq[4].model[0].up
+    assert L.my_upsample(seq[2]) is up1 and L.my_upsample(seq[3].model[2]) is up2
+    assert L.my_upsample(seq[1]) is None and L.my_upsample(seq[4].model[2]) is None
+    plain = cn.INSResBlock(16, 16, dropout=0.0)            # no dropout: no fused tail, nothing to pair
+    seq2 = nn.Sequential(plain, cn.LeakyReLUConvTranspose2d_2(16, 8, kernel_size=3, stride=1, padding=1, output_padding=0))
+    assert cn.pair_decoder_upsamples(seq2) == 0 and L.my_upsample(plain) is None
+
+
+def test_norm_upsample_pairing_under_copies_and_the_off_switch(monkeypatch):
+    from scda_amd import layers as L
+    cn, seq = _decoder_branch()
+    cn.pair_decoder_upsamples(seq)
+    up1 = seq[3].model[0].up
+    up1.expect_upsampled((1, 2, 3, 4))
+    assert L.my_upsample(seq[2]) is up1 and up1._upsampled_shape is None      # asking for the pair clears an announcement left behind
+    dup = copy.deepcopy(seq)
+    assert L.my_upsample(dup[2]) is None and dup[3].model[0].up._producer is None and L.my_upsample(seq[2]) is up1
+    assert cn.pair_decoder_upsamples(dup) == 2 and L.my_upsample(dup[2]) is dup[3].model[0].up
+    again = pickle.loads(pickle.dumps(seq))
+    assert L.my_upsample(again[2]) is None and L.my_upsample(again[3].model[2]) is None
+    replica = copy.copy(seq[2]); replica.__dict__ = dict(seq[2].__dict__)     # a shallow replica must not announce to the original's module
+    assert replica._up_ref is not None and L.my_upsample(replica) is None
+    monkeypatch.setenv("SCDA_NO_NORM_UP_FUSION", "1")
+    assert L.my_upsample(seq[2]) is None
