@@ -409,6 +409,16 @@ int scda_instnorm_drop_add_up2_fwd_hip(const float *x, const float *residual, fl
                                        int IW, float eps, float p, uint64_t seed, float scale /* 1 / (1 - p) */, void *stream);
 int scda_instnorm_drop_add_up2_fwd_dev_hip(const float *x, const float *residual, float *y2, float *mean, float *rstd, int planes,
                                            int IH, int IW, float eps, float p, const uint64_t *seed_dev, float scale, void *stream);
+/* ... and their backward in one launch: the bilinear gather of dy2 [planes, 2 IH, 2 IW] feeds the norm's gradient in registers;
+ * dresidual [planes, IH, IW] = the gathered gradient itself (the residual input's gradient of the tail form).  Bit-identical to
+ * scda_upsample2x_bwd_hip followed by scda_instnorm_bwd_hip / scda_instnorm_drop_bwd_hip. */
+int scda_instnorm_up2_bwd_hip(const float *dy2, const float *x, const float *mean, const float *rstd, float *dx, int planes, int IH,
+                              int IW, int act, float slope, void *stream);
+int scda_instnorm_drop_up2_bwd_hip(const float *dy2, const float *x, const float *mean, const float *rstd, float *dx, float *dresidual,
+                                   int planes, int IH, int IW, float p, uint64_t seed, float scale, void *stream);
+int scda_instnorm_drop_up2_bwd_dev_hip(const float *dy2, const float *x, const float *mean, const float *rstd, float *dx,
+                                       float *dresidual, int planes, int IH, int IW, float p, const uint64_t *seed_dev, float scale,
+                                       void *stream);
 /* F.binary_cross_entropy(p, t), mean : tools/faster_rcnn_train_val.py:584-600,627-628,675-687,723-732 */
 int scda_bce_fwd_hip(const float *p, const float *t, int n, float *out1, void *stream);
 int scda_bce_bwd_hip(const float *p, const float *t, int n, const float *grad_scalar, float *dp, void *stream);

@@ -4,6 +4,8 @@ PyTorch is plumbing here: it owns device memory, the stream and the backward
 graph walk; every forward/backward body below is one or more calls through the
 C ABI of libscda_ops.so.  No Function has a CPU branch.
 """
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -442,9 +444,9 @@ class InstNormDropAddFn(Function):
 
 
 class InstanceNormUpFn(Function):
-    """Upsample2x(act(InstanceNorm(x))) as ONE launch (N.instnorm_up2_fwd): the small normalised plane never reaches memory.  The
-    backward is the two existing kernels -- the bilinear gather, then the norm's gradient, which needs x / mean / rstd only.
-    Bit-identical to InstanceNormFn -> Upsample2xFn in both directions."""
+    """Upsample2x(act(InstanceNorm(x))) as ONE launch each way (N.instnorm_up2_fwd / instnorm_up2_bwd): the small normalised plane
+    never reaches memory, its gradient passes from the bilinear gather to the norm's backward in registers (which needs x / mean /
+    rstd only).  Bit-identical to InstanceNormFn -> Upsample2xFn in both directions."""
 
     @staticmethod
     def forward(ctx, x, eps, act, slope):
@@ -458,13 +460,16 @@ class InstanceNormUpFn(Function):
     def backward(ctx, dy2):
         x, mean, rstd = ctx.saved_tensors
         act, slope = ctx.cfg
-        return N.instnorm_bwd(N.upsample2x_bwd(_c(dy2)), x, mean, rstd, act, slope), None, None, None
+        dy2 = _c(dy2)
+        if N.aligned16(dy2) and not os.environ.get("SCDA_NO_NORM_UP_BWD_FUSION"):
+            return N.instnorm_up2_bwd(dy2, x, mean, rstd, act, slope), None, None, None      # the gather and the norm's gradient in one launch
+        return N.instnorm_bwd(N.upsample2x_bwd(dy2), x, mean, rstd, act, slope), None, None, None
 
 
 class InstNormDropAddUpFn(Function):
     """Upsample2x(residual + Dropout_p(InstanceNorm(x))): the tail of the LAST INSResBlock of a decoder and the Interpolate of the
-    up-sampling block behind it as one launch; backward as InstNormDropAddFn's behind the bilinear gather.  Bit-identical to
-    InstNormDropAddFn -> Upsample2xFn."""
+    up-sampling block behind it as one launch each way (the backward also writes the gathered gradient: it is the residual input's).
+    Bit-identical to InstNormDropAddFn -> Upsample2xFn."""
 
     @staticmethod
     def forward(ctx, x, residual, eps, p, seed):
@@ -478,7 +483,11 @@ class InstNormDropAddUpFn(Function):
     def backward(ctx, dy2):
         x, mean, rstd = ctx.saved_tensors
         p, seed = ctx.cfg
-        dy = N.upsample2x_bwd(_c(dy2))
+        dy2 = _c(dy2)
+        if ctx.needs_input_grad[0] and N.aligned16(dy2) and not os.environ.get("SCDA_NO_NORM_UP_BWD_FUSION"):
+            dx, dy = N.instnorm_drop_up2_bwd(dy2, x, mean, rstd, p, seed)
+            return dx, (dy if ctx.needs_input_grad[1] else None), None, None, None
+        dy = N.upsample2x_bwd(dy2)
         dx = N.instnorm_drop_bwd(dy, x, mean, rstd, p, seed) if ctx.needs_input_grad[0] else None
         return dx, (dy if ctx.needs_input_grad[1] else None), None, None, None
 

@@ -489,15 +489,13 @@ __global__ __launch_bounds__(1024) void instnorm_fwd_kernel(const float *__restr
 // dx = rstd * (g - mean(g) - xh * mean(g * xh)),  g = dy gated by the fused activation, xh = (x - mean) * rstd.
 // VPT > 0: g (and, with CACHE_X, xh) stay in registers between the reduction and the output pass (VPT float4 each);
 // the 256x256 planes keep g only (64 VGPRs) and re-read x for the output pass.
-template <int VPT, bool CACHE_X>
-__global__ __launch_bounds__(1024) void instnorm_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ x,
-                                                            const float *__restrict__ mean_in,
-                                                            const float *__restrict__ rstd_in, float *__restrict__ dx,
-                                                            const int HW, const int act, const float slope, const DropTail dt) {
-    __shared__ float red[16];
-    const size_t base = (size_t)blockIdx.x * HW;
-    const float mean = mean_in[blockIdx.x], rstd = rstd_in[blockIdx.x];
-    const unsigned long long dseed = dt.seed_ptr ? *dt.seed_ptr : dt.seed;
+// The register-resident form (VPT float4 per thread) as a body two kernels share: instnorm_bwd_kernel reads the incoming gradient
+// from memory, instnorm_up2_bwd_kernel (behind the bilinear kernels) hands over the values it has just gathered.  `gload(j)` = the
+// thread's j-th float4 of dy (slot j * 1024 + threadIdx.x of the plane).
+template <int VPT, bool CACHE_X, class GLoad>
+__device__ __forceinline__ void instnorm_bwd_plane(const GLoad &gload, const float *__restrict__ x, const float mean, const float rstd,
+                                                   float *__restrict__ dx, const int HW, const int act, const float slope,
+                                                   const DropTail dt, const unsigned long long dseed, const size_t base, float *red) {
     auto drop = [&](float g, const size_t i) -> float {      // the fused dropout's gradient (see DropTail)
         if (!dt.on) return g;
         return mix_hash(dseed, (uint64_t)i) >= dt.thr ? g * dt.scale : 0.f;
@@ -507,38 +505,60 @@ __global__ __launch_bounds__(1024) void instnorm_bwd_kernel(const float *__restr
         if (act == 2) return xh > 0.f ? g : g * slope;
         return g;
     };
-    if (VPT > 0) {
-        const float4 *x4 = reinterpret_cast<const float4 *>(x + base), *g4 = reinterpret_cast<const float4 *>(dy + base);
-        float4 xc[(VPT > 0 && CACHE_X) ? VPT : 1], g[VPT > 0 ? VPT : 1];
-        auto norm4 = [&](const float4 xv) -> float4 {
-            float4 h;
-            h.x = (xv.x - mean) * rstd; h.y = (xv.y - mean) * rstd; h.z = (xv.z - mean) * rstd; h.w = (xv.w - mean) * rstd;
-            return h;
-        };
-        float s1 = 0.f, s2 = 0.f;
+    const float4 *x4 = reinterpret_cast<const float4 *>(x + base);
+    float4 xc[CACHE_X ? VPT : 1], g[VPT];
+    auto norm4 = [&](const float4 xv) -> float4 {
+        float4 h;
+        h.x = (xv.x - mean) * rstd; h.y = (xv.y - mean) * rstd; h.z = (xv.z - mean) * rstd; h.w = (xv.w - mean) * rstd;
+        return h;
+    };
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int j = 0; j < VPT; ++j) {
-            const float4 xh = norm4(x4[j * 1024 + threadIdx.x]);
-            float4 gv = g4[j * 1024 + threadIdx.x];
-            const size_t i0 = base + 4 * (size_t)(j * 1024 + threadIdx.x);
-            gv.x = drop(gv.x, i0); gv.y = drop(gv.y, i0 + 1); gv.z = drop(gv.z, i0 + 2); gv.w = drop(gv.w, i0 + 3);
-            if (CACHE_X) xc[j] = xh;
-            g[j].x = gate(gv.x, xh.x); g[j].y = gate(gv.y, xh.y); g[j].z = gate(gv.z, xh.z); g[j].w = gate(gv.w, xh.w);
-            s1 += (g[j].x + g[j].y) + (g[j].z + g[j].w);
-            s2 += (g[j].x * xh.x + g[j].y * xh.y) + (g[j].z * xh.z + g[j].w * xh.w);
-        }
-        const float m1 = block_sum(s1, red) / (float)HW;
-        const float m2 = block_sum(s2, red) / (float)HW;
-        float4 *d4 = reinterpret_cast<float4 *>(dx + base);
+    for (int j = 0; j < VPT; ++j) {
+        const float4 xh = norm4(x4[j * 1024 + threadIdx.x]);
+        float4 gv = gload(j);
+        const size_t i0 = base + 4 * (size_t)(j * 1024 + threadIdx.x);
+        gv.x = drop(gv.x, i0); gv.y = drop(gv.y, i0 + 1); gv.z = drop(gv.z, i0 + 2); gv.w = drop(gv.w, i0 + 3);
+        if (CACHE_X) xc[j] = xh;
+        g[j].x = gate(gv.x, xh.x); g[j].y = gate(gv.y, xh.y); g[j].z = gate(gv.z, xh.z); g[j].w = gate(gv.w, xh.w);
+        s1 += (g[j].x + g[j].y) + (g[j].z + g[j].w);
+        s2 += (g[j].x * xh.x + g[j].y * xh.y) + (g[j].z * xh.z + g[j].w * xh.w);
+    }
+    const float m1 = block_sum(s1, red) / (float)HW;
+    const float m2 = block_sum(s2, red) / (float)HW;
+    float4 *d4 = reinterpret_cast<float4 *>(dx + base);
 #pragma unroll
-        for (int j = 0; j < VPT; ++j) {
-            const float4 xh = CACHE_X ? xc[j] : norm4(x4[j * 1024 + threadIdx.x]);
-            float4 o;
-            o.x = rstd * (g[j].x - m1 - xh.x * m2); o.y = rstd * (g[j].y - m1 - xh.y * m2);
-            o.z = rstd * (g[j].z - m1 - xh.z * m2); o.w = rstd * (g[j].w - m1 - xh.w * m2);
-            d4[j * 1024 + threadIdx.x] = o;
-        }
+    for (int j = 0; j < VPT; ++j) {
+        const float4 xh = CACHE_X ? xc[j] : norm4(x4[j * 1024 + threadIdx.x]);
+        float4 o;
+        o.x = rstd * (g[j].x - m1 - xh.x * m2); o.y = rstd * (g[j].y - m1 - xh.y * m2);
+        o.z = rstd * (g[j].z - m1 - xh.z * m2); o.w = rstd * (g[j].w - m1 - xh.w * m2);
+        d4[j * 1024 + threadIdx.x] = o;
+    }
+}
+
+template <int VPT, bool CACHE_X>
+__global__ __launch_bounds__(1024) void instnorm_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ x,
+                                                            const float *__restrict__ mean_in,
+                                                            const float *__restrict__ rstd_in, float *__restrict__ dx,
+                                                            const int HW, const int act, const float slope, const DropTail dt) {
+    __shared__ float red[16];
+    const size_t base = (size_t)blockIdx.x * HW;
+    const float mean = mean_in[blockIdx.x], rstd = rstd_in[blockIdx.x];
+    const unsigned long long dseed = dt.seed_ptr ? *dt.seed_ptr : dt.seed;
+    if constexpr (VPT > 0) {
+        const float4 *g4 = reinterpret_cast<const float4 *>(dy + base);
+        instnorm_bwd_plane<VPT, CACHE_X>([&](const int j) { return g4[j * 1024 + threadIdx.x]; }, x, mean, rstd, dx, HW, act, slope, dt, dseed, base, red);
     } else {
+        auto drop = [&](float g, const size_t i) -> float {
+            if (!dt.on) return g;
+            return mix_hash(dseed, (uint64_t)i) >= dt.thr ? g * dt.scale : 0.f;
+        };
+        auto gate = [&](float g, float xh) -> float {
+            if (act == 1) return xh > 0.f ? g : 0.f;
+            if (act == 2) return xh > 0.f ? g : g * slope;
+            return g;
+        };
         float s1 = 0.f, s2 = 0.f;
         for (int i = threadIdx.x; i < HW; i += blockDim.x) {
             const float xh = (x[base + i] - mean) * rstd;
@@ -945,6 +965,15 @@ __device__ __forceinline__ float up2_blend(const float ly0, const float ly1, con
     return __fmaf_rn(ly0, top, __fmul_rn(ly1, bot));
 }
 
+// the weight with which output row / column o enters input row / column i (0: it does not), and the gather's accumulation step --
+// spelled out for the same reason: upsample2_bwd_kernel, upsample2_bwd_rows_kernel and instnorm_up2_bwd_kernel agree bit for bit
+__device__ __forceinline__ float up2_weight(const float s, const int o, const int i, const int In) {
+    int i0, i1;
+    float l0, l1;
+    up2_taps(s, o, In, i0, i1, l0, l1);
+    return __fadd_rn(i0 == i ? l0 : 0.f, i1 == i ? l1 : 0.f);
+}
+
 template <int ROWS>
 __global__ __launch_bounds__(256) void upsample2_fwd_kernel(const float *__restrict__ x, float *__restrict__ y,
                                                             const int IH, const int IW, const int OH, const int OW,
@@ -1083,11 +1112,8 @@ __global__ __launch_bounds__(256) void upsample2_bwd_kernel(const float *__restr
     for (int ox = threadIdx.x; ox < OW; ox += blockDim.x) {
         float acc = 0.f;
         for (int oy = ylo; oy <= yhi; ++oy) {
-            const float fy = sh * (float)oy;
-            const int y0 = (int)fy, y1 = y0 + (y0 < IH - 1 ? 1 : 0);
-            const float ly1 = fminf(fmaxf(fy - (float)y0, 0.f), 1.f), ly0 = 1.f - ly1;
-            const float wy = (y0 == iy ? ly0 : 0.f) + (y1 == iy ? ly1 : 0.f);
-            if (wy != 0.f) acc += wy * g[(size_t)oy * OW + ox];
+            const float wy = up2_weight(sh, oy, iy, IH);
+            if (wy != 0.f) acc = __fmaf_rn(wy, g[(size_t)oy * OW + ox], acc);
         }
         rowbuf[ox] = acc;
     }
@@ -1097,11 +1123,8 @@ __global__ __launch_bounds__(256) void upsample2_bwd_kernel(const float *__restr
         up2_candidates(ix, IW, OW, sw, xlo, xhi);
         float acc = 0.f;
         for (int ox = xlo; ox <= xhi; ++ox) {
-            const float fx = sw * (float)ox;
-            const int x0 = (int)fx, x1 = x0 + (x0 < IW - 1 ? 1 : 0);
-            const float lx1 = fminf(fmaxf(fx - (float)x0, 0.f), 1.f), lx0 = 1.f - lx1;
-            const float wx = (x0 == ix ? lx0 : 0.f) + (x1 == ix ? lx1 : 0.f);
-            if (wx != 0.f) acc += wx * rowbuf[ox];
+            const float wx = up2_weight(sw, ox, ix, IW);
+            if (wx != 0.f) acc = __fmaf_rn(wx, rowbuf[ox], acc);
         }
         dx[(size_t)row * IW + ix] = acc;
     }
@@ -1131,13 +1154,10 @@ __global__ __launch_bounds__(256) void upsample2_bwd_rows_kernel(const float *__
         up2_candidates(iy, IH, OH, sh, ylo, yhi);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int oy = ylo; oy <= yhi; ++oy) {
-            const float fy = sh * (float)oy;
-            const int y0 = (int)fy, y1 = y0 + (y0 < IH - 1 ? 1 : 0);
-            const float ly1 = fminf(fmaxf(fy - (float)y0, 0.f), 1.f), ly0 = 1.f - ly1;
-            const float wy = (y0 == iy ? ly0 : 0.f) + (y1 == iy ? ly1 : 0.f);
+            const float wy = up2_weight(sh, oy, iy, IH);
             if (wy != 0.f) {
                 const float4 v = *reinterpret_cast<const float4 *>(g + (size_t)oy * OW + q * 4);
-                acc.x += wy * v.x; acc.y += wy * v.y; acc.z += wy * v.z; acc.w += wy * v.w;
+                acc.x = __fmaf_rn(wy, v.x, acc.x); acc.y = __fmaf_rn(wy, v.y, acc.y); acc.z = __fmaf_rn(wy, v.z, acc.z); acc.w = __fmaf_rn(wy, v.w, acc.w);
             }
         }
         *reinterpret_cast<float4 *>(rowbuf + rr * OW + q * 4) = acc;
@@ -1150,14 +1170,67 @@ __global__ __launch_bounds__(256) void upsample2_bwd_rows_kernel(const float *__
         const float *rb = rowbuf + rr * OW;
         float acc = 0.f;
         for (int ox = xlo; ox <= xhi; ++ox) {
-            const float fx = sw * (float)ox;
-            const int x0 = (int)fx, x1 = x0 + (x0 < IW - 1 ? 1 : 0);
-            const float lx1 = fminf(fmaxf(fx - (float)x0, 0.f), 1.f), lx0 = 1.f - lx1;
-            const float wx = (x0 == ix ? lx0 : 0.f) + (x1 == ix ? lx1 : 0.f);
-            if (wx != 0.f) acc += wx * rb[ox];
+            const float wx = up2_weight(sw, ox, ix, IW);
+            if (wx != 0.f) acc = __fmaf_rn(wx, rb[ox], acc);
         }
         dx[(size_t)(row0 + rr) * IW + ix] = acc;
     }
+}
+
+// The backward of instnorm_up2_fwd_kernel in one launch: the bilinear gather of the 2H x 2W gradient (pass A: output rows into an
+// LDS block [IH][2 IW], as upsample2_bwd_rows_kernel for the whole plane; pass B: every thread gathers the four consecutive columns
+// of each of ITS float4 slots) hands the small plane's gradient to the norm's backward in registers (instnorm_bwd_plane); with
+// `dsmall` it is also written out (the residual input's gradient of the dropout-and-add tail).  Same values as the two launches.
+template <int VPT>
+__global__ __launch_bounds__(1024) void instnorm_up2_bwd_kernel(const float *__restrict__ dy2, const float *__restrict__ x,
+                                                                const float *__restrict__ mean_in, const float *__restrict__ rstd_in,
+                                                                float *__restrict__ dx, float *__restrict__ dsmall, const int IH,
+                                                                const int IW, const int act, const float slope, const DropTail dt,
+                                                                const float sh, const float sw) {
+    constexpr int HW = VPT * 4096;
+    __shared__ float red[16];
+    __shared__ __attribute__((aligned(16))) float inter[2 * HW];        // [IH][OW]
+    const int OH = 2 * IH, OW = 2 * IW, q_per_row = OW >> 2;
+    const size_t base = (size_t)blockIdx.x * HW;
+    const float *g = dy2 + base * 4;
+    for (int i = threadIdx.x; i < IH * q_per_row; i += 1024) {
+        const int iy = i / q_per_row, q = i - iy * q_per_row;
+        int ylo, yhi;
+        up2_candidates(iy, IH, OH, sh, ylo, yhi);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int oy = ylo; oy <= yhi; ++oy) {
+            const float wy = up2_weight(sh, oy, iy, IH);
+            if (wy != 0.f) {
+                const float4 v = *reinterpret_cast<const float4 *>(g + (size_t)oy * OW + q * 4);
+                acc.x = __fmaf_rn(wy, v.x, acc.x); acc.y = __fmaf_rn(wy, v.y, acc.y); acc.z = __fmaf_rn(wy, v.z, acc.z); acc.w = __fmaf_rn(wy, v.w, acc.w);
+            }
+        }
+        *reinterpret_cast<float4 *>(inter + iy * OW + q * 4) = acc;
+    }
+    __syncthreads();
+    float4 gs[VPT];
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+        const int idx = 4 * (j * 1024 + (int)threadIdx.x), iy = idx / IW, ix0 = idx - iy * IW;
+        const float *rb = inter + iy * OW;
+        float r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int xlo, xhi;
+            up2_candidates(ix0 + k, IW, OW, sw, xlo, xhi);
+            float acc = 0.f;
+            for (int ox = xlo; ox <= xhi; ++ox) {
+                const float wx = up2_weight(sw, ox, ix0 + k, IW);
+                if (wx != 0.f) acc = __fmaf_rn(wx, rb[ox], acc);
+            }
+            r[k] = acc;
+        }
+        gs[j] = make_float4(r[0], r[1], r[2], r[3]);
+        if (dsmall) reinterpret_cast<float4 *>(dsmall + base)[j * 1024 + threadIdx.x] = gs[j];
+    }
+    const float mean = mean_in[blockIdx.x], rstd = rstd_in[blockIdx.x];
+    const unsigned long long dseed = dt.seed_ptr ? *dt.seed_ptr : dt.seed;
+    instnorm_bwd_plane<VPT, true>([&](const int j) { return gs[j]; }, x, mean, rstd, dx, HW, act, slope, dt, dseed, base, red);
 }
 
 // ------------------------------------------------------------- BCE ----------
@@ -1724,6 +1797,41 @@ SCDA_API int scda_instnorm_drop_add_up2_fwd_dev_hip(const float *x, const float 
     NN_CHECK(x && residual && y2 && mean && rstd && seed_dev && planes > 0 && p >= 0.f && p < 1.f, "scda_instnorm_drop_add_up2_fwd_dev_hip")
     return instnorm_up2_launch(x, y2, mean, rstd, planes, IH, IW, eps, 0, 0.f, DropTail{residual, drop_threshold(p), 0ull, scale, 1, (const unsigned long long *)seed_dev}, stream,
                                "scda_instnorm_drop_add_up2_fwd_dev_hip");
+}
+
+static int instnorm_up2_bwd_launch(const float *dy2, const float *x, const float *mean, const float *rstd, float *dx, float *dsmall,
+                                   int planes, int IH, int IW, int act, float slope, const DropTail dt, void *stream, const char *who) {
+    if (!scda_instnorm_up2_supported(IH, IW)) { set_error("%s: planes of %d x %d are not supported (scda_instnorm_up2_supported)", who, IH, IW); return SCDA_EINVAL; }
+    if (((((uintptr_t)dy2) | ((uintptr_t)x) | ((uintptr_t)dx) | ((uintptr_t)dsmall)) & 15) != 0) { set_error("%s: dy2, x, dx and the residual's gradient must be 16-byte aligned", who); return SCDA_EINVAL; }
+    const float sh = up_scale(IH, 2 * IH), sw = up_scale(IW, 2 * IW);
+    if ((long long)IH * IW == 4096)
+        hipLaunchKernelGGL(instnorm_up2_bwd_kernel<1>, dim3(planes), dim3(1024), 0, as_stream(stream), dy2, x, mean, rstd, dx, dsmall, IH, IW, act, slope, dt, sh, sw);
+    else
+        hipLaunchKernelGGL(instnorm_up2_bwd_kernel<4>, dim3(planes), dim3(1024), 0, as_stream(stream), dy2, x, mean, rstd, dx, dsmall, IH, IW, act, slope, dt, sh, sw);
+    return launch_status("instnorm_up2_bwd_kernel");
+}
+
+SCDA_API int scda_instnorm_up2_bwd_hip(const float *dy2, const float *x, const float *mean, const float *rstd, float *dx, int planes,
+                                       int IH, int IW, int act, float slope, void *stream) {
+    NN_CHECK(dy2 && x && mean && rstd && dx && planes > 0, "scda_instnorm_up2_bwd_hip")
+    return instnorm_up2_bwd_launch(dy2, x, mean, rstd, dx, nullptr, planes, IH, IW, act, slope, DropTail{nullptr, 0u, 0ull, 1.f, 0, nullptr}, stream,
+                                   "scda_instnorm_up2_bwd_hip");
+}
+
+SCDA_API int scda_instnorm_drop_up2_bwd_hip(const float *dy2, const float *x, const float *mean, const float *rstd, float *dx,
+                                            float *dresidual, int planes, int IH, int IW, float p, uint64_t seed, float scale, void *stream) {
+    NN_CHECK(dy2 && x && mean && rstd && dx && dresidual && planes > 0 && p >= 0.f && p < 1.f, "scda_instnorm_drop_up2_bwd_hip")
+    return instnorm_up2_bwd_launch(dy2, x, mean, rstd, dx, dresidual, planes, IH, IW, 0, 0.f, DropTail{nullptr, drop_threshold(p), seed, scale, 1, nullptr},
+                                   stream, "scda_instnorm_drop_up2_bwd_hip");
+}
+
+SCDA_API int scda_instnorm_drop_up2_bwd_dev_hip(const float *dy2, const float *x, const float *mean, const float *rstd, float *dx,
+                                                float *dresidual, int planes, int IH, int IW, float p, const uint64_t *seed_dev, float scale,
+                                                void *stream) {
+    NN_CHECK(dy2 && x && mean && rstd && dx && dresidual && seed_dev && planes > 0 && p >= 0.f && p < 1.f, "scda_instnorm_drop_up2_bwd_dev_hip")
+    return instnorm_up2_bwd_launch(dy2, x, mean, rstd, dx, dresidual, planes, IH, IW, 0, 0.f,
+                                   DropTail{nullptr, drop_threshold(p), 0ull, scale, 1, (const unsigned long long *)seed_dev}, stream,
+                                   "scda_instnorm_drop_up2_bwd_dev_hip");
 }
 
 SCDA_API int scda_bce_fwd_hip(const float *p, const float *t, int n, float *out1, void *stream) {

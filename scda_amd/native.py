@@ -1050,6 +1050,31 @@ def instnorm_drop_add_up2_fwd(x, residual, eps, p, seed):
     return y2, mean, rstd
 
 
+def instnorm_up2_bwd(dy2, x, mean, rstd, act, slope):
+    """gradient of instnorm_up2_fwd w.r.t. x: the bilinear gather and the norm's backward in one launch"""
+    _req(dy2, "dy2"); _req(x, "x")
+    B, C, H, W = x.shape
+    dx = torch.empty_like(x)
+    _check(lib().scda_instnorm_up2_bwd_hip(_p(dy2), _p(x), _p(mean), _p(rstd), _p(dx), i32(B * C), i32(H), i32(W), i32(act), f32(slope),
+                                           _stream()), "scda_instnorm_up2_bwd_hip")
+    return dx
+
+
+def instnorm_drop_up2_bwd(dy2, x, mean, rstd, p, seed):
+    """gradients of instnorm_drop_add_up2_fwd -> (dx, dresidual): dresidual = the gathered gradient of the small plane"""
+    _req(dy2, "dy2"); _req(x, "x")
+    B, C, H, W = x.shape
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x)
+    if torch.is_tensor(seed):
+        _check(lib().scda_instnorm_drop_up2_bwd_dev_hip(_p(dy2), _p(x), _p(mean), _p(rstd), _p(dx), _p(dres), i32(B * C), i32(H), i32(W), f32(p),
+                                                        _p(seed), f32(1.0 / (1.0 - p)), _stream()), "scda_instnorm_drop_up2_bwd_dev_hip")
+        return dx, dres
+    _check(lib().scda_instnorm_drop_up2_bwd_hip(_p(dy2), _p(x), _p(mean), _p(rstd), _p(dx), _p(dres), i32(B * C), i32(H), i32(W), f32(p),
+                                                u64(seed & 0xFFFFFFFFFFFFFFFF), f32(1.0 / (1.0 - p)), _stream()), "scda_instnorm_drop_up2_bwd_hip")
+    return dx, dres
+
+
 def upsample2x_bwd(dy):
     _req(dy, "dy")
     B, C, OH, OW = dy.shape

@@ -447,9 +447,10 @@ def test_ins_res_block_uses_fused_tail(cuda, monkeypatch):
 
 @pytest.mark.parametrize("act", [0, 1, 2])
 @pytest.mark.parametrize("shape", [(4, 128, 64, 64), (4, 64, 128, 128), (2, 3, 32, 128), (1, 2, 128, 32)])
-def test_norm_and_upsample_in_one_launch_equals_two(cuda, shape, act):
-    """Upsample2x(act(InstanceNorm(x))) as ONE launch (autograd_ops.InstanceNormUpFn: the normalised plane goes to LDS, the same
-    workgroup writes the 2H x 2W map) against InstanceNormFn -> Upsample2xFn: output and gradient bit for bit"""
+def test_norm_and_upsample_in_one_launch_equals_two(cuda, shape, act, monkeypatch):
+    """Upsample2x(act(InstanceNorm(x))) as ONE launch each way (autograd_ops.InstanceNormUpFn: the normalised plane goes to LDS, the
+    same workgroup writes the 2H x 2W map; backward: the bilinear gather hands the small plane's gradient to the norm's backward in
+    registers) against InstanceNormFn -> Upsample2xFn: output and gradient bit for bit"""
     from scda_amd import autograd_ops as A, native as N
     g = gen(93)
     x = torch.randn(*shape, generator=g).to(cuda)
@@ -460,6 +461,10 @@ def test_norm_and_upsample_in_one_launch_equals_two(cuda, shape, act):
     x2 = x.clone().requires_grad_()
     y2 = A.Upsample2xFn.apply(A.InstanceNormFn.apply(x2, 1e-5, act, 0.01)); y2.backward(dy)
     assert y1.shape == y2.shape and torch.equal(y1, y2) and torch.equal(x1.grad, x2.grad)
+    monkeypatch.setenv("SCDA_NO_NORM_UP_BWD_FUSION", "1")          # the forward fused, the backward as the two launches
+    x3 = x.clone().requires_grad_()
+    A.InstanceNormUpFn.apply(x3, 1e-5, act, 0.01).backward(dy)
+    assert torch.equal(x3.grad, x2.grad)
 
 
 @pytest.mark.parametrize("shape", [(4, 128, 64, 64), (2, 5, 128, 128)])
